@@ -1,0 +1,406 @@
+/*
+ * nfagg.h — C ABI of libnfagg, the MI355X (gfx950) flow-aggregation backend.
+ *
+ * This header is the drop-in boundary behind netobserv-ebpf-agent's userspace
+ * flow stage. Every entry point names the reference interface it replaces
+ * (paths relative to the reference repository root). The reference-side cgo
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Rules of the boundary:
+ *   - plain C, plain pointers and sizes; no callbacks into the caller, no
+ *     pointer retained after a call returns (cgo pointer rules);
+ *   - the caller owns input buffers until the call returns, the library owns
+ *     the flow table, eviction output goes into caller-provided buffers;
+ *   - one producer per handle; calls on a handle are synchronous and must not
+ *     overlap (exactly one goroutine runs Accounter.Account, account.go:58);
+ *   - return value 0 = NFAGG_OK, >0 = a condition the caller must act on,
+ *     <0 = error (nfagg_last_error gives the text). No Go-visible panics.
+ *
+ * There is NO CPU fallback behind this ABI: if the HIP runtime or a gfx950
+ * device is missing, nfagg_create fails with NFAGG_ENODEV.
+ */
+#ifndef NFAGG_H
+#define NFAGG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFAGG_ABI_VERSION 1u
+
+/* ------------------------------------------------------------------ */
+/* Record ABI — byte-for-byte the structs of bpf/types.h               */
+/* ------------------------------------------------------------------ */
+
+/* bpf/types.h:191-204 flow_id; pkg/ebpf/bpf_x86_bpfel.go:108-120 BpfFlowId.
+ * 40 bytes, alignment 2. Byte 39 is padding: the library zeroes it on ingest
+ * (the kernel memsets it, bpf/flows.c:177-178; Go ignores it). */
+typedef struct nfagg_flow_id {
+    uint8_t  src_ip[16];          /* IPv4 as ::ffff:a.b.c.d */
+    uint8_t  dst_ip[16];
+    uint16_t src_port;            /* host endian */
+    uint16_t dst_port;
+    uint8_t  transport_protocol;
+    uint8_t  icmp_type;
+    uint8_t  icmp_code;
+    uint8_t  pad_;
+} nfagg_flow_id;
+
+/* bpf/types.h:94-126 flow_metrics; bpf_x86_bpfel.go:122-153 BpfFlowMetrics.
+ * 104 bytes, alignment 8. */
+typedef struct nfagg_flow_metrics {
+    uint64_t start_mono_time_ts;  /* @0  */
+    uint64_t end_mono_time_ts;    /* @8  */
+    uint64_t bytes;               /* @16 */
+    uint32_t packets;             /* @24 */
+    uint16_t eth_protocol;        /* @28 */
+    uint16_t flags;               /* @30 */
+    uint8_t  src_mac[6];          /* @32 */
+    uint8_t  dst_mac[6];          /* @38 */
+    uint32_t if_index_first_seen; /* @44 */
+    uint32_t lock;                /* @48 struct bpf_spin_lock */
+    uint32_t sampling;            /* @52 */
+    uint8_t  direction_first_seen;/* @56 */
+    uint8_t  errno_;              /* @57 */
+    uint8_t  dscp;                /* @58 */
+    uint8_t  nb_observed_intf;    /* @59 */
+    uint8_t  observed_direction[6];/* @60 */
+    uint8_t  pad2_[2];            /* @66 */
+    uint32_t observed_intf[6];    /* @68 */
+    uint16_t ssl_version;         /* @92 */
+    uint16_t tls_cipher_suite;    /* @94 */
+    uint16_t tls_key_share;       /* @96 */
+    uint8_t  tls_types;           /* @98 */
+    uint8_t  misc_flags;          /* @99 */
+    uint8_t  pad4_[4];            /* @100 */
+} nfagg_flow_metrics;
+
+/* bpf/types.h:212-215 flow_record; pkg/model/record.go:63 RawRecord.
+ * 144 bytes — the unit on the ring buffer (byte-exact vector:
+ * pkg/model/record_test.go:19-102). */
+typedef struct nfagg_flow_record {
+    nfagg_flow_id      id;        /* @0  */
+    nfagg_flow_metrics metrics;   /* @40 */
+} nfagg_flow_record;
+
+/* bpf/types.h:174-181 additional_metrics (RTT / IPsec). 32 bytes. */
+typedef struct nfagg_additional_metrics {
+    uint64_t start_mono_time_ts;
+    uint64_t end_mono_time_ts;
+    uint64_t flow_rtt;
+    int32_t  ipsec_encrypted_ret;
+    uint16_t eth_protocol;
+    uint8_t  ipsec_encrypted;     /* bool */
+    uint8_t  pad_;
+} nfagg_additional_metrics;
+
+/* bpf/types.h:131-140 dns_metrics. 64 bytes (name is NOT 2-aligned). */
+typedef struct nfagg_dns_metrics {
+    uint64_t start_mono_time_ts;
+    uint64_t end_mono_time_ts;
+    uint64_t latency;
+    uint16_t id;
+    uint16_t flags;
+    uint16_t eth_protocol;
+    uint8_t  errno_;
+    char     name[32];
+    uint8_t  pad_;
+} nfagg_dns_metrics;
+
+/* bpf/types.h:142-151 pkt_drop_metrics. 32 bytes. */
+typedef struct nfagg_pkt_drop_metrics {
+    uint64_t start_mono_time_ts;
+    uint64_t end_mono_time_ts;
+    uint16_t bytes;
+    uint16_t packets;
+    uint32_t latest_drop_cause;
+    uint16_t latest_flags;
+    uint16_t eth_protocol;
+    uint8_t  latest_state;
+    uint8_t  pad_[3];
+} nfagg_pkt_drop_metrics;
+
+/* bpf/types.h:153-161 network_events_metrics. 72 bytes. */
+typedef struct nfagg_network_events_metrics {
+    uint64_t start_mono_time_ts;
+    uint64_t end_mono_time_ts;
+    uint8_t  network_events[4][8];
+    uint16_t bytes[4];
+    uint16_t packets[4];
+    uint16_t eth_protocol;
+    uint8_t  network_events_idx;
+    uint8_t  pad_[5];
+} nfagg_network_events_metrics;
+
+/* bpf/types.h:163-172 xlat_metrics. 56 bytes. */
+typedef struct nfagg_xlat_metrics {
+    uint64_t start_mono_time_ts;
+    uint64_t end_mono_time_ts;
+    uint8_t  saddr[16];
+    uint8_t  daddr[16];
+    uint16_t sport;
+    uint16_t dport;
+    uint16_t zone_id;
+    uint16_t eth_protocol;
+} nfagg_xlat_metrics;
+
+/* bpf/types.h quic_metrics_t. 24 bytes. */
+typedef struct nfagg_quic_metrics {
+    uint64_t start_mono_time_ts;
+    uint64_t end_mono_time_ts;
+    uint32_t version;
+    uint16_t eth_protocol;
+    uint8_t  seen_long_hdr;
+    uint8_t  seen_short_hdr;
+} nfagg_quic_metrics;
+
+/* ------------------------------------------------------------------ */
+/* Status codes                                                         */
+/* ------------------------------------------------------------------ */
+enum {
+    NFAGG_OK       = 0,
+    /* >0: the caller must act, nothing went wrong */
+    NFAGG_FULL     = 1,  /* ingest stopped before a record whose NEW key would
+                            exceed max_entries (account.go:85): evict with
+                            NFAGG_REASON_FULL, then resubmit the remainder */
+    NFAGG_TRUNCATED = 2, /* output buffer smaller than the result */
+    /* <0: errors */
+    NFAGG_EINVAL   = -1,
+    NFAGG_ENODEV   = -2, /* no HIP runtime / no gfx950 device: there is no CPU path */
+    NFAGG_ENOMEM   = -3,
+    NFAGG_EDEVICE  = -4, /* a HIP call failed; see nfagg_last_error */
+    NFAGG_ESTATE   = -5, /* call not valid in the handle's current state */
+    NFAGG_ERANGE   = -6, /* per-epoch sequence space exhausted */
+};
+
+/* Eviction reasons — the label values of the reference's Prometheus counters
+ * (pkg/flow/account.go:71,78,90; pkg/metrics/metrics.go). */
+enum {
+    NFAGG_REASON_TIMEOUT = 0,   /* "timeout" */
+    NFAGG_REASON_FULL    = 1,   /* "full"    */
+    NFAGG_REASON_CLOSING = 2,   /* "closing" */
+};
+
+/* Accumulation semantics of the flow table. */
+enum {
+    /* pkg/model/flow_content.go:28-61 AccumulateBase, first record of a key
+     * stored whole (account.go:95). This is what Accounter does. */
+    NFAGG_MODE_ACCOUNTER = 0,
+    /* bpf/flows.c:98-143 update_existing_flow + :76-96 add_observed_intf:
+     * bytes/packets counted only on if_index_first_seen, other interfaces are
+     * appended to observed_intf[] ("direction dedup"). */
+    NFAGG_MODE_KERNEL_DEDUP = 1,
+};
+
+enum {
+    NFAGG_SKETCH_CM  = 1u,  /* Count-Min over src IP and dst IP, adding bytes */
+    NFAGG_SKETCH_HLL = 2u,  /* HyperLogLog over src IP and dst IP */
+};
+
+/* Sketch identifiers for snapshot / device-pointer / estimate calls. */
+enum {
+    NFAGG_CM_SRC  = 0,   /* uint64_t[cm_depth << cm_log2_width] */
+    NFAGG_CM_DST  = 1,
+    NFAGG_HLL_SRC = 2,   /* uint8_t [1 << hll_p] in snapshots; uint32_t on device */
+    NFAGG_HLL_DST = 3,
+};
+
+/* ------------------------------------------------------------------ */
+/* Handle and configuration                                             */
+/* ------------------------------------------------------------------ */
+typedef struct nfagg_handle nfagg_handle;
+
+/* Replaces the arguments of flow.NewAccounter (pkg/flow/account.go:34-53;
+ * call site pkg/agent/agent.go:208-212). Clocks, Prometheus metrics and the
+ * OVN sample decoder stay on the Go side. Zero = default for every field
+ * except struct_size. */
+typedef struct nfagg_config {
+    uint32_t struct_size;        /* sizeof(nfagg_config); ABI guard */
+    int32_t  device;             /* HIP device ordinal */
+    uint64_t max_entries;        /* CACHE_MAX_FLOWS (config.go:146); 0 -> 5000 */
+    uint32_t table_log2_slots;   /* 0 -> smallest 2^k >= 2*max_entries (min 2^10) */
+    uint32_t mode;               /* NFAGG_MODE_* */
+    uint32_t sketch_flags;       /* NFAGG_SKETCH_* */
+    uint32_t cm_depth;           /* 0 -> 4  (1..8) */
+    uint32_t cm_log2_width;      /* 0 -> 20 */
+    uint32_t hll_p;              /* 0 -> 14 (4..18) */
+    uint64_t staging_records;    /* pinned staging ring, records per buffer; 0 -> 1<<20 */
+    uint32_t n_shards;           /* 0/1 -> unsharded. Records whose
+                                    nfagg_shard_of(id,n_shards) != shard_id are
+                                    skipped on ingest and counted in stats */
+    uint32_t shard_id;
+    uint32_t profile;            /* 1 -> bracket kernels with HIP events (stats) */
+    uint32_t ingest_variant;     /* 0 -> default kernel; others: see DESIGN.md */
+    /* Optional caller-owned DEVICE buffers for the sketches (so that another
+     * library, e.g. RCCL via torch.distributed, can all-reduce them in place).
+     * NULL -> the library allocates. Sizes as listed under NFAGG_CM_* above,
+     * HLL buffers hold uint32_t registers. */
+    void*    ext_sketch[4];
+} nfagg_config;
+
+typedef struct nfagg_stats {
+    uint64_t records_ingested;   /* accepted into the table (this shard) */
+    uint64_t records_skipped;    /* not this shard */
+    uint64_t entries;            /* live keys now  (accounter-entries gauge, account.go:98) */
+    uint64_t evictions[3];       /* per NFAGG_REASON_* (evictions_total) */
+    uint64_t evicted_flows[3];   /* per reason (evicted_flows_total) */
+    uint64_t epoch_seq;          /* records ingested since the last eviction */
+    uint64_t table_slots;
+    uint64_t table_bytes;
+    /* filled when cfg.profile != 0 (HIP events on the handle's stream) */
+    uint64_t ingest_launches;
+    double   ingest_kernel_ms;   /* sum of ingest-kernel durations */
+    uint64_t evict_launches;
+    double   evict_kernel_ms;
+    uint64_t sketch_launches;
+    double   sketch_kernel_ms;
+    uint64_t max_probe;          /* longest probe sequence seen at eviction scans (0 if untracked) */
+} nfagg_stats;
+
+uint32_t nfagg_abi_version(void);
+
+/* Replaces flow.NewAccounter (pkg/flow/account.go:34-53). */
+int nfagg_create(const nfagg_config* cfg, nfagg_handle** out);
+
+/* Replaces nothing in the reference (Go GC frees the Accounter); required by
+ * C ownership. Pending flows are discarded: evict with NFAGG_REASON_CLOSING
+ * first (account.go:73-80). */
+void nfagg_destroy(nfagg_handle* h);
+
+/* Text of the last error on this handle (NULL handle: last create error). */
+const char* nfagg_last_error(const nfagg_handle* h);
+
+/* ------------------------------------------------------------------ */
+/* Ingest — replaces the `case record, ok := <-in` arm of               */
+/* Accounter.Account (pkg/flow/account.go:72-96), batched.              */
+/* ------------------------------------------------------------------ */
+
+/* records: n x 144-byte flow_record_t in HOST memory (what
+ * model.ReadFrom decodes, pkg/model/record.go:227-231), in arrival order.
+ * The records are folded in exactly that order. *consumed = number of
+ * leading records folded; returns NFAGG_FULL when it stopped early. */
+int nfagg_ingest(nfagg_handle* h, const void* records, size_t n, size_t* consumed);
+
+/* Same, records already in DEVICE memory of cfg.device (16-byte aligned). */
+int nfagg_ingest_device(nfagg_handle* h, const void* d_records, size_t n, size_t* consumed);
+
+/* Zero-copy producer path: borrow the next pinned staging buffer
+ * (capacity = cfg.staging_records), fill it (e.g. straight from the eBPF ring,
+ * pkg/flow/tracer_ringbuf.go:112-134), then commit the first n records.
+ * commit has nfagg_ingest semantics. */
+int nfagg_staging_acquire(nfagg_handle* h, void** buf, size_t* capacity_records);
+int nfagg_staging_commit(nfagg_handle* h, size_t n, size_t* consumed);
+
+/* len(c.entries) (account.go:85,98). Synchronises with the device. */
+int nfagg_len(nfagg_handle* h, uint64_t* entries);
+
+/* ------------------------------------------------------------------ */
+/* Evict — replaces Accounter.evict (pkg/flow/account.go:102-124) up to */
+/* the point where model.NewRecord is called per entry.                 */
+/* ------------------------------------------------------------------ */
+
+/* Writes every live flow as one 144-byte flow_record_t {id, folded metrics}
+ * into `out` (HOST memory, room for `cap` records), clears the table, starts
+ * a new epoch. Order of records is unspecified (Go map order is random;
+ * the reference's tests compare by key, account_test.go:94-98).
+ * If cap < live entries nothing is evicted: *n_out = live entries and
+ * NFAGG_TRUNCATED is returned. The caller turns each record into a
+ * model.Record with model.NewRecord(key, &content, now, mono, ...)
+ * exactly as account.go:116-119 (helper: nfagg_record_times). */
+int nfagg_evict(nfagg_handle* h, int reason, void* out, size_t cap, size_t* n_out);
+
+/* Same with `d_out` in DEVICE memory. */
+int nfagg_evict_device(nfagg_handle* h, int reason, void* d_out, size_t cap, size_t* n_out);
+
+/* pkg/model/record.go:90-97: TimeFlowStart = now - (mono_now - start_mono),
+ * TimeFlowEnd likewise; uint64 wrap then signed nanoseconds, as Go does.
+ * now_unix_ns is the wall clock in ns since the Unix epoch. */
+void nfagg_record_times(int64_t now_unix_ns, uint64_t mono_now_ns,
+                        const nfagg_flow_metrics* m,
+                        int64_t* time_flow_start_unix_ns,
+                        int64_t* time_flow_end_unix_ns);
+
+/* ------------------------------------------------------------------ */
+/* Per-CPU map rollup — replaces lookupAndDeletePerCPUMap's accumulator */
+/* closures (pkg/tracer/tracer.go:1057-1110,1118-1146).                 */
+/* ------------------------------------------------------------------ */
+
+/* For each of n_flows flows: fold n_cpu per-CPU partials (CPU index
+ * ascending; element 0 adopted whole, elements 1.. folded into it) with the
+ * matching model.Accumulate* (pkg/model/flow_content.go), and apply
+ * buildBaseFromAdditional (flow_content.go:63-74) to base[i] for every
+ * partial. `base` is in/out: the caller passes the flow's base metrics from
+ * the main map, or zeroes when the main map had no entry
+ * (tracer.go:1136-1139). All pointers are HOST memory.
+ *   partials: n_flows * n_cpu structs, flow-major
+ *   folded:   n_flows structs */
+int nfagg_rollup_additional(nfagg_handle* h, const nfagg_additional_metrics* partials,
+                            size_t n_flows, size_t n_cpu,
+                            nfagg_flow_metrics* base, nfagg_additional_metrics* folded);
+int nfagg_rollup_dns(nfagg_handle* h, const nfagg_dns_metrics* partials,
+                     size_t n_flows, size_t n_cpu,
+                     nfagg_flow_metrics* base, nfagg_dns_metrics* folded);
+int nfagg_rollup_drops(nfagg_handle* h, const nfagg_pkt_drop_metrics* partials,
+                       size_t n_flows, size_t n_cpu,
+                       nfagg_flow_metrics* base, nfagg_pkt_drop_metrics* folded);
+int nfagg_rollup_network_events(nfagg_handle* h, const nfagg_network_events_metrics* partials,
+                                size_t n_flows, size_t n_cpu,
+                                nfagg_flow_metrics* base, nfagg_network_events_metrics* folded);
+int nfagg_rollup_xlat(nfagg_handle* h, const nfagg_xlat_metrics* partials,
+                      size_t n_flows, size_t n_cpu,
+                      nfagg_flow_metrics* base, nfagg_xlat_metrics* folded);
+int nfagg_rollup_quic(nfagg_handle* h, const nfagg_quic_metrics* partials,
+                      size_t n_flows, size_t n_cpu,
+                      nfagg_flow_metrics* base, nfagg_quic_metrics* folded);
+
+/* ------------------------------------------------------------------ */
+/* Sketches — new functionality (no reference counterpart; spec in      */
+/* DESIGN.md §sketches, scalar oracle in oracle/).                      */
+/* ------------------------------------------------------------------ */
+
+/* Copy a sketch to HOST memory. CM: uint64_t[depth<<log2w]; HLL: uint8_t[1<<p]. */
+int nfagg_sketch_snapshot(nfagg_handle* h, int which, void* out, size_t out_bytes);
+/* Device pointer and byte size of a sketch array (for in-place RCCL all-reduce:
+ * CM sum uint64, HLL max uint32). */
+int nfagg_sketch_device_ptr(nfagg_handle* h, int which, void** d_ptr, size_t* bytes);
+/* Zero all sketches (start of a sketch window). */
+int nfagg_sketch_reset(nfagg_handle* h);
+/* Cardinality from the device registers: integer histogram of register values
+ * computed on the GPU, FP64 estimate from the histogram in a fixed order.
+ * which = NFAGG_HLL_SRC / NFAGG_HLL_DST. */
+int nfagg_hll_estimate(nfagg_handle* h, int which, double* estimate);
+/* Count-Min point query for one 16-byte IP: min over rows. Host-side read of
+ * d counters. which = NFAGG_CM_SRC / NFAGG_CM_DST. */
+int nfagg_cm_query(nfagg_handle* h, int which, const uint8_t ip[16], uint64_t* estimate);
+/* The HLL estimator itself, on a host histogram hist[0..64] of register
+ * values for m = 1<<p registers (exposed so callers can estimate after a
+ * cross-GPU max-merge). */
+double nfagg_hll_estimate_from_histogram(const uint32_t* hist, uint32_t p);
+
+/* ------------------------------------------------------------------ */
+/* Sharding, stats, sync                                                */
+/* ------------------------------------------------------------------ */
+
+/* Shard of a flow key: the function that routes records to GPUs
+ * (hash of the 40 key bytes with byte 39 forced to 0). */
+uint32_t nfagg_shard_of(const nfagg_flow_id* id, uint32_t n_shards);
+/* The 64-bit key hash itself (table index / fingerprint / shard all derive from it). */
+uint64_t nfagg_key_hash(const nfagg_flow_id* id);
+/* The 64-bit hash of a 16-byte IP with the given seed index (0..3), as used by
+ * the sketches. */
+uint64_t nfagg_ip_hash(const uint8_t ip[16], uint32_t seed_index);
+
+int nfagg_stats_get(nfagg_handle* h, nfagg_stats* out);
+int nfagg_stats_reset_profile(nfagg_handle* h);
+/* Wait until all submitted work of this handle has finished. */
+int nfagg_sync(nfagg_handle* h);
+/* The hipStream_t the handle launches on (as void*), for event timing by the caller. */
+void* nfagg_stream(nfagg_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFAGG_H */

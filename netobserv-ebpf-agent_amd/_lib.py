@@ -1,0 +1,104 @@
+"""ctypes binding of libnfagg.so (include/nfagg.h). There is no fallback: if the
+HIP library has not been built, importing this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnfagg.so")
+SYNTH_PATH = os.path.join(_HERE, "lib", "libnfagg_synth.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+        "(or __graft_entry__.build()). libnfagg has no CPU/Python fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+OK, FULL, TRUNCATED = 0, 1, 2
+EINVAL, ENODEV, ENOMEM, EDEVICE, ESTATE, ERANGE = -1, -2, -3, -4, -5, -6
+REASON_TIMEOUT, REASON_FULL, REASON_CLOSING = 0, 1, 2
+REASON_NAMES = {0: "timeout", 1: "full", 2: "closing"}
+MODE_ACCOUNTER, MODE_KERNEL_DEDUP = 0, 1
+SKETCH_CM, SKETCH_HLL = 1, 2
+CM_SRC, CM_DST, HLL_SRC, HLL_DST = 0, 1, 2, 3
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32), ("max_entries", C.c_uint64),
+        ("table_log2_slots", C.c_uint32), ("mode", C.c_uint32), ("sketch_flags", C.c_uint32),
+        ("cm_depth", C.c_uint32), ("cm_log2_width", C.c_uint32), ("hll_p", C.c_uint32),
+        ("staging_records", C.c_uint64), ("n_shards", C.c_uint32), ("shard_id", C.c_uint32),
+        ("profile", C.c_uint32), ("ingest_variant", C.c_uint32), ("ext_sketch", C.c_void_p * 4),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("records_ingested", C.c_uint64), ("records_skipped", C.c_uint64), ("entries", C.c_uint64),
+        ("evictions", C.c_uint64 * 3), ("evicted_flows", C.c_uint64 * 3), ("epoch_seq", C.c_uint64),
+        ("table_slots", C.c_uint64), ("table_bytes", C.c_uint64),
+        ("ingest_launches", C.c_uint64), ("ingest_kernel_ms", C.c_double),
+        ("evict_launches", C.c_uint64), ("evict_kernel_ms", C.c_double),
+        ("sketch_launches", C.c_uint64), ("sketch_kernel_ms", C.c_double), ("max_probe", C.c_uint64),
+    ]
+
+
+_vp, _sz, _psz = C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)
+
+# every symbol include/nfagg.h declares, with its signature
+SIGNATURES = {
+    "nfagg_abi_version": (C.c_uint32, []),
+    "nfagg_create": (C.c_int, [C.POINTER(Config), C.POINTER(_vp)]),
+    "nfagg_destroy": (None, [_vp]),
+    "nfagg_last_error": (C.c_char_p, [_vp]),
+    "nfagg_ingest": (C.c_int, [_vp, _vp, _sz, _psz]),
+    "nfagg_ingest_device": (C.c_int, [_vp, _vp, _sz, _psz]),
+    "nfagg_staging_acquire": (C.c_int, [_vp, C.POINTER(_vp), _psz]),
+    "nfagg_staging_commit": (C.c_int, [_vp, _sz, _psz]),
+    "nfagg_len": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "nfagg_evict": (C.c_int, [_vp, C.c_int, _vp, _sz, _psz]),
+    "nfagg_evict_device": (C.c_int, [_vp, C.c_int, _vp, _sz, _psz]),
+    "nfagg_record_times": (None, [C.c_int64, C.c_uint64, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "nfagg_rollup_additional": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "nfagg_rollup_dns": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "nfagg_rollup_drops": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "nfagg_rollup_network_events": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "nfagg_rollup_xlat": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "nfagg_rollup_quic": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "nfagg_sketch_snapshot": (C.c_int, [_vp, C.c_int, _vp, _sz]),
+    "nfagg_sketch_device_ptr": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _psz]),
+    "nfagg_sketch_reset": (C.c_int, [_vp]),
+    "nfagg_hll_estimate": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
+    "nfagg_cm_query": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(C.c_uint64)]),
+    "nfagg_hll_estimate_from_histogram": (C.c_double, [_vp, C.c_uint32]),
+    "nfagg_shard_of": (C.c_uint32, [_vp, C.c_uint32]),
+    "nfagg_key_hash": (C.c_uint64, [_vp]),
+    "nfagg_ip_hash": (C.c_uint64, [_vp, C.c_uint32]),
+    "nfagg_stats_get": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "nfagg_stats_reset_profile": (C.c_int, [_vp]),
+    "nfagg_sync": (C.c_int, [_vp]),
+    "nfagg_stream": (_vp, [_vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)   # AttributeError here = the .so does not export the ABI
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def load_synth():
+    """libnfagg_synth.so: device-side synthetic stream generator (bench/test support)."""
+    if not os.path.exists(SYNTH_PATH):
+        raise ImportError(f"{SYNTH_PATH} is missing: build with make -C {os.path.join(_HERE, 'csrc')}")
+    s = C.CDLL(SYNTH_PATH)
+    u64 = C.c_uint64
+    s.nfagg_synth_stream.restype = C.c_int
+    s.nfagg_synth_stream.argtypes = [_vp, u64, u64, u64, u64, _vp, C.c_uint32, C.c_uint32, _vp, _vp]
+    s.nfagg_synth_zipf_thresholds.restype = None
+    s.nfagg_synth_zipf_thresholds.argtypes = [u64, C.c_double, _vp]
+    s.nfagg_synth_shard_population.restype = None
+    s.nfagg_synth_shard_population.argtypes = [u64, C.c_uint32, C.c_uint32, _vp]
+    s.nfagg_synth_stream_host.restype = None
+    s.nfagg_synth_stream_host.argtypes = [_vp, u64, u64, u64, u64, _vp, C.c_uint32, C.c_uint32, _vp]
+    return s

@@ -1,0 +1,696 @@
+// nfagg_api.hip — the C ABI of libnfagg (include/nfagg.h): handle, pinned
+// staging ring, batch control flow of Accounter.Account
+// (pkg/flow/account.go:58-100) around the kernels. No CPU fallback: without a
+// gfx950 device nfagg_create fails.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/nfagg.h"
+#include "nfagg_internal.h"
+
+using namespace nfagg;
+
+static_assert(sizeof(nfagg_flow_id) == 40, "flow_id");
+static_assert(sizeof(nfagg_flow_metrics) == 104, "flow_metrics");
+static_assert(sizeof(nfagg_flow_record) == 144, "flow_record");
+static_assert(sizeof(nfagg_additional_metrics) == 32, "additional");
+static_assert(sizeof(nfagg_dns_metrics) == 64, "dns");
+static_assert(sizeof(nfagg_pkt_drop_metrics) == 32, "drops");
+static_assert(sizeof(nfagg_network_events_metrics) == 72, "netev");
+static_assert(sizeof(nfagg_xlat_metrics) == 56, "xlat");
+static_assert(sizeof(nfagg_quic_metrics) == 24, "quic");
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+}  // namespace
+
+struct nfagg_handle {
+    nfagg_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint64_t slots = 0;
+    TableView tv{};
+    SketchView sk{};
+    bool own_sketch[4] = {false, false, false, false};
+    DevCounters* h_ctr = nullptr;       // pinned mirror
+    // staging ring (host ingest path)
+    void* pinned[2] = {nullptr, nullptr};
+    void* d_stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_free[2] = {nullptr, nullptr};
+    int stage_next = 0;
+    bool stage_acquired = false;
+    // careful-path scratch
+    uint64_t careful_chunk = 0;
+    uint32_t* d_slot_idx = nullptr;
+    uint8_t* d_flags = nullptr;
+    uint32_t* d_block_counts = nullptr;
+    std::vector<uint32_t> h_block_counts;
+    // eviction buffer (device)
+    void* d_evict = nullptr;
+    uint64_t d_evict_cap = 0;
+    // rollup scratch
+    void* d_roll[3] = {nullptr, nullptr, nullptr};
+    size_t d_roll_cap[3] = {0, 0, 0};
+    uint32_t* d_hist = nullptr;
+    // accounting
+    uint64_t epoch_seq = 0;
+    uint64_t live = 0;       // exact when live_exact
+    uint64_t live_ub = 0;    // upper bound on the device's n_live
+    bool must_evict = false; // a "full" split is pending (account.go:85-94)
+    uint64_t split_seq = 0;
+    nfagg_stats stats{};
+    std::vector<EventPair> ev_pending;
+    std::vector<EventPair> ev_free;
+    std::string err;
+};
+
+namespace {
+
+int fail(nfagg_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((h), NFAGG_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
+
+// --- profiling: HIP events on the handle's stream around the dominant kernels
+void prof_begin(nfagg_handle* h, EventPair& ep, int kind) {
+    if (h->ev_free.empty()) {
+        hipEventCreate(&ep.a); hipEventCreate(&ep.b);
+    } else { ep = h->ev_free.back(); h->ev_free.pop_back(); }
+    ep.kind = kind;
+    hipEventRecord(ep.a, h->stream);
+}
+void prof_end(nfagg_handle* h, EventPair& ep) {
+    hipEventRecord(ep.b, h->stream);
+    h->ev_pending.push_back(ep);
+}
+void prof_resolve(nfagg_handle* h) {
+    for (auto& ep : h->ev_pending) {
+        hipEventSynchronize(ep.b);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, ep.a, ep.b);
+        if (ep.kind == 0) { h->stats.ingest_kernel_ms += ms; h->stats.ingest_launches++; }
+        else if (ep.kind == 1) { h->stats.evict_kernel_ms += ms; h->stats.evict_launches++; }
+        else { h->stats.sketch_kernel_ms += ms; h->stats.sketch_launches++; }
+        h->ev_free.push_back(ep);
+    }
+    h->ev_pending.clear();
+}
+
+int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t seq_base) {
+    EventPair ep{};
+    const bool prof = h->cfg.profile != 0;
+    if (prof) { if (h->ev_pending.size() >= 8192) prof_resolve(h); prof_begin(h, ep, 0); }
+    hipError_t e = launch_ingest(h->tv, d, n, seq_base, (int)h->cfg.mode, (int)h->cfg.ingest_variant, h->stream);
+    if (prof) prof_end(h, ep);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "ingest launch failed: %s", hipGetErrorString(e));
+    if (h->sk.flags) {
+        if (prof) prof_begin(h, ep, 2);
+        e = launch_sketch_update(h->sk, h->tv, d, n, h->stream);
+        if (prof) prof_end(h, ep);
+        if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "sketch launch failed: %s", hipGetErrorString(e));
+    }
+    return NFAGG_OK;
+}
+
+// Bring the device counters to the host (synchronises the stream).
+int refresh_counters(nfagg_handle* h) {
+    HIP_TRY(h, hipMemcpyAsync(h->h_ctr, h->tv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->h_ctr->error) return fail(h, NFAGG_EDEVICE, "flow table probe overflow (table too small for the live key set)");
+    h->live_ub = h->h_ctr->n_live;
+    if (!h->must_evict) h->live = h->h_ctr->n_live;
+    h->stats.records_skipped = h->h_ctr->n_skipped;
+    if (h->h_ctr->max_probe > h->stats.max_probe) h->stats.max_probe = h->h_ctr->max_probe;
+    return NFAGG_OK;
+}
+
+// The record arm of Accounter.Account (account.go:81-96) for a device-resident batch.
+int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t* consumed_out) {
+    size_t consumed = 0;
+    const uint64_t maxe = h->cfg.max_entries;
+    const char* base = static_cast<const char*>(d_records);
+    int rc = NFAGG_OK;
+    if (h->must_evict) { if (consumed_out) *consumed_out = 0; return n ? NFAGG_FULL : NFAGG_OK; }
+    while (consumed < n) {
+        const uint64_t rem = n - consumed;
+        if (h->epoch_seq + rem >= 0xFFFFFFF0ull) {
+            rc = fail(h, NFAGG_ERANGE, "more than 2^32-16 records in one eviction epoch; evict first");
+            break;
+        }
+        const void* d = base + consumed * kRecordBytes;
+        if (h->live_ub + rem <= maxe) {
+            // no record of this batch can find len(entries) >= maxEntries (account.go:85)
+            if ((rc = launch_ingest_profiled(h, d, rem, h->epoch_seq)) != NFAGG_OK) break;
+            h->live_ub += rem; h->epoch_seq += rem; consumed += rem;
+            h->stats.records_ingested += rem;
+            break;
+        }
+        if ((rc = refresh_counters(h)) != NFAGG_OK) break;
+        const uint64_t room = maxe > h->live ? maxe - h->live : 0;
+        if (room >= rem) continue;
+        if (room >= 65536 || (room > 0 && room >= rem / 4)) {
+            // the first `room` records cannot overflow either
+            if ((rc = launch_ingest_profiled(h, d, room, h->epoch_seq)) != NFAGG_OK) break;
+            h->live_ub += room; h->epoch_seq += room; consumed += room;
+            h->stats.records_ingested += room;
+            continue;
+        }
+        // ---- careful path: the split point may lie inside this chunk
+        const uint64_t chunk = rem < h->careful_chunk ? rem : h->careful_chunk;
+        const uint64_t seq0 = h->epoch_seq;
+        hipError_t e = launch_claim(h->tv, d, chunk, seq0, h->d_slot_idx, h->stream);
+        if (e == hipSuccess) e = launch_first_flags(h->tv, h->d_slot_idx, chunk, seq0, h->d_flags, h->d_block_counts, h->stream);
+        if (e != hipSuccess) { rc = fail(h, NFAGG_EDEVICE, "claim launch failed: %s", hipGetErrorString(e)); break; }
+        const uint64_t nblk = (chunk + kFlagBlock - 1) / kFlagBlock;
+        h->h_block_counts.resize(nblk);
+        e = hipMemcpyAsync(h->h_block_counts.data(), h->d_block_counts, nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { rc = fail(h, NFAGG_EDEVICE, "claim sync failed: %s", hipGetErrorString(e)); break; }
+        uint64_t total_new = 0;
+        for (uint64_t b = 0; b < nblk; b++) total_new += h->h_block_counts[b];
+        if (h->live + total_new <= maxe) {
+            if ((rc = launch_ingest_profiled(h, d, chunk, seq0)) != NFAGG_OK) break;
+            h->live += total_new; h->live_ub = h->live; h->epoch_seq += chunk; consumed += chunk;
+            h->stats.records_ingested += chunk;
+            continue;
+        }
+        // The (room+1)-th new key of the chunk arrives with the table full:
+        // everything before it is folded, then the caller must evict ("full").
+        uint64_t want = room + 1, blk = 0, before = 0;
+        while (before + h->h_block_counts[blk] < want) { before += h->h_block_counts[blk]; blk++; }
+        uint8_t fl[kFlagBlock];
+        const uint64_t off = blk * kFlagBlock;
+        const uint64_t cnt = (chunk - off) < (uint64_t)kFlagBlock ? (chunk - off) : (uint64_t)kFlagBlock;
+        e = hipMemcpy(fl, h->d_flags + off, cnt, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(h, NFAGG_EDEVICE, "flag copy failed: %s", hipGetErrorString(e)); break; }
+        uint64_t split = off;
+        for (uint64_t k = 0; k < cnt; k++) {
+            if (fl[k]) { before++; if (before == want) { split = off + k; break; } }
+        }
+        if (split > 0 && (rc = launch_ingest_profiled(h, d, split, seq0)) != NFAGG_OK) break;
+        h->epoch_seq += split; consumed += split;
+        h->stats.records_ingested += split;
+        h->live = maxe > h->live ? maxe : h->live;   // len(entries) == maxEntries now
+        h->live_ub = h->live + (total_new - room);
+        h->must_evict = true;
+        h->split_seq = seq0 + split;
+        rc = NFAGG_FULL;
+        break;
+    }
+    if (consumed_out) *consumed_out = consumed;
+    return rc;
+}
+
+int ensure_bytes(nfagg_handle* h, void** p, size_t* cap, size_t need) {
+    if (*cap >= need) return NFAGG_OK;
+    if (*p) { hipFree(*p); *p = nullptr; *cap = 0; }
+    size_t want = need + need / 4 + 4096;
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) return fail(h, NFAGG_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    *cap = want;
+    return NFAGG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t nfagg_abi_version(void) { return NFAGG_ABI_VERSION; }
+
+const char* nfagg_last_error(const nfagg_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
+    if (!cfg_in || !out) return fail(nullptr, NFAGG_EINVAL, "null argument");
+    if (cfg_in->struct_size != sizeof(nfagg_config))
+        return fail(nullptr, NFAGG_EINVAL, "nfagg_config.struct_size %u != %zu (ABI mismatch)", cfg_in->struct_size, sizeof(nfagg_config));
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, NFAGG_ENODEV, "no HIP device available (%s); libnfagg has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    nfagg_config cfg = *cfg_in;
+    if (cfg.device < 0 || cfg.device >= ndev) return fail(nullptr, NFAGG_EINVAL, "device %d out of range (0..%d)", cfg.device, ndev - 1);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg.device) != hipSuccess) return fail(nullptr, NFAGG_ENODEV, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, NFAGG_ENODEV, "device %d is %s; libnfagg is built for gfx950 (MI355X) only", cfg.device, prop.gcnArchName);
+    if (cfg.max_entries == 0) cfg.max_entries = 5000;   // CACHE_MAX_FLOWS default (pkg/config/config.go:146)
+    if (cfg.mode != NFAGG_MODE_ACCOUNTER)
+        return fail(nullptr, NFAGG_EINVAL, "mode %u not available in this build (kernel-dedup merge is on the roadmap, DESIGN.md)", cfg.mode);
+    if (cfg.cm_depth == 0) cfg.cm_depth = 4;
+    if (cfg.cm_log2_width == 0) cfg.cm_log2_width = 20;
+    if (cfg.hll_p == 0) cfg.hll_p = 14;
+    if (cfg.cm_depth > 8 || cfg.cm_log2_width < 4 || cfg.cm_log2_width > 28 || cfg.hll_p < 4 || cfg.hll_p > 18)
+        return fail(nullptr, NFAGG_EINVAL, "sketch parameters out of range");
+    if (cfg.staging_records == 0) cfg.staging_records = 1ull << 20;
+    if (cfg.n_shards == 0) cfg.n_shards = 1;
+    if (cfg.shard_id >= cfg.n_shards) return fail(nullptr, NFAGG_EINVAL, "shard_id %u >= n_shards %u", cfg.shard_id, cfg.n_shards);
+    uint64_t slots = cfg.table_log2_slots ? (1ull << cfg.table_log2_slots) : next_pow2(2 * cfg.max_entries);
+    if (slots < (1ull << 16)) slots = 1ull << 16;
+    if (slots < 2 * cfg.max_entries) return fail(nullptr, NFAGG_EINVAL, "table_log2_slots too small: need >= 2*max_entries slots");
+    if (slots > (1ull << 31)) return fail(nullptr, NFAGG_EINVAL, "table larger than 2^31 slots not supported");
+
+    nfagg_handle* h = new (std::nothrow) nfagg_handle();
+    if (!h) return fail(nullptr, NFAGG_ENOMEM, "out of host memory");
+    h->cfg = cfg; h->device = cfg.device; h->slots = slots;
+#define CREATE_TRY(expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e2_ = (expr);                                                                 \
+        if (e2_ != hipSuccess) {                                                                 \
+            int rc_ = fail(nullptr, (e2_ == hipErrorOutOfMemory) ? NFAGG_ENOMEM : NFAGG_EDEVICE, \
+                           "%s failed: %s", #expr, hipGetErrorString(e2_));                      \
+            nfagg_destroy(h);                                                                    \
+            return rc_;                                                                          \
+        }                                                                                        \
+    } while (0)
+    CREATE_TRY(hipSetDevice(h->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc((void**)&h->tv.hot, slots * sizeof(SlotHot)));
+    CREATE_TRY(hipMalloc((void**)&h->tv.cold, slots * sizeof(SlotCold)));
+    // the live list can transiently hold bogus claims of the careful path: size it by slots
+    CREATE_TRY(hipMalloc((void**)&h->tv.live_list, slots * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc((void**)&h->tv.ctr, sizeof(DevCounters)));
+    CREATE_TRY(hipMemsetAsync(h->tv.hot, 0, slots * sizeof(SlotHot), h->stream));
+    CREATE_TRY(hipMemsetAsync(h->tv.cold, 0, slots * sizeof(SlotCold), h->stream));
+    CREATE_TRY(hipMemsetAsync(h->tv.ctr, 0, sizeof(DevCounters), h->stream));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_ctr, sizeof(DevCounters), hipHostMallocDefault));
+    h->tv.mask = slots - 1; h->tv.n_shards = cfg.n_shards; h->tv.shard_id = cfg.shard_id;
+    // careful path: never let claimed slots exceed 3/4 of the table
+    h->careful_chunk = slots / 4;
+    if (h->careful_chunk > (1ull << 22)) h->careful_chunk = 1ull << 22;
+    CREATE_TRY(hipMalloc((void**)&h->d_slot_idx, h->careful_chunk * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc((void**)&h->d_flags, h->careful_chunk));
+    CREATE_TRY(hipMalloc((void**)&h->d_block_counts, ((h->careful_chunk + kFlagBlock - 1) / kFlagBlock) * sizeof(uint32_t)));
+    for (int b = 0; b < 2; b++) CREATE_TRY(hipEventCreateWithFlags(&h->stage_free[b], hipEventDisableTiming));
+    // sketches
+    h->sk.cm_depth = cfg.cm_depth; h->sk.cm_log2w = cfg.cm_log2_width; h->sk.hll_p = cfg.hll_p;
+    h->sk.flags = cfg.sketch_flags & (NFAGG_SKETCH_CM | NFAGG_SKETCH_HLL);
+    if (h->sk.flags & NFAGG_SKETCH_CM) {
+        const size_t bytes = ((size_t)cfg.cm_depth << cfg.cm_log2_width) * sizeof(uint64_t);
+        for (int k = 0; k < 2; k++) {
+            if (cfg.ext_sketch[k]) h->sk.cm[k] = (uint64_t*)cfg.ext_sketch[k];
+            else { CREATE_TRY(hipMalloc((void**)&h->sk.cm[k], bytes)); h->own_sketch[k] = true; CREATE_TRY(hipMemsetAsync(h->sk.cm[k], 0, bytes, h->stream)); }
+        }
+    }
+    if (h->sk.flags & NFAGG_SKETCH_HLL) {
+        const size_t bytes = ((size_t)1 << cfg.hll_p) * sizeof(uint32_t);
+        for (int k = 0; k < 2; k++) {
+            if (cfg.ext_sketch[2 + k]) h->sk.hll[k] = (uint32_t*)cfg.ext_sketch[2 + k];
+            else { CREATE_TRY(hipMalloc((void**)&h->sk.hll[k], bytes)); h->own_sketch[2 + k] = true; CREATE_TRY(hipMemsetAsync(h->sk.hll[k], 0, bytes, h->stream)); }
+        }
+    }
+    CREATE_TRY(hipMalloc((void**)&h->d_hist, 65 * sizeof(uint32_t)));
+    CREATE_TRY(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+    h->stats.table_slots = slots;
+    h->stats.table_bytes = slots * (sizeof(SlotHot) + sizeof(SlotCold));
+    *out = h;
+    return NFAGG_OK;
+}
+
+void nfagg_destroy(nfagg_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    prof_resolve(h);
+    for (auto& ep : h->ev_free) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+    for (int b = 0; b < 2; b++) {
+        if (h->pinned[b]) hipHostFree(h->pinned[b]);
+        if (h->d_stage[b]) hipFree(h->d_stage[b]);
+        if (h->stage_free[b]) hipEventDestroy(h->stage_free[b]);
+    }
+    for (int k = 0; k < 2; k++) {
+        if (h->own_sketch[k] && h->sk.cm[k]) hipFree(h->sk.cm[k]);
+        if (h->own_sketch[2 + k] && h->sk.hll[k]) hipFree(h->sk.hll[k]);
+    }
+    for (int k = 0; k < 3; k++) if (h->d_roll[k]) hipFree(h->d_roll[k]);
+    if (h->d_hist) hipFree(h->d_hist);
+    if (h->d_evict) hipFree(h->d_evict);
+    if (h->d_slot_idx) hipFree(h->d_slot_idx);
+    if (h->d_flags) hipFree(h->d_flags);
+    if (h->d_block_counts) hipFree(h->d_block_counts);
+    if (h->tv.hot) hipFree(h->tv.hot);
+    if (h->tv.cold) hipFree(h->tv.cold);
+    if (h->tv.live_list) hipFree(h->tv.live_list);
+    if (h->tv.ctr) hipFree(h->tv.ctr);
+    if (h->h_ctr) hipHostFree(h->h_ctr);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int nfagg_ingest_device(nfagg_handle* h, const void* d_records, size_t n, size_t* consumed) {
+    if (!h || (!d_records && n)) return fail(h, NFAGG_EINVAL, "null argument");
+    if (((uintptr_t)d_records & 15u) != 0) return fail(h, NFAGG_EINVAL, "device records must be 16-byte aligned");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return ingest_device_core(h, d_records, n, consumed);
+}
+
+static int staging_alloc(nfagg_handle* h) {
+    if (h->pinned[0]) return NFAGG_OK;
+    const size_t bytes = (size_t)h->cfg.staging_records * kRecordBytes;
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(h, hipHostMalloc(&h->pinned[b], bytes, hipHostMallocDefault));
+        HIP_TRY(h, hipMalloc(&h->d_stage[b], bytes));
+    }
+    return NFAGG_OK;
+}
+
+int nfagg_ingest(nfagg_handle* h, const void* records, size_t n, size_t* consumed_out) {
+    if (!h || (!records && n)) return fail(h, NFAGG_EINVAL, "null argument");
+    if (h->stage_acquired) return fail(h, NFAGG_ESTATE, "a staging buffer is acquired; commit it first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = staging_alloc(h);
+    if (rc != NFAGG_OK) return rc;
+    size_t consumed = 0;
+    const char* src = static_cast<const char*>(records);
+    const size_t cap = (size_t)h->cfg.staging_records;
+    // pinned ring, double buffered: the CPU fills buffer b+1 while the GPU
+    // copies/folds buffer b (tracer_ringbuf.go:112-134 forwards one record at a time)
+    while (consumed < n) {
+        const size_t m = (n - consumed) < cap ? (n - consumed) : cap;
+        const int b = h->stage_next;
+        HIP_TRY(h, hipEventSynchronize(h->stage_free[b]));
+        memcpy(h->pinned[b], src + consumed * kRecordBytes, m * kRecordBytes);
+        HIP_TRY(h, hipMemcpyAsync(h->d_stage[b], h->pinned[b], m * kRecordBytes, hipMemcpyHostToDevice, h->stream));
+        size_t c = 0;
+        rc = ingest_device_core(h, h->d_stage[b], m, &c);
+        HIP_TRY(h, hipEventRecord(h->stage_free[b], h->stream));
+        h->stage_next ^= 1;
+        consumed += c;
+        if (rc != NFAGG_OK) break;
+    }
+    if (consumed_out) *consumed_out = consumed;
+    return rc;
+}
+
+int nfagg_staging_acquire(nfagg_handle* h, void** buf, size_t* capacity_records) {
+    if (!h || !buf) return fail(h, NFAGG_EINVAL, "null argument");
+    if (h->stage_acquired) return fail(h, NFAGG_ESTATE, "staging buffer already acquired");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = staging_alloc(h);
+    if (rc != NFAGG_OK) return rc;
+    const int b = h->stage_next;
+    HIP_TRY(h, hipEventSynchronize(h->stage_free[b]));
+    *buf = h->pinned[b];
+    if (capacity_records) *capacity_records = (size_t)h->cfg.staging_records;
+    h->stage_acquired = true;
+    return NFAGG_OK;
+}
+
+int nfagg_staging_commit(nfagg_handle* h, size_t n, size_t* consumed) {
+    if (!h) return NFAGG_EINVAL;
+    if (!h->stage_acquired) return fail(h, NFAGG_ESTATE, "no staging buffer acquired");
+    if (n > h->cfg.staging_records) return fail(h, NFAGG_EINVAL, "n exceeds staging capacity");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int b = h->stage_next;
+    h->stage_acquired = false;
+    HIP_TRY(h, hipMemcpyAsync(h->d_stage[b], h->pinned[b], n * kRecordBytes, hipMemcpyHostToDevice, h->stream));
+    int rc = ingest_device_core(h, h->d_stage[b], n, consumed);
+    HIP_TRY(h, hipEventRecord(h->stage_free[b], h->stream));
+    h->stage_next ^= 1;
+    return rc;
+}
+
+int nfagg_len(nfagg_handle* h, uint64_t* entries) {
+    if (!h || !entries) return fail(h, NFAGG_EINVAL, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = refresh_counters(h);
+    if (rc != NFAGG_OK) return rc;
+    *entries = h->live;
+    return NFAGG_OK;
+}
+
+static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device, size_t cap, size_t* n_out) {
+    if (!h || !n_out || reason < 0 || reason > 2) return fail(h, NFAGG_EINVAL, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = refresh_counters(h);
+    if (rc != NFAGG_OK) return rc;
+    const uint64_t legit = h->live;
+    const uint64_t claimed = h->h_ctr->n_live;
+    *n_out = (size_t)legit;
+    if (legit > cap) return NFAGG_TRUNCATED;
+    if (legit && !out) return fail(h, NFAGG_EINVAL, "null output buffer");
+    if (reason == NFAGG_REASON_TIMEOUT && legit == 0 && claimed == 0) return NFAGG_OK;  // account.go:64-66
+    void* d_out = out;
+    if (!out_is_device) {
+        size_t capb = (size_t)h->d_evict_cap;
+        rc = ensure_bytes(h, &h->d_evict, &capb, (size_t)legit * kRecordBytes + 16);
+        h->d_evict_cap = capb;
+        if (rc != NFAGG_OK) return rc;
+        d_out = h->d_evict;
+    }
+    HIP_TRY(h, hipMemsetAsync(&h->tv.ctr->n_out, 0, sizeof(unsigned long long), h->stream));
+    EventPair ep{};
+    if (h->cfg.profile) prof_begin(h, ep, 1);
+    hipError_t e = launch_evict(h->tv, claimed, h->must_evict ? h->split_seq : ~0ull, d_out, h->stream);
+    if (h->cfg.profile) prof_end(h, ep);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "evict launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync(h->h_ctr, h->tv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->h_ctr->n_out != legit)
+        return fail(h, NFAGG_EDEVICE, "evict wrote %llu records, expected %llu", (unsigned long long)h->h_ctr->n_out, (unsigned long long)legit);
+    if (!out_is_device && legit)
+        HIP_TRY(h, hipMemcpy(out, h->d_evict, (size_t)legit * kRecordBytes, hipMemcpyDeviceToHost));
+    h->stats.evictions[reason]++;
+    h->stats.evicted_flows[reason] += legit;
+    h->epoch_seq = 0; h->live = 0; h->live_ub = 0; h->must_evict = false; h->split_seq = 0;
+    return NFAGG_OK;
+}
+
+int nfagg_evict(nfagg_handle* h, int reason, void* out, size_t cap, size_t* n_out) {
+    return evict_core(h, reason, out, false, cap, n_out);
+}
+
+int nfagg_evict_device(nfagg_handle* h, int reason, void* d_out, size_t cap, size_t* n_out) {
+    if (d_out && ((uintptr_t)d_out & 15u)) return fail(h, NFAGG_EINVAL, "device output must be 16-byte aligned");
+    return evict_core(h, reason, d_out, true, cap, n_out);
+}
+
+// pkg/model/record.go:90-97
+void nfagg_record_times(int64_t now_unix_ns, uint64_t mono_now_ns, const nfagg_flow_metrics* m,
+                        int64_t* time_flow_start_unix_ns, int64_t* time_flow_end_unix_ns) {
+    const int64_t start_delta = (int64_t)(mono_now_ns - m->start_mono_time_ts);
+    const int64_t end_delta = (int64_t)(mono_now_ns - m->end_mono_time_ts);
+    if (time_flow_start_unix_ns) *time_flow_start_unix_ns = (int64_t)((uint64_t)now_unix_ns - (uint64_t)start_delta);
+    if (time_flow_end_unix_ns) *time_flow_end_unix_ns = (int64_t)((uint64_t)now_unix_ns - (uint64_t)end_delta);
+}
+
+// ---------------------------------------------------------------- rollups
+static int rollup_core(nfagg_handle* h, int kind, const void* partials, size_t n_flows, size_t n_cpu,
+                       nfagg_flow_metrics* base, void* folded) {
+    if (!h || !partials || !base || !folded) return fail(h, NFAGG_EINVAL, "null argument");
+    if (n_flows == 0) return NFAGG_OK;
+    if (n_cpu == 0) return fail(h, NFAGG_EINVAL, "n_cpu must be >= 1");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t ssz = rollup_struct_size(kind);
+    const size_t pb = n_flows * n_cpu * ssz, bb = n_flows * sizeof(nfagg_flow_metrics), fb = n_flows * ssz;
+    int rc;
+    if ((rc = ensure_bytes(h, &h->d_roll[0], &h->d_roll_cap[0], pb)) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_roll[1], &h->d_roll_cap[1], bb)) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_roll[2], &h->d_roll_cap[2], fb)) != NFAGG_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_roll[0], partials, pb, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_roll[1], base, bb, hipMemcpyHostToDevice, h->stream));
+    hipError_t e = launch_rollup(kind, h->d_roll[0], n_flows, n_cpu, h->d_roll[1], h->d_roll[2], h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "rollup launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync(base, h->d_roll[1], bb, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(folded, h->d_roll[2], fb, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NFAGG_OK;
+}
+
+int nfagg_rollup_additional(nfagg_handle* h, const nfagg_additional_metrics* p, size_t nf, size_t nc,
+                            nfagg_flow_metrics* base, nfagg_additional_metrics* folded) { return rollup_core(h, 0, p, nf, nc, base, folded); }
+int nfagg_rollup_dns(nfagg_handle* h, const nfagg_dns_metrics* p, size_t nf, size_t nc,
+                     nfagg_flow_metrics* base, nfagg_dns_metrics* folded) { return rollup_core(h, 1, p, nf, nc, base, folded); }
+int nfagg_rollup_drops(nfagg_handle* h, const nfagg_pkt_drop_metrics* p, size_t nf, size_t nc,
+                       nfagg_flow_metrics* base, nfagg_pkt_drop_metrics* folded) { return rollup_core(h, 2, p, nf, nc, base, folded); }
+int nfagg_rollup_network_events(nfagg_handle* h, const nfagg_network_events_metrics* p, size_t nf, size_t nc,
+                                nfagg_flow_metrics* base, nfagg_network_events_metrics* folded) { return rollup_core(h, 3, p, nf, nc, base, folded); }
+int nfagg_rollup_xlat(nfagg_handle* h, const nfagg_xlat_metrics* p, size_t nf, size_t nc,
+                      nfagg_flow_metrics* base, nfagg_xlat_metrics* folded) { return rollup_core(h, 4, p, nf, nc, base, folded); }
+int nfagg_rollup_quic(nfagg_handle* h, const nfagg_quic_metrics* p, size_t nf, size_t nc,
+                      nfagg_flow_metrics* base, nfagg_quic_metrics* folded) { return rollup_core(h, 5, p, nf, nc, base, folded); }
+
+// ---------------------------------------------------------------- sketches
+static int sketch_info(nfagg_handle* h, int which, void** p, size_t* bytes) {
+    if (which == NFAGG_CM_SRC || which == NFAGG_CM_DST) {
+        if (!(h->sk.flags & NFAGG_SKETCH_CM)) return fail(h, NFAGG_ESTATE, "Count-Min sketch not enabled");
+        *p = h->sk.cm[which - NFAGG_CM_SRC];
+        *bytes = ((size_t)h->sk.cm_depth << h->sk.cm_log2w) * sizeof(uint64_t);
+        return NFAGG_OK;
+    }
+    if (which == NFAGG_HLL_SRC || which == NFAGG_HLL_DST) {
+        if (!(h->sk.flags & NFAGG_SKETCH_HLL)) return fail(h, NFAGG_ESTATE, "HyperLogLog sketch not enabled");
+        *p = h->sk.hll[which - NFAGG_HLL_SRC];
+        *bytes = ((size_t)1 << h->sk.hll_p) * sizeof(uint32_t);
+        return NFAGG_OK;
+    }
+    return fail(h, NFAGG_EINVAL, "unknown sketch id %d", which);
+}
+
+int nfagg_sketch_device_ptr(nfagg_handle* h, int which, void** d_ptr, size_t* bytes) {
+    if (!h || !d_ptr || !bytes) return fail(h, NFAGG_EINVAL, "null argument");
+    return sketch_info(h, which, d_ptr, bytes);
+}
+
+int nfagg_sketch_snapshot(nfagg_handle* h, int which, void* out, size_t out_bytes) {
+    if (!h || !out) return fail(h, NFAGG_EINVAL, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    void* p; size_t bytes;
+    int rc = sketch_info(h, which, &p, &bytes);
+    if (rc != NFAGG_OK) return rc;
+    if (which == NFAGG_CM_SRC || which == NFAGG_CM_DST) {
+        if (out_bytes < bytes) return NFAGG_TRUNCATED;
+        HIP_TRY(h, hipMemcpyAsync(out, p, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return NFAGG_OK;
+    }
+    const size_t m = (size_t)1 << h->sk.hll_p;
+    if (out_bytes < m) return NFAGG_TRUNCATED;
+    size_t cap0 = h->d_roll_cap[0];
+    rc = ensure_bytes(h, &h->d_roll[0], &cap0, m);
+    h->d_roll_cap[0] = cap0;
+    if (rc != NFAGG_OK) return rc;
+    hipError_t e = launch_hll_pack((const uint32_t*)p, h->sk.hll_p, (uint8_t*)h->d_roll[0], h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "hll pack launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync(out, h->d_roll[0], m, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NFAGG_OK;
+}
+
+int nfagg_sketch_reset(nfagg_handle* h) {
+    if (!h) return NFAGG_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int which = 0; which < 4; which++) {
+        const bool on = which < 2 ? (h->sk.flags & NFAGG_SKETCH_CM) : (h->sk.flags & NFAGG_SKETCH_HLL);
+        if (!on) continue;
+        void* p; size_t bytes;
+        int rc = sketch_info(h, which, &p, &bytes);
+        if (rc != NFAGG_OK) return rc;
+        HIP_TRY(h, hipMemsetAsync(p, 0, bytes, h->stream));
+    }
+    return NFAGG_OK;
+}
+
+// HyperLogLog estimate (Flajolet et al. 2007, 64-bit hash so no large-range
+// correction) from the histogram of register values: sum_k hist[k] * 2^-k in
+// ascending k. Our own spec; the scalar oracle loops over the registers instead.
+double nfagg_hll_estimate_from_histogram(const uint32_t* hist, uint32_t p) {
+    const double m = (double)(1ull << p);
+    const double alpha = (p == 4) ? 0.673 : (p == 5) ? 0.697 : (p == 6) ? 0.709 : 0.7213 / (1.0 + 1.079 / m);
+    double sum = 0.0;
+    for (int k = 0; k <= 64; k++) sum += (double)hist[k] * __builtin_ldexp(1.0, -k);
+    double e = alpha * m * m / sum;
+    if (e <= 2.5 * m && hist[0] != 0) e = m * __builtin_log(m / (double)hist[0]);
+    return e;
+}
+
+int nfagg_hll_estimate(nfagg_handle* h, int which, double* estimate) {
+    if (!h || !estimate) return fail(h, NFAGG_EINVAL, "null argument");
+    if (which != NFAGG_HLL_SRC && which != NFAGG_HLL_DST) return fail(h, NFAGG_EINVAL, "which must be an HLL sketch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    void* p; size_t bytes;
+    int rc = sketch_info(h, which, &p, &bytes);
+    if (rc != NFAGG_OK) return rc;
+    hipError_t e = launch_hll_histogram((const uint32_t*)p, h->sk.hll_p, h->d_hist, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "hll histogram launch failed: %s", hipGetErrorString(e));
+    uint32_t hist[65];
+    HIP_TRY(h, hipMemcpyAsync(hist, h->d_hist, sizeof hist, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *estimate = nfagg_hll_estimate_from_histogram(hist, h->sk.hll_p);
+    return NFAGG_OK;
+}
+
+int nfagg_cm_query(nfagg_handle* h, int which, const uint8_t ip[16], uint64_t* estimate) {
+    if (!h || !ip || !estimate) return fail(h, NFAGG_EINVAL, "null argument");
+    if (which != NFAGG_CM_SRC && which != NFAGG_CM_DST) return fail(h, NFAGG_EINVAL, "which must be a CM sketch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    void* p; size_t bytes;
+    int rc = sketch_info(h, which, &p, &bytes);
+    if (rc != NFAGG_OK) return rc;
+    uint64_t lo, hi;
+    memcpy(&lo, ip, 8); memcpy(&hi, ip + 8, 8);
+    const uint64_t ha = ip_hash(lo, hi, 0), hb = ip_hash(lo, hi, 1) | 1ull;
+    uint64_t best = ~0ull;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (uint32_t r = 0; r < h->sk.cm_depth; r++) {
+        uint64_t v;
+        const uint64_t at = ((uint64_t)r << h->sk.cm_log2w) + cm_index(ha, hb, r, h->sk.cm_log2w);
+        HIP_TRY(h, hipMemcpy(&v, (const uint64_t*)p + at, sizeof v, hipMemcpyDeviceToHost));
+        if (v < best) best = v;
+    }
+    *estimate = best;
+    return NFAGG_OK;
+}
+
+// ---------------------------------------------------------------- misc
+uint64_t nfagg_key_hash(const nfagg_flow_id* id) {
+    uint64_t w[5];
+    memcpy(w, id, 40);
+    w[4] &= 0x00ffffffffffffffull;   // byte 39
+    return key_hash(w);
+}
+
+uint32_t nfagg_shard_of(const nfagg_flow_id* id, uint32_t n_shards) { return shard_of_hash(nfagg_key_hash(id), n_shards); }
+
+uint64_t nfagg_ip_hash(const uint8_t ip[16], uint32_t seed_index) {
+    uint64_t lo, hi;
+    memcpy(&lo, ip, 8); memcpy(&hi, ip + 8, 8);
+    return ip_hash(lo, hi, seed_index);
+}
+
+int nfagg_sync(nfagg_handle* h) {
+    if (!h) return NFAGG_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NFAGG_OK;
+}
+
+void* nfagg_stream(nfagg_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int nfagg_stats_get(nfagg_handle* h, nfagg_stats* out) {
+    if (!h || !out) return fail(h, NFAGG_EINVAL, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = refresh_counters(h);
+    if (rc != NFAGG_OK) return rc;
+    prof_resolve(h);
+    h->stats.entries = h->live;
+    h->stats.epoch_seq = h->epoch_seq;
+    *out = h->stats;
+    return NFAGG_OK;
+}
+
+int nfagg_stats_reset_profile(nfagg_handle* h) {
+    if (!h) return NFAGG_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    prof_resolve(h);
+    h->stats.ingest_launches = h->stats.evict_launches = h->stats.sketch_launches = 0;
+    h->stats.ingest_kernel_ms = h->stats.evict_kernel_ms = h->stats.sketch_kernel_ms = 0.0;
+    return NFAGG_OK;
+}
+
+}  // extern "C"

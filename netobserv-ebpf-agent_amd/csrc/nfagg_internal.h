@@ -1,0 +1,103 @@
+// nfagg_internal.h — device-side layout of the flow table and the launch
+// interface between the C ABI (nfagg_api.hip) and the kernels.
+//
+// The table replaces Accounter.entries (pkg/flow/account.go:22,
+// map[BpfFlowId]*BpfFlowMetrics): open addressing, linear probing, one
+// 128-byte "hot" line per slot (tag + key + every field a record updates) and
+// one 128-byte "cold" line (fields that only the first record of a flow, or
+// the first record with a non-zero MAC, ever writes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nfagg_hash.h"
+
+namespace nfagg {
+
+constexpr int kRecordBytes = 144;   // bpf/types.h:212-215
+constexpr int kRecordDwords = 36;
+constexpr int kKeyBytes = 40;       // bpf/types.h:191-204
+
+// All 64-bit words of a slot are accessed with agent-scope atomics while an
+// ingest kernel runs (per-XCD L2s are not coherent with each other; see
+// DESIGN.md §coherence). Identities are zero so that eviction can reset a
+// slot by zeroing it.
+struct alignas(128) SlotHot {
+    uint64_t tag;        // 0 empty | (fp<<2)|2 claimed, key being written | (fp<<2)|3 ready
+    uint64_t key[5];     // flow_id, byte 39 zero
+    uint64_t bytes;      // sum, wraps (flow_content.go:42)
+    uint64_t end;        // max          (:39-41)
+    uint64_t start_inv;  // max of ~start over non-zero starts; 0 = unset (:36-38)
+    uint32_t packets;    // sum, wraps (:43)
+    uint32_t flags;      // OR (:44), low 16 bits
+    uint64_t eth_tag;    // max of (seq+1)<<16 | eth_protocol  over non-zero eth   (:45-47 last non-zero)
+    uint64_t dscp_tag;   // max of (seq+1)<<8  | dscp          over non-zero dscp  (:54-56)
+    uint64_t samp_tag;   // max of (seq+1)<<32 | sampling      over non-zero sampling (:57-59)
+    uint64_t first_inv;  // max of ~seq: the first record of the flow in this epoch (account.go:95)
+    uint32_t lock;       // guards the cold line
+    uint32_t pad;
+};
+static_assert(sizeof(SlotHot) == 128, "hot line");
+
+struct alignas(128) SlotCold {
+    uint64_t smac_inv;   // max of ~seq over records with non-zero src_mac (:48-50 first non-zero)
+    uint64_t dmac_inv;   // same for dst_mac (:51-53)
+    uint64_t smac;       // low 48 bits
+    uint64_t dmac;
+    uint64_t ident[8];   // record dwords 21..35 (metrics bytes 44..103) of the first record
+    uint64_t pad[4];
+};
+static_assert(sizeof(SlotCold) == 128, "cold line");
+
+// Device-resident counters, mirrored to pinned host memory on demand.
+struct DevCounters {
+    unsigned long long n_live;     // claimed slots this epoch (== len(c.entries) unless a split is pending)
+    unsigned long long n_out;      // records written by the evict kernel
+    unsigned long long n_skipped;  // records of other shards
+    unsigned long long n_accepted;
+    unsigned int error;            // non-zero: a kernel bailed out (probe overflow)
+    unsigned int max_probe;
+    unsigned long long pad[2];
+};
+
+struct TableView {
+    SlotHot* hot;
+    SlotCold* cold;
+    uint32_t* live_list;           // slot indices claimed this epoch, in claim order
+    DevCounters* ctr;
+    uint64_t mask;                 // slots - 1
+    uint32_t n_shards, shard_id;
+};
+
+struct SketchView {
+    uint64_t* cm[2];               // src, dst : depth << log2w counters
+    uint32_t* hll[2];              // src, dst : 1 << p registers (uint32 on device)
+    uint32_t cm_depth, cm_log2w, hll_p, flags;
+};
+
+// ---- launch wrappers (defined in nfagg_kernels.hip) ----
+// Fold records[0..n) into the table; record i carries sequence seq_base + i.
+// variant: 0 = default, see DESIGN.md.
+hipError_t launch_ingest(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
+                         int mode, int variant, hipStream_t s);
+// Careful path, phase A: claim slots only; writes the slot index of every record.
+hipError_t launch_claim(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
+                        uint32_t* d_slot_idx, hipStream_t s);
+// Careful path: flags[i] = record i is the first occurrence of a key new in this epoch chunk;
+// block_counts[b] = number of flags set in block b of kFlagBlock records.
+constexpr int kFlagBlock = 1024;
+hipError_t launch_first_flags(const TableView& t, const uint32_t* d_slot_idx, uint64_t n, uint64_t seq_base,
+                              uint8_t* d_flags, uint32_t* d_block_counts, hipStream_t s);
+// Write every live flow whose first record has seq < seq_limit as a 144-byte
+// record (dense, order unspecified), zero every claimed slot, reset n_live.
+hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);
+// Sketch update over a batch (nfagg_sketch.hip).
+hipError_t launch_sketch_update(const SketchView& sk, const TableView& t, const void* d_records, uint64_t n, hipStream_t s);
+hipError_t launch_hll_histogram(const uint32_t* d_regs, uint32_t p, uint32_t* d_hist65, hipStream_t s);
+hipError_t launch_hll_pack(const uint32_t* d_regs, uint32_t p, uint8_t* d_out, hipStream_t s);
+
+// Per-CPU rollups (nfagg_rollup.hip). kind: 0 additional,1 dns,2 drops,3 netev,4 xlat,5 quic.
+hipError_t launch_rollup(int kind, const void* d_partials, uint64_t n_flows, uint64_t n_cpu,
+                         void* d_base, void* d_folded, hipStream_t s);
+size_t rollup_struct_size(int kind);
+
+}  // namespace nfagg

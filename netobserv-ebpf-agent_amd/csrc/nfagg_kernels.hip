@@ -1,0 +1,176 @@
+// nfagg_kernels.hip — ingest / claim / evict kernels of the flow table (gfx950).
+//
+// Replaces the body of Accounter.Account's record arm and Accounter.evict
+// (pkg/flow/account.go:81-96, 102-124). HBM-bound hash/scatter work: no MFMA.
+#include "nfagg_device.h"
+
+namespace nfagg {
+
+// ------------------------------------------------------------------
+// Variant 0 ("direct"): one record per lane, every record merged into the
+// table with agent-scope atomics. Correct for any stream; hot keys serialise
+// on their slot — the LDS-combining variants exist for that.
+// ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ingest_direct(TableView t, const void* __restrict__ recs,
+                                                       uint64_t n, uint64_t seq_base) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long skipped = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Rec r;
+        load_record(recs, i, r);
+        r.canonicalize();
+        uint64_t w[5];
+        r.key_words(w);
+        const uint64_t h = key_hash(w);
+        if (t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id) { skipped++; continue; }
+        const uint32_t idx = find_or_claim(t, w, h);
+        if (idx == kNoSlot) continue;
+        Partial p;
+        partial_from_record(r, seq_base + i, p);
+        merge_partial(t, idx, p);
+    }
+    if (skipped) aadd(&t.ctr->n_skipped, skipped);
+}
+
+// ------------------------------------------------------------------
+// Careful path (possible "full" eviction inside the batch, account.go:85-94).
+// Phase A: claim slots only and plant first_inv, remember each record's slot.
+// ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_claim(TableView t, const void* __restrict__ recs, uint64_t n,
+                                               uint64_t seq_base, uint32_t* __restrict__ slot_idx) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Rec r;
+        load_record(recs, i, r);
+        r.canonicalize();
+        uint64_t w[5];
+        r.key_words(w);
+        const uint64_t h = key_hash(w);
+        if (t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id) { slot_idx[i] = kNoSlot; continue; }
+        const uint32_t idx = find_or_claim(t, w, h);
+        slot_idx[i] = idx;
+        if (idx != kNoSlot) amax(&t.hot[idx].first_inv, ~(seq_base + i));
+    }
+}
+
+// flags[i] = record i is the first record (in arrival order) of a key that was
+// not in the table before this chunk: exactly the records at which
+// len(c.entries) grows (account.go:95). A slot older than the chunk has a
+// first_inv larger than every ~seq of the chunk, so equality identifies both.
+__global__ __launch_bounds__(kFlagBlock) void k_first_flags(TableView t, const uint32_t* __restrict__ slot_idx,
+                                                            uint64_t n, uint64_t seq_base,
+                                                            uint8_t* __restrict__ flags,
+                                                            uint32_t* __restrict__ block_counts) {
+    __shared__ unsigned int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * kFlagBlock + threadIdx.x;
+    unsigned f = 0;
+    if (i < n) {
+        const uint32_t idx = slot_idx[i];
+        if (idx != kNoSlot) f = (t.hot[idx].first_inv == ~(seq_base + i)) ? 1u : 0u;
+        flags[i] = (uint8_t)f;
+    }
+    if (f) atomicAdd(&cnt, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = cnt;
+}
+
+// ------------------------------------------------------------------
+// Evict: Accounter.evict (account.go:102-124) up to NewRecord. One lane per
+// claimed slot: rebuild the 144-byte flow_record_t, write it densely, zero
+// the slot (zero is every field's identity, so the next epoch needs no init).
+// ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_evict(TableView t, uint64_t n_live, uint64_t seq_limit,
+                                               void* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_live; i += stride) {
+        const uint32_t idx = t.live_list[i];
+        SlotHot* H = &t.hot[idx];
+        SlotCold* C = &t.cold[idx];
+        const SlotHot hv = *H;
+        const SlotCold cv = *C;
+        const uint64_t first_seq = ~hv.first_inv;
+        // A slot claimed by the careful path for a key that first appears at or
+        // after the split point is not part of this epoch: drop it.
+        const bool emit = hv.first_inv != 0 && first_seq < seq_limit;
+        if (emit) {
+            uint32_t d[kRecordDwords];
+#pragma unroll
+            for (int k = 0; k < 5; k++) { d[2 * k] = (uint32_t)hv.key[k]; d[2 * k + 1] = (uint32_t)(hv.key[k] >> 32); }
+            const uint64_t start = hv.start_inv ? ~hv.start_inv : 0ull;
+            d[10] = (uint32_t)start; d[11] = (uint32_t)(start >> 32);
+            d[12] = (uint32_t)hv.end; d[13] = (uint32_t)(hv.end >> 32);
+            d[14] = (uint32_t)hv.bytes; d[15] = (uint32_t)(hv.bytes >> 32);
+            d[16] = hv.packets;
+            d[17] = (uint32_t)(hv.eth_tag & 0xffffu) | ((hv.flags & 0xffffu) << 16);
+            d[18] = (uint32_t)cv.smac;
+            d[19] = (uint32_t)((cv.smac >> 32) & 0xffffu) | (uint32_t)((cv.dmac & 0xffffu) << 16);
+            d[20] = (uint32_t)(cv.dmac >> 16);
+#pragma unroll
+            for (int k = 0; k < 7; k++) { d[21 + 2 * k] = (uint32_t)cv.ident[k]; d[22 + 2 * k] = (uint32_t)(cv.ident[k] >> 32); }
+            d[35] = 0;
+            d[23] = (uint32_t)hv.samp_tag;                                   // sampling: last non-zero
+            d[24] = (d[24] & 0xff00ffffu) | ((uint32_t)(hv.dscp_tag & 0xffu) << 16);  // dscp: last non-zero
+            const unsigned long long pos = aadd(&t.ctr->n_out, 1ull);
+            uint4* o = reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + pos * kRecordBytes);
+#pragma unroll
+            for (int k = 0; k < 9; k++) o[k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+        }
+        uint4* hz = reinterpret_cast<uint4*>(H);
+        uint4* cz = reinterpret_cast<uint4*>(C);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { hz[k] = make_uint4(0, 0, 0, 0); cz[k] = make_uint4(0, 0, 0, 0); }
+    }
+}
+
+__global__ void k_reset_after_evict(DevCounters* c) {
+    c->n_live = 0;
+    c->max_probe = 0;
+}
+
+static inline int grid_for(uint64_t n, int block, int max_blocks) {
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+hipError_t launch_ingest_lds(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
+                             int variant, hipStream_t s);  // nfagg_ingest_lds.hip
+
+hipError_t launch_ingest(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
+                         int mode, int variant, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    (void)mode;
+    if (variant != 1) return launch_ingest_lds(t, d_records, n, seq_base, variant, s);
+    hipLaunchKernelGGL(k_ingest_direct, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, t, d_records, n, seq_base);
+    return hipGetLastError();
+}
+
+hipError_t launch_claim(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
+                        uint32_t* d_slot_idx, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_claim, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, t, d_records, n, seq_base, d_slot_idx);
+    return hipGetLastError();
+}
+
+hipError_t launch_first_flags(const TableView& t, const uint32_t* d_slot_idx, uint64_t n, uint64_t seq_base,
+                              uint8_t* d_flags, uint32_t* d_block_counts, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const int blocks = (int)((n + kFlagBlock - 1) / kFlagBlock);
+    hipLaunchKernelGGL(k_first_flags, dim3(blocks), dim3(kFlagBlock), 0, s, t, d_slot_idx, n, seq_base, d_flags, d_block_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s) {
+    if (n_live) {
+        hipLaunchKernelGGL(k_evict, dim3(grid_for(n_live, 256, 256 * 8)), dim3(256), 0, s, t, n_live, seq_limit, d_out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_reset_after_evict, dim3(1), dim3(1), 0, s, t.ctr);
+    return hipGetLastError();
+}
+
+}  // namespace nfagg

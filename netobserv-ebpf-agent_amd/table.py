@@ -1,0 +1,215 @@
+"""FlowTable — object wrapper over one libnfagg handle (include/nfagg.h).
+
+All computation happens in the HIP library; this file only marshals numpy
+buffers and raw device pointers across the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .records import FLOW_RECORD, ROLLUP_KINDS, FLOW_METRICS
+
+
+class NfaggError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"nfagg error {code}: {msg}")
+        self.code = code
+
+
+_ROLLUP_FN = {
+    "additional": L.lib.nfagg_rollup_additional, "dns": L.lib.nfagg_rollup_dns, "drops": L.lib.nfagg_rollup_drops,
+    "network_events": L.lib.nfagg_rollup_network_events, "xlat": L.lib.nfagg_rollup_xlat, "quic": L.lib.nfagg_rollup_quic,
+}
+
+
+class FlowTable:
+    """The GPU-resident replacement of Accounter.entries (pkg/flow/account.go:22)."""
+
+    def __init__(self, max_entries=5000, device=0, mode=L.MODE_ACCOUNTER, sketches=0, cm_depth=0, cm_log2_width=0,
+                 hll_p=0, table_log2_slots=0, staging_records=0, n_shards=1, shard_id=0, profile=False,
+                 ingest_variant=0, ext_sketch=None):
+        cfg = L.Config()
+        cfg.struct_size = C.sizeof(L.Config)
+        cfg.device = device
+        cfg.max_entries = max_entries
+        cfg.table_log2_slots = table_log2_slots
+        cfg.mode = mode
+        cfg.sketch_flags = sketches
+        cfg.cm_depth, cfg.cm_log2_width, cfg.hll_p = cm_depth, cm_log2_width, hll_p
+        cfg.staging_records = staging_records
+        cfg.n_shards, cfg.shard_id = n_shards, shard_id
+        cfg.profile = 1 if profile else 0
+        cfg.ingest_variant = ingest_variant
+        if ext_sketch:
+            for k, p in enumerate(ext_sketch):
+                cfg.ext_sketch[k] = p
+        self._h = C.c_void_p()
+        rc = L.lib.nfagg_create(C.byref(cfg), C.byref(self._h))
+        if rc != L.OK:
+            msg = L.lib.nfagg_last_error(None)
+            self._h = None
+            raise NfaggError(rc, msg.decode() if msg else "nfagg_create failed")
+        self.max_entries = max_entries if max_entries else 5000
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib.nfagg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, ok=(L.OK,)):
+        if rc not in ok:
+            msg = L.lib.nfagg_last_error(self._h)
+            raise NfaggError(rc, msg.decode() if msg else "")
+        return rc
+
+    # -- ingest
+    def ingest(self, records: np.ndarray):
+        """nfagg_ingest: fold host records in order. Returns (status, consumed)."""
+        records = np.ascontiguousarray(records)
+        assert records.dtype.itemsize == 144 or records.dtype == np.uint8
+        n = records.nbytes // 144
+        consumed = C.c_size_t(0)
+        rc = L.lib.nfagg_ingest(self._h, records.ctypes.data_as(C.c_void_p), n, C.byref(consumed))
+        self._check(rc, (L.OK, L.FULL))
+        return rc, consumed.value
+
+    def ingest_device(self, d_ptr: int, n: int):
+        consumed = C.c_size_t(0)
+        rc = L.lib.nfagg_ingest_device(self._h, C.c_void_p(d_ptr), n, C.byref(consumed))
+        self._check(rc, (L.OK, L.FULL))
+        return rc, consumed.value
+
+    def staging_acquire(self):
+        buf, cap = C.c_void_p(), C.c_size_t(0)
+        self._check(L.lib.nfagg_staging_acquire(self._h, C.byref(buf), C.byref(cap)))
+        arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(cap.value * 144,)).view(FLOW_RECORD)
+        return arr
+
+    def staging_commit(self, n):
+        consumed = C.c_size_t(0)
+        rc = L.lib.nfagg_staging_commit(self._h, n, C.byref(consumed))
+        self._check(rc, (L.OK, L.FULL))
+        return rc, consumed.value
+
+    def __len__(self):
+        v = C.c_uint64(0)
+        self._check(L.lib.nfagg_len(self._h, C.byref(v)))
+        return v.value
+
+    # -- evict
+    def evict(self, reason=L.REASON_TIMEOUT, cap=None) -> np.ndarray:
+        """nfagg_evict: every live flow as one flow_record_t; table cleared."""
+        if cap is None:
+            cap = max(len(self), 1)
+        out = np.zeros(cap, dtype=FLOW_RECORD)
+        n = C.c_size_t(0)
+        rc = L.lib.nfagg_evict(self._h, reason, out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+        self._check(rc, (L.OK, L.TRUNCATED))
+        if rc == L.TRUNCATED:
+            return self.evict(reason, cap=n.value)
+        return out[: n.value]
+
+    def evict_device(self, d_ptr: int, cap: int, reason=L.REASON_TIMEOUT) -> int:
+        n = C.c_size_t(0)
+        self._check(L.lib.nfagg_evict_device(self._h, reason, C.c_void_p(d_ptr), cap, C.byref(n)))
+        return n.value
+
+    # -- rollups (pkg/tracer/tracer.go:1057-1146)
+    def rollup(self, kind: str, partials: np.ndarray, n_cpu: int, base: np.ndarray):
+        dt = ROLLUP_KINDS[kind]
+        partials = np.ascontiguousarray(partials, dtype=dt)
+        n_flows = partials.size // n_cpu
+        base = np.ascontiguousarray(base, dtype=FLOW_METRICS).copy()
+        folded = np.zeros(n_flows, dtype=dt)
+        self._check(_ROLLUP_FN[kind](self._h, partials.ctypes.data_as(C.c_void_p), n_flows, n_cpu,
+                                     base.ctypes.data_as(C.c_void_p), folded.ctypes.data_as(C.c_void_p)))
+        return base, folded
+
+    # -- sketches
+    def sketch_snapshot(self, which):
+        p, b = C.c_void_p(), C.c_size_t(0)
+        self._check(L.lib.nfagg_sketch_device_ptr(self._h, which, C.byref(p), C.byref(b)))
+        if which in (L.CM_SRC, L.CM_DST):
+            out = np.zeros(b.value // 8, dtype=np.uint64)
+        else:
+            out = np.zeros(b.value // 4, dtype=np.uint8)
+        self._check(L.lib.nfagg_sketch_snapshot(self._h, which, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def sketch_device_ptr(self, which):
+        p, b = C.c_void_p(), C.c_size_t(0)
+        self._check(L.lib.nfagg_sketch_device_ptr(self._h, which, C.byref(p), C.byref(b)))
+        return p.value, b.value
+
+    def sketch_reset(self):
+        self._check(L.lib.nfagg_sketch_reset(self._h))
+
+    def hll_estimate(self, which):
+        v = C.c_double(0)
+        self._check(L.lib.nfagg_hll_estimate(self._h, which, C.byref(v)))
+        return v.value
+
+    def cm_query(self, which, ip16: bytes):
+        v = C.c_uint64(0)
+        buf = (C.c_uint8 * 16).from_buffer_copy(bytes(ip16))
+        self._check(L.lib.nfagg_cm_query(self._h, which, buf, C.byref(v)))
+        return v.value
+
+    # -- misc
+    def stats(self) -> L.Stats:
+        s = L.Stats()
+        self._check(L.lib.nfagg_stats_get(self._h, C.byref(s)))
+        return s
+
+    def reset_profile(self):
+        self._check(L.lib.nfagg_stats_reset_profile(self._h))
+
+    def sync(self):
+        self._check(L.lib.nfagg_sync(self._h))
+
+    @property
+    def stream(self) -> int:
+        return L.lib.nfagg_stream(self._h) or 0
+
+
+def key_hash(flow_id_bytes: bytes) -> int:
+    buf = (C.c_uint8 * 40).from_buffer_copy(bytes(flow_id_bytes)[:40])
+    return L.lib.nfagg_key_hash(buf)
+
+
+def shard_of(flow_id_bytes: bytes, n_shards: int) -> int:
+    buf = (C.c_uint8 * 40).from_buffer_copy(bytes(flow_id_bytes)[:40])
+    return L.lib.nfagg_shard_of(buf, n_shards)
+
+
+def ip_hash(ip16: bytes, seed_index: int) -> int:
+    buf = (C.c_uint8 * 16).from_buffer_copy(bytes(ip16))
+    return L.lib.nfagg_ip_hash(buf, seed_index)
+
+
+def hll_estimate_from_histogram(hist, p: int) -> float:
+    h = np.ascontiguousarray(hist, dtype=np.uint32)
+    assert h.size == 65
+    return L.lib.nfagg_hll_estimate_from_histogram(h.ctypes.data_as(C.c_void_p), p)
+
+
+def record_times(now_unix_ns: int, mono_now_ns: int, metrics: np.void):
+    """pkg/model/record.go:90-97 via the library helper."""
+    m = np.ascontiguousarray(np.array([metrics], dtype=FLOW_METRICS))
+    a, b = C.c_int64(0), C.c_int64(0)
+    L.lib.nfagg_record_times(now_unix_ns, mono_now_ns, m.ctypes.data_as(C.c_void_p), C.byref(a), C.byref(b))
+    return a.value, b.value

@@ -1,0 +1,192 @@
+"""ctypes binding of oracle/libnfagg_oracle.so — CPU ORACLE, TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg. The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libnfagg_oracle.so")
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("nfagg_oracle.c", "nfagg_oracle.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_vp, _u64, _sz = C.c_void_p, C.c_uint64, C.c_size_t
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        l = C.CDLL(_SO)
+        sig = {
+            "orc_accumulate_base": (None, [_vp, _vp]),
+            "orc_accumulate_dns": (None, [_vp, _vp]), "orc_accumulate_drops": (None, [_vp, _vp]),
+            "orc_accumulate_netev": (None, [_vp, _vp]), "orc_accumulate_xlat": (None, [_vp, _vp]),
+            "orc_accumulate_additional": (None, [_vp, _vp]), "orc_accumulate_quic": (None, [_vp, _vp]),
+            "orc_add_uint16": (C.c_uint16, [C.c_uint16, C.c_uint16]),
+            "orc_rollup": (None, [C.c_int, _vp, _sz, _sz, _vp, _vp]),
+            "orc_acc_new": (_vp, [_u64, C.c_int]), "orc_acc_free": (None, [_vp]),
+            "orc_acc_ingest": (_sz, [_vp, _vp, _sz]), "orc_acc_len": (_sz, [_vp]),
+            "orc_acc_evict": (_sz, [_vp, _vp, _sz]),
+            "orc_record_times": (None, [C.c_int64, _u64, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+            "orc_key_hash": (_u64, [_vp]), "orc_ip_hash": (_u64, [_vp, C.c_uint32]),
+            "orc_shard_of": (C.c_uint32, [_vp, C.c_uint32]),
+            "orc_cm_update": (None, [_vp, C.c_uint32, C.c_uint32, _vp, _u64]),
+            "orc_cm_query": (_u64, [_vp, C.c_uint32, C.c_uint32, _vp]),
+            "orc_hll_update": (None, [_vp, C.c_uint32, _vp]),
+            "orc_hll_estimate": (C.c_double, [_vp, C.c_uint32]),
+            "orc_sketch_ingest": (None, [_vp, _sz, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint32]),
+            "orc_bench_flow_id": (None, [_u64, _vp]), "orc_bench_record": (None, [_u64, _u64, _vp]),
+            "orc_zipf_thresholds": (None, [_u64, C.c_double, _vp]),
+            "orc_splitmix64": (_u64, [_u64]),
+            "orc_stream_key_index": (_u64, [_u64, _u64, _u64, _vp, C.c_uint32]),
+            "orc_gen_stream": (None, [_u64, _u64, _sz, _u64, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(l, name)
+            f.restype, f.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+# numpy layouts restated for the oracle's own structs (kept separate from the
+# product's records.py on purpose; tests assert they agree)
+FLOW_ID = np.dtype({"names": ["src_ip", "dst_ip", "src_port", "dst_port", "proto", "icmp_type", "icmp_code", "pad"],
+                    "formats": [("u1", 16), ("u1", 16), "<u2", "<u2", "u1", "u1", "u1", "u1"],
+                    "offsets": [0, 16, 32, 34, 36, 37, 38, 39], "itemsize": 40})
+FLOW_METRICS = np.dtype({
+    "names": ["start", "end", "bytes", "packets", "eth_protocol", "flags", "src_mac", "dst_mac", "if_index_first_seen",
+              "lock", "sampling", "direction_first_seen", "err_no", "dscp", "nb_observed_intf", "observed_direction",
+              "pad2", "observed_intf", "ssl_version", "tls_cipher_suite", "tls_key_share", "tls_types", "misc_flags", "pad4"],
+    "formats": ["<u8", "<u8", "<u8", "<u4", "<u2", "<u2", ("u1", 6), ("u1", 6), "<u4", "<u4", "<u4", "u1", "u1", "u1", "u1",
+                ("u1", 6), ("u1", 2), ("<u4", 6), "<u2", "<u2", "<u2", "u1", "u1", ("u1", 4)],
+    "offsets": [0, 8, 16, 24, 28, 30, 32, 38, 44, 48, 52, 56, 57, 58, 59, 60, 66, 68, 92, 94, 96, 98, 99, 100],
+    "itemsize": 104})
+FLOW_RECORD = np.dtype({"names": ["id", "metrics"], "formats": [FLOW_ID, FLOW_METRICS], "offsets": [0, 40], "itemsize": 144})
+ADDITIONAL = np.dtype({"names": ["start", "end", "flow_rtt", "ipsec_ret", "eth_protocol", "ipsec_encrypted", "pad"],
+                       "formats": ["<u8", "<u8", "<u8", "<i4", "<u2", "u1", "u1"], "offsets": [0, 8, 16, 24, 28, 30, 31], "itemsize": 32})
+DNS = np.dtype({"names": ["start", "end", "latency", "id", "flags", "eth_protocol", "err_no", "name", "pad"],
+                "formats": ["<u8", "<u8", "<u8", "<u2", "<u2", "<u2", "u1", ("u1", 32), "u1"],
+                "offsets": [0, 8, 16, 24, 26, 28, 30, 31, 63], "itemsize": 64})
+DROPS = np.dtype({"names": ["start", "end", "bytes", "packets", "latest_drop_cause", "latest_flags", "eth_protocol", "latest_state", "pad"],
+                  "formats": ["<u8", "<u8", "<u2", "<u2", "<u4", "<u2", "<u2", "u1", ("u1", 3)],
+                  "offsets": [0, 8, 16, 18, 20, 24, 26, 28, 29], "itemsize": 32})
+NETEV = np.dtype({"names": ["start", "end", "network_events", "bytes", "packets", "eth_protocol", "network_events_idx", "pad"],
+                  "formats": ["<u8", "<u8", ("u1", (4, 8)), ("<u2", 4), ("<u2", 4), "<u2", "u1", ("u1", 5)],
+                  "offsets": [0, 8, 16, 48, 56, 64, 66, 67], "itemsize": 72})
+XLAT = np.dtype({"names": ["start", "end", "saddr", "daddr", "sport", "dport", "zone_id", "eth_protocol"],
+                 "formats": ["<u8", "<u8", ("u1", 16), ("u1", 16), "<u2", "<u2", "<u2", "<u2"],
+                 "offsets": [0, 8, 16, 32, 48, 50, 52, 54], "itemsize": 56})
+QUIC = np.dtype({"names": ["start", "end", "version", "eth_protocol", "seen_long_hdr", "seen_short_hdr"],
+                 "formats": ["<u8", "<u8", "<u4", "<u2", "u1", "u1"], "offsets": [0, 8, 16, 20, 22, 23], "itemsize": 24})
+KIND_DTYPES = [ADDITIONAL, DNS, DROPS, NETEV, XLAT, QUIC]
+KIND_INDEX = {"additional": 0, "dns": 1, "drops": 2, "network_events": 3, "xlat": 4, "quic": 5}
+
+# orc_content (nfagg_oracle.h): base, six int flags, then the six parts in declaration order
+CONTENT = np.dtype([("base", FLOW_METRICS), ("has_dns", "<i4"), ("has_drops", "<i4"), ("has_netev", "<i4"),
+                    ("has_xlat", "<i4"), ("has_additional", "<i4"), ("has_quic", "<i4"),
+                    ("dns", DNS), ("drops", DROPS), ("netev", NETEV), ("xlat", XLAT),
+                    ("additional", ADDITIONAL), ("quic", QUIC)], align=False)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Accounter:
+    """orc_accounter: pkg/flow/account.go restated (oracle)."""
+
+    def __init__(self, max_entries, mode=0):
+        self._a = lib().orc_acc_new(max_entries, mode)
+
+    def ingest(self, records) -> int:
+        r = np.ascontiguousarray(records)
+        return lib().orc_acc_ingest(self._a, _p(r), r.nbytes // 144)
+
+    def __len__(self):
+        return lib().orc_acc_len(self._a)
+
+    def evict(self) -> np.ndarray:
+        n = len(self)
+        out = np.zeros(max(n, 1), dtype=FLOW_RECORD)
+        got = lib().orc_acc_evict(self._a, _p(out), n)
+        return out[:got]
+
+    def close(self):
+        if self._a:
+            lib().orc_acc_free(self._a)
+            self._a = None
+
+    def __del__(self):
+        self.close()
+
+
+def run_accounter(records, max_entries, mode=0):
+    """Drive the oracle exactly like Accounter.Account does: fold, evict on full
+    (account.go:85-94), final eviction on close (:73-80). Returns the list of
+    evicted batches (each sorted by key) and their reasons."""
+    acc = Accounter(max_entries, mode)
+    r = np.ascontiguousarray(records)
+    n = r.nbytes // 144
+    raw = r.view(np.uint8).reshape(-1)
+    out, off = [], 0
+    while off < n:
+        c = acc.ingest(raw[off * 144:])
+        off += c
+        if off < n:
+            out.append(("full", acc.evict()))
+    out.append(("closing", acc.evict()))
+    acc.close()
+    return out
+
+
+def gen_stream(n, j0=0, seed=1, n_keys=1000, thresholds=None, hot_permille=0, variant=0, pop_index=None):
+    out = np.zeros(n, dtype=FLOW_RECORD)
+    th = _p(thresholds) if thresholds is not None else None
+    pi = _p(pop_index) if pop_index is not None else None
+    lib().orc_gen_stream(seed, j0, n, n_keys, th, hot_permille, variant, pi, _p(out))
+    return out
+
+
+def zipf_thresholds(n_keys, s):
+    out = np.zeros(n_keys, dtype=np.uint64)
+    lib().orc_zipf_thresholds(n_keys, s, _p(out))
+    return out
+
+
+def sketches(records, depth=4, log2w=20, p=14):
+    r = np.ascontiguousarray(records)
+    cm_s = np.zeros(depth << log2w, dtype=np.uint64)
+    cm_d = np.zeros(depth << log2w, dtype=np.uint64)
+    hs = np.zeros(1 << p, dtype=np.uint8)
+    hd = np.zeros(1 << p, dtype=np.uint8)
+    lib().orc_sketch_ingest(_p(r), r.nbytes // 144, _p(cm_s), _p(cm_d), depth, log2w, _p(hs), _p(hd), p)
+    return cm_s, cm_d, hs, hd
+
+
+def hll_estimate(regs, p):
+    r = np.ascontiguousarray(regs, dtype=np.uint8)
+    return lib().orc_hll_estimate(_p(r), p)
+
+
+def rollup(kind, partials, n_cpu, base):
+    k = KIND_INDEX[kind]
+    dt = KIND_DTYPES[k]
+    parts = np.ascontiguousarray(partials).view(np.uint8).reshape(-1)
+    n_flows = parts.size // dt.itemsize // n_cpu
+    b = np.ascontiguousarray(base).copy()
+    folded = np.zeros(n_flows, dtype=dt)
+    lib().orc_rollup(k, _p(parts), n_flows, n_cpu, _p(b), _p(folded))
+    return b, folded
