@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — flow-records/s of the MI355X flow-aggregation hot path.
+
+One "step" = one pass of the hot path over one batch of synthetic input:
+fold a Zipf(1.1) stream of 144-byte flow_record_t (already resident in HBM)
+into the flow table (nfagg_ingest_device) and evict it (nfagg_evict_device).
+Workload at N=1: BASELINE.json configs[1] — 100 M records, 1 M unique flows,
+hash-aggregate only. At N>1 the records shard by flow-key hash: every rank owns
+the population members whose key hashes to it and folds its own stream of the
+same size (weak scaling, no data-path collective; --sketches adds the per-tick
+RCCL all-reduce of the Count-Min / HLL arrays, configs[2]/[3]).
+
+Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit,
+`roofline` (HBM-bound: algorithmic bytes / ingest-kernel time measured with HIP
+events on the kernel's stream) and `cpu_baseline` (the CPU oracle — a C
+restatement of pkg/flow.Accounter — timed on a bounded sample of the same stream).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_INGEST = 392      # 144 read record + 144 read slot + 104 write value
+ALG_BYTES_SKETCH = 130      # CM 2 keys x 4 rows x (8+8) + HLL 2 x (1+1)
+ALG_BYTES_EVICT = 296       # per evicted flow
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--records", type=int, default=100_000_000, help="records per GPU per step")
+    ap.add_argument("--flows", type=int, default=1_000_000, help="unique flows per GPU")
+    ap.add_argument("--zipf", type=float, default=1.1)
+    ap.add_argument("--hot-permille", type=int, default=0, help="configs[4]: share of records hitting one flow")
+    ap.add_argument("--sketches", action="store_true", help="configs[2]/[3]: CM(d=4,w=2^20)+HLL(p=14), all-reduced per step when N>1")
+    ap.add_argument("--variant", type=int, default=0, help="ingest kernel variant (DESIGN.md)")
+    ap.add_argument("--chunk", type=int, default=0, help="records per nfagg_ingest_device call (0 = whole stream)")
+    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="records of the stream the CPU oracle is timed on (0 = skip)")
+    ap.add_argument("--max-entries", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import netobserv_ebpf_agent_amd as nf
+    from netobserv_ebpf_agent_amd import synth
+
+    n, keys = args.records, args.flows
+    # ---- synthetic stream, generated in HBM (seed 2)
+    th = synth.zipf_thresholds(keys, args.zipf)
+    d_th = torch.from_numpy(th.view(np.int64)).cuda()
+    d_pop = None
+    if world > 1:
+        pop = synth.shard_population(keys, world, rank)
+        d_pop = torch.from_numpy(pop.view(np.int64)).cuda()
+    d_recs = torch.empty(n * 144, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    seed = 2 + 1000 * rank
+    synth.stream_device(d_recs.data_ptr(), n, seed=seed, n_keys=keys, d_thresholds=d_th.data_ptr(),
+                        hot_permille=args.hot_permille, d_pop_index=d_pop.data_ptr() if d_pop is not None else 0)
+    torch.cuda.synchronize()
+
+    max_entries = args.max_entries or max(1 << 22, 4 * keys)
+    sk_flags = (nf.SKETCH_CM | nf.SKETCH_HLL) if args.sketches else 0
+    ext = None
+    cm_t = hll_t = None
+    if args.sketches:
+        cm_t = [torch.zeros(4 << 20, dtype=torch.int64, device="cuda") for _ in range(2)]
+        hll_t = [torch.zeros(1 << 14, dtype=torch.int32, device="cuda") for _ in range(2)]
+        ext = [cm_t[0].data_ptr(), cm_t[1].data_ptr(), hll_t[0].data_ptr(), hll_t[1].data_ptr()]
+        torch.cuda.synchronize()
+    tab = nf.FlowTable(max_entries=max_entries, device=local_rank, sketches=sk_flags, profile=True,
+                       ingest_variant=args.variant, n_shards=world, shard_id=rank, ext_sketch=ext)
+    d_out = torch.empty(keys * 144 + 16, dtype=torch.uint8, device="cuda")
+    chunk = args.chunk or n
+
+    def step():
+        off = 0
+        while off < n:
+            m = min(chunk, n - off)
+            rc, c = tab.ingest_device(d_recs.data_ptr() + off * 144, m)
+            assert rc == nf.OK and c == m, (rc, c)
+            off += m
+        if args.sketches and world > 1:
+            tab.sync()          # the sketch kernels run on the table's stream
+            for t in cm_t:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            for t in hll_t:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        flows = tab.evict_device(d_out.data_ptr(), keys, nf.REASON_TIMEOUT)
+        if args.sketches:
+            tab.sketch_reset()
+        return flows
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    flows = 0
+    for _ in range(args.warmup):
+        flows = step()
+    barrier()
+    tab.reset_profile()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        flows = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    st = tab.stats()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        f = torch.tensor([flows], dtype=torch.int64, device="cuda")
+        dist.all_reduce(f, op=dist.ReduceOp.SUM)
+        flows_total = int(f.item())
+    else:
+        flows_total = flows
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        total_records = n * world * steps
+        ingest_ms = st.ingest_kernel_ms / max(st.ingest_launches, 1)
+        recs_per_launch = n * steps / max(st.ingest_launches, 1)
+        achieved = ALG_BYTES_INGEST * recs_per_launch / (ingest_ms * 1e-3) / 1e9 if ingest_ms > 0 else 0.0
+        out = {
+            "metric": "flow-records/s ingested + evictions/s, 1/2/4/8 GPU; % HBM roofline",
+            "value": round(total_records / dt / 1e6, 3),
+            "unit": "Mrecords/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": ("configs[1]: %dM-record Zipf(%.1f) stream, %dk unique flows per GPU, hash-aggregate%s, device-resident input"
+                             % (n // 1_000_000, args.zipf, keys // 1000, "+CM(d=4,w=2^20)+HLL(p=14)" if args.sketches else " only")),
+                "records_per_gpu_per_step": n, "unique_flows_per_gpu": keys, "hot_permille": args.hot_permille,
+                "parallelism": "key-hash shards x%d" % world, "ingest_variant": args.variant,
+                "evictions_per_step": 1, "evicted_flows_per_step": flows_total,
+                "evictions_per_s": round(steps / dt, 3), "evicted_flows_per_s": round(flows_total * steps / dt, 1),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_ingest (hash-insert/fold)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_record": ALG_BYTES_INGEST, "records_per_launch": int(recs_per_launch),
+                "launch_ms": round(ingest_ms, 4), "launches": int(st.ingest_launches),
+                "kernel_Mrecords_per_s": round(recs_per_launch / (ingest_ms * 1e-3) / 1e6, 1) if ingest_ms > 0 else None,
+                "evict_launch_ms": round(st.evict_kernel_ms / max(st.evict_launches, 1), 4),
+                "sketch_launch_ms": round(st.sketch_kernel_ms / max(st.sketch_launches, 1), 4) if st.sketch_launches else None,
+            },
+        }
+        # ---- CPU baseline: the oracle (C restatement of pkg/flow.Accounter), 1 core, bounded sample
+        if args.cpu_sample > 0:
+            from oracle import oracle as O
+            O.build()
+            m = min(args.cpu_sample, n)
+            sample = d_recs[: m * 144].cpu().numpy()
+            acc = O.Accounter(max_entries)
+            t1 = time.perf_counter()
+            consumed = acc.ingest(sample)
+            ev = acc.evict()
+            cpu_dt = time.perf_counter() - t1
+            acc.close()
+            assert consumed == m
+            out["cpu_baseline"] = {
+                "value": round(m / cpu_dt / 1e6, 3), "unit": "Mrecords/s", "cores": 1, "kind": "port",
+                "sample": "first %d records of rank 0's stream (%d flows), oracle Accounter ingest+evict, %.1f s" % (m, len(ev), cpu_dt),
+                "host_cores_available": os.cpu_count(),
+            }
+        print(json.dumps(out), flush=True)
+    tab.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

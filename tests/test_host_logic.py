@@ -1,0 +1,122 @@
+"""Host-side pieces of the boundary that need no GPU, checked against the oracle:
+hashes/sharding, record time derivation (record.go:90-97), the HLL estimator,
+the synthetic generators."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_key_hash_and_shard_match_oracle(nf, O):
+    recs = O.gen_stream(2000, seed=7, n_keys=500, variant=1)      # dirty padding byte 39 included
+    for r in recs[:300]:
+        kb = r["id"].tobytes()
+        assert nf.key_hash(kb) == O.lib().orc_key_hash(kb)
+        for n in (1, 2, 3, 8):
+            assert nf.shard_of(kb, n) == O.lib().orc_shard_of(kb, n) < n
+    # byte 39 is not part of the key (bpf_x86_bpfel.go:119 blank field)
+    kb = bytearray(recs[0]["id"].tobytes()); h0 = nf.key_hash(bytes(kb)); kb[39] ^= 0xff
+    assert nf.key_hash(bytes(kb)) == h0
+
+
+def test_ip_hash_matches_oracle(nf, O):
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        ip = rng.integers(0, 256, 16, dtype=np.uint8).tobytes()
+        for s in range(4):
+            assert nf.ip_hash(ip, s) == O.lib().orc_ip_hash(ip, s)
+
+
+def test_shards_partition_the_population(nf):
+    from netobserv_ebpf_agent_amd import synth
+    pops = [synth.shard_population(2000, 4, s) for s in range(4)]
+    allm = np.concatenate(pops)
+    assert len(np.unique(allm)) == len(allm)              # disjoint
+    lo = int(min(p.max() for p in pops))
+    assert set(range(lo + 1)) <= set(allm.tolist())        # and covering: every member up to the shortest shard's reach
+
+
+def test_record_times_match_oracle_and_reference_vector(nf, O):
+    # account_test.go:104-126: now - (1000-123) ns / now - (1000-789) ns
+    now = 1661272402 * 10**9
+    m = np.zeros(1, dtype=nf.FLOW_METRICS)
+    m["start_mono_time_ts"], m["end_mono_time_ts"] = 123, 789
+    s, e = nf.record_times(now, 1000, m[0])
+    assert (s, e) == (now - (1000 - 123), now - (1000 - 789))
+    rng = np.random.default_rng(5)
+    for _ in range(100):
+        m["start_mono_time_ts"] = int(rng.integers(0, 2**63)) * 2 + int(rng.integers(0, 2))
+        m["end_mono_time_ts"] = int(rng.integers(0, 2**63))
+        mono = int(rng.integers(0, 2**63))
+        a, b = C.c_int64(0), C.c_int64(0)
+        om = m.view(O.FLOW_METRICS)
+        O.lib().orc_record_times(now, mono, om.ctypes.data_as(C.c_void_p), C.byref(a), C.byref(b))
+        assert nf.record_times(now, mono, m[0]) == (a.value, b.value)     # uint64 wrap included
+
+
+def test_new_record_mirrors_reference(nf):
+    """pkg/model/record.go:82-114 through the host mirror (account_test.go expectations)."""
+    r = np.zeros(1, dtype=nf.FLOW_RECORD)[0]
+    r["metrics"]["start_mono_time_ts"], r["metrics"]["end_mono_time_ts"] = 123, 789
+    r["metrics"]["nb_observed_intf"] = 2
+    r["metrics"]["observed_intf"][:2] = [7, 8]
+    r["metrics"]["observed_direction"][:2] = [1, 0]
+    now = 1661272402 * 10**9
+    rec = nf.NewRecord(r["id"], r["metrics"], now, 1000)
+    assert rec.TimeFlowStart == now - 877 and rec.TimeFlowEnd == now - 211
+    assert [(i.Interface, i.Direction, i.Udn) for i in rec.Interfaces] == [
+        ("[namer unset] 0", 0, ""), ("[namer unset] 7", 1, ""), ("[namer unset] 8", 0, "")]
+
+
+def test_hll_estimator_from_histogram_within_1ulp_of_scalar(nf, O):
+    """north_star: HLL estimate agrees with a scalar HLL on the same registers to ±1 ULP."""
+    rng = np.random.default_rng(11)
+    for p, n in ((14, 50), (14, 20000), (14, 400000), (10, 3000), (4, 3), (16, 5_000_000)):
+        regs = np.zeros(1 << p, dtype=np.uint8)
+        # geometric register values as a real HLL would produce for ~n items
+        idx = rng.integers(0, 1 << p, size=min(n, 2_000_000))
+        rho = np.minimum(rng.geometric(0.5, size=idx.size), 64 - p + 1).astype(np.uint8)
+        np.maximum.at(regs, idx, rho)
+        hist = np.bincount(regs, minlength=65).astype(np.uint32)
+        got = nf.hll_estimate_from_histogram(hist, p)
+        want = O.hll_estimate(regs, p)
+        assert abs(got - want) <= np.spacing(want), (p, n, got, want)
+    # empty sketch: linear counting of m zeros -> 0
+    assert nf.hll_estimate_from_histogram(np.bincount(np.zeros(1 << 14, dtype=np.uint8), minlength=65), 14) == 0.0
+
+
+def test_synth_host_generator_matches_oracle_generator(nf, O):
+    from netobserv_ebpf_agent_amd import synth
+    th_p = synth.zipf_thresholds(1000, 1.1)
+    th_o = O.zipf_thresholds(1000, 1.1)
+    assert np.array_equal(th_p, th_o)
+    pop = synth.shard_population(1000, 2, 1)
+    for kw in (dict(variant=0), dict(variant=1), dict(variant=1, hot_permille=900), dict(variant=0, pop_index=pop)):
+        a = synth.stream_host(5000, j0=17, seed=42, n_keys=1000, thresholds=th_p, **kw)
+        b = O.gen_stream(5000, j0=17, seed=42, n_keys=1000, thresholds=th_o, **kw)
+        assert a.tobytes() == b.tobytes(), kw
+    # uniform draw (no table)
+    assert synth.stream_host(3000, seed=1, n_keys=1000).tobytes() == O.gen_stream(3000, seed=1, n_keys=1000).tobytes()
+
+
+def test_zipf_stream_shape(O):
+    """Zipf(1.1) over 1000 keys: rank 0 gets ~1/H of the records."""
+    th = O.zipf_thresholds(1000, 1.1)
+    recs = O.gen_stream(200000, seed=2, n_keys=1000, thresholds=th)
+    ports = recs["id"]["src_port"].astype(np.int64) - 1024
+    h = sum(k ** -1.1 for k in range(1, 1001))
+    frac0 = (ports == 0).mean()
+    assert abs(frac0 - 1 / h) < 0.01
+    assert len(np.unique(ports)) > 900
+
+
+def test_config1_plumbing_through_oracle(O):
+    """BASELINE configs[0]: 10k records, 1k unique keys, CPU only (no GPU): the
+    oracle's Accounter, bytes/packets conserved."""
+    recs = O.gen_stream(10000, seed=1, n_keys=1000)
+    out = O.run_accounter(recs, max_entries=5000)
+    assert [r for r, _ in out] == ["closing"]
+    ev = out[0][1]
+    assert len(ev) == len(np.unique(recs["id"]["src_port"]))
+    assert int(ev["metrics"]["bytes"].sum()) == int(recs["metrics"]["bytes"].sum())
+    assert int(ev["metrics"]["packets"].sum()) == int(recs["metrics"]["packets"].sum())

@@ -1,0 +1,253 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs — bit-exact on every byte of every evicted
+flow_record_t. Mirrors the reference's own tests where they exist
+(pkg/flow/account_test.go) and widens to the cases SURVEY.md §8(c) lists as
+unpinned (order-dependent fields, wrap-around, evict-on-full inside a batch)."""
+import queue
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from conftest import assert_records_equal
+from test_oracle_kat import K1, K2, K3, mk
+
+pytestmark = pytest.mark.gpu
+
+PN = dict(start="start_mono_time_ts", end="end_mono_time_ts")
+
+
+def drive_product(tab, records, batch):
+    """Feed `records` in arrival order in batches; evict on NFAGG_FULL exactly as
+    account.go:85-94; final eviction as on close (:73-80)."""
+    nf = __import__("netobserv_ebpf_agent_amd")
+    out, off, n = [], 0, len(records)
+    while off < n:
+        hi = min(n, off + batch)
+        while off < hi:
+            rc, c = tab.ingest(records[off:hi])
+            off += c
+            if rc == nf.FULL:
+                out.append(("full", nf.sort_by_key(tab.evict(nf.REASON_FULL))))
+    out.append(("closing", nf.sort_by_key(tab.evict(nf.REASON_CLOSING))))
+    return out
+
+
+def check_against_oracle(nf, O, records, max_entries, batch, **table_kw):
+    want = O.run_accounter(records, max_entries)
+    with nf.FlowTable(max_entries=max_entries, **table_kw) as tab:
+        got = drive_product(tab, records.view(nf.FLOW_RECORD), batch)
+    assert [r for r, _ in got] == [r for r, _ in want], "eviction sequence differs"
+    for k, ((_, g), (_, w)) in enumerate(zip(got, want)):
+        assert_records_equal(g, w, f"eviction #{k}")
+    return want
+
+
+# ---------------------------------------------------------------- reference tests through the C ABI
+def test_evict_max_entries(nf):
+    """pkg/flow/account_test.go:47-128 TestEvict_MaxEntries, via the host mirror of Accounter.Account."""
+    now = 1661272402 * 10**9
+    acc = nf.NewAccounter(2, 3600.0, lambda: now, lambda: 1000, nf.NoOp())
+    inputs, evictor = queue.Queue(), queue.Queue()
+    th = threading.Thread(target=acc.Account, args=(inputs, evictor), daemon=True)
+    th.start()
+    assert evictor.empty()
+    R = nf.FLOW_RECORD
+    inputs.put(mk(R, K1, PN, bytes=123, packets=1, start=123, end=123, flags=1))
+    inputs.put(mk(R, K2, PN, bytes=456, packets=1, start=456, end=456, flags=1))
+    inputs.put(mk(R, K1, PN, bytes=321, packets=1, start=789, end=789, flags=1))
+    time.sleep(0.5)
+    assert evictor.empty()                                   # nothing evicted until the maximum is surpassed
+    inputs.put(mk(R, K3, PN, bytes=111, packets=1, start=888, end=888, flags=1))
+    r = evictor.get(timeout=10)
+    assert len(r) == 2
+    by_port = {int(x.ID["src_port"]): x for x in r}
+    a, b = by_port[333], by_port[12]
+    m = a.Metrics
+    assert (m["bytes"], m["packets"], m["start_mono_time_ts"], m["end_mono_time_ts"], m["flags"]) == (444, 2, 123, 789, 1)
+    assert a.TimeFlowStart == now - (1000 - 123) and a.TimeFlowEnd == now - (1000 - 789)
+    assert [(i.Interface, i.Direction) for i in a.Interfaces] == [("[namer unset] 0", 0)]
+    m = b.Metrics
+    assert (m["bytes"], m["packets"], m["start_mono_time_ts"], m["end_mono_time_ts"], m["flags"]) == (456, 1, 456, 456, 1)
+    assert b.TimeFlowStart == now - (1000 - 456) and b.TimeFlowEnd == now - (1000 - 456)
+    time.sleep(0.2)
+    assert evictor.empty()
+    assert acc.metrics.evictions_total == {("accounter", "full"): 1}
+    assert acc.metrics.evicted_flows_total == {("accounter", "full"): 2}
+    inputs.put(nf.CLOSE)
+    r = evictor.get(timeout=10)                              # closing flushes k3 (account.go:73-80)
+    assert len(r) == 1 and int(r[0].ID["dst_port"]) == 443 and int(r[0].Metrics["bytes"]) == 111
+    th.join(timeout=10)
+    acc.close()
+
+
+def test_evict_period(nf):
+    """pkg/flow/account_test.go:130-217 TestEvict_Period (timeouts scaled up: a GPU box pages the HIP module in)."""
+    now = 1661272402 * 10**9
+    acc = nf.NewAccounter(200, 0.4, lambda: now, lambda: 1000, nf.NoOp())
+    len(acc.table)                                           # warm the device before the clock matters
+    inputs, evictor = queue.Queue(), queue.Queue()
+    th = threading.Thread(target=acc.Account, args=(inputs, evictor), daemon=True)
+    th.start()
+    R = nf.FLOW_RECORD
+    for t in (123, 456, 789):
+        inputs.put(mk(R, K1, PN, bytes=10, packets=1, start=t, end=t, flags=1))
+    time.sleep(0.8)                                          # forcing at least one eviction here
+    for t in (1123, 1456):
+        inputs.put(mk(R, K1, PN, bytes=10, packets=1, start=t, end=t, flags=1))
+    r = evictor.get(timeout=10)
+    assert len(r) == 1
+    m = r[0].Metrics
+    assert (m["bytes"], m["packets"], m["start_mono_time_ts"], m["end_mono_time_ts"], m["flags"]) == (30, 3, 123, 789, 1)
+    assert r[0].TimeFlowStart == now - 1000 + 123 and r[0].TimeFlowEnd == now - 1000 + 789
+    r = evictor.get(timeout=10)
+    assert len(r) == 1
+    m = r[0].Metrics
+    assert (m["bytes"], m["packets"], m["start_mono_time_ts"], m["end_mono_time_ts"], m["flags"]) == (20, 2, 1123, 1456, 1)
+    time.sleep(0.9)
+    assert evictor.empty()                                   # no more flows are evicted (empty table: no eviction, :64-66)
+    inputs.put(nf.CLOSE)
+    assert evictor.get(timeout=10) == []                     # closing always sends, even an empty batch
+    th.join(timeout=10)
+    acc.close()
+
+
+# ---------------------------------------------------------------- seeded streams vs the oracle
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("ingest_variant", [0, 1])
+@pytest.mark.parametrize("batch", [1 << 30, 1000, 257])
+def test_stream_parity(nf, O, variant, ingest_variant, batch):
+    th = O.zipf_thresholds(3000, 1.1)
+    recs = O.gen_stream(40000, seed=100 + variant, n_keys=3000, thresholds=th, variant=variant)
+    want = check_against_oracle(nf, O, recs, 1 << 16, batch, ingest_variant=ingest_variant)
+    assert len(want) == 1 and len(want[0][1]) > 1500
+
+
+def test_single_record_batches(nf, O):
+    recs = O.gen_stream(600, seed=5, n_keys=40, variant=1)
+    check_against_oracle(nf, O, recs, 1000, 1)
+
+
+def test_config1_10k_records_1k_keys(nf, O):
+    """BASELINE configs[0] on the GPU path (the CPU-only leg is tests/test_host_logic.py)."""
+    recs = O.gen_stream(10000, seed=1, n_keys=1000)
+    want = check_against_oracle(nf, O, recs, 5000, 1 << 30)
+    assert len(want[0][1]) == len(np.unique(recs["id"]["src_port"]))
+
+
+@pytest.mark.parametrize("ingest_variant", [0, 1])
+def test_hot_key_stream(nf, O, ingest_variant):
+    """BASELINE configs[4] shape: 90 % of the records are one flow (LDS / atomic contention)."""
+    th = O.zipf_thresholds(5000, 1.1)
+    recs = O.gen_stream(60000, seed=5, n_keys=5000, thresholds=th, hot_permille=900, variant=1)
+    check_against_oracle(nf, O, recs, 1 << 16, 1 << 30, ingest_variant=ingest_variant)
+
+
+def test_wraparound_and_zero_fields(nf, O):
+    """u64 bytes / u32 packets wrap (flow_content.go:42-43) and all-zero optional fields."""
+    recs = O.gen_stream(3000, seed=9, n_keys=3, variant=1)   # ~1000 records per key, wrap values injected
+    check_against_oracle(nf, O, recs, 100, 1 << 30)
+    z = np.zeros(10, dtype=O.FLOW_RECORD)                     # ten all-zero records: one flow, everything zero
+    check_against_oracle(nf, O, z, 100, 1 << 30)
+
+
+@pytest.mark.parametrize("max_entries,batch", [(2, 1 << 30), (100, 1 << 30), (100, 333), (1, 50), (999, 4096), (3000, 1 << 30)])
+def test_evict_on_full_inside_batches(nf, O, max_entries, batch):
+    """account.go:85-94: the arrival of the (maxEntries+1)-th distinct key flushes what was
+    accumulated so far — the split point must be found inside a parallel batch."""
+    th = O.zipf_thresholds(1000, 1.1)
+    recs = O.gen_stream(20000, seed=77, n_keys=1000, thresholds=th, variant=1)
+    want = check_against_oracle(nf, O, recs, max_entries, batch)
+    if max_entries < 500:
+        assert sum(1 for r, _ in want if r == "full") >= 2
+        assert all(len(b) == max_entries for r, b in want if r == "full")
+
+
+def test_empty_and_ragged_inputs(nf, O):
+    with nf.FlowTable(max_entries=16) as tab:
+        assert tab.ingest(np.zeros(0, dtype=nf.FLOW_RECORD)) == (nf.OK, 0)
+        assert len(tab) == 0
+        assert len(tab.evict(nf.REASON_TIMEOUT)) == 0
+        s = tab.stats()
+        assert list(s.evictions) == [0, 0, 0]                 # an empty table does not count a timeout eviction (:64-66)
+        assert len(tab.evict(nf.REASON_CLOSING)) == 0
+        assert list(tab.stats().evictions) == [0, 0, 1]       # closing does (:78)
+    for n in (1, 63, 64, 65, 255, 256, 257, 1023):            # ragged tile tails
+        recs = O.gen_stream(n, seed=n, n_keys=50, variant=1)
+        check_against_oracle(nf, O, recs, 1000, 1 << 30)
+
+
+def test_epochs_are_independent(nf, O):
+    """After an eviction the table starts from nothing: two ticks = two independent folds."""
+    a = O.gen_stream(5000, seed=1, n_keys=300, variant=1)
+    b = O.gen_stream(5000, j0=5000, seed=1, n_keys=300, variant=1)
+    with nf.FlowTable(max_entries=1000) as tab:
+        for part in (a, b):
+            assert tab.ingest(part.view(nf.FLOW_RECORD)) == (nf.OK, len(part))
+            got = nf.sort_by_key(tab.evict(nf.REASON_TIMEOUT))
+            want = O.run_accounter(part, 1000)[0][1]
+            assert_records_equal(got, want)
+            assert len(tab) == 0
+
+
+def test_truncated_evict_keeps_state(nf, O):
+    import ctypes as C
+    recs = O.gen_stream(2000, seed=3, n_keys=100)
+    with nf.FlowTable(max_entries=1000) as tab:
+        tab.ingest(recs.view(nf.FLOW_RECORD))
+        n = len(tab)
+        out = np.zeros(10, dtype=nf.FLOW_RECORD)
+        got = C.c_size_t(0)
+        rc = nf._lib.lib.nfagg_evict(tab._h, nf.REASON_TIMEOUT, out.ctypes.data_as(C.c_void_p), 10, C.byref(got))
+        assert rc == nf.TRUNCATED and got.value == n and len(tab) == n
+        assert_records_equal(nf.sort_by_key(tab.evict()), O.run_accounter(recs, 1000)[0][1])
+
+
+def test_staging_acquire_commit(nf, O):
+    recs = O.gen_stream(5000, seed=21, n_keys=400, variant=1)
+    with nf.FlowTable(max_entries=1000, staging_records=2048) as tab:
+        off = 0
+        while off < len(recs):
+            buf = tab.staging_acquire()
+            m = min(len(buf), len(recs) - off)
+            buf[:m] = recs[off:off + m].view(nf.FLOW_RECORD)
+            rc, c = tab.staging_commit(m)
+            assert (rc, c) == (nf.OK, m)
+            off += m
+        assert_records_equal(nf.sort_by_key(tab.evict()), O.run_accounter(recs, 1000)[0][1])
+
+
+def test_small_staging_ring_many_chunks(nf, O):
+    recs = O.gen_stream(30000, seed=22, n_keys=2000, variant=1)
+    check_against_oracle(nf, O, recs, 4096, 1 << 30, staging_records=1000)
+
+
+@pytest.mark.parametrize("n_shards", [2, 8])
+def test_sharded_tables_cover_the_stream(nf, O, n_shards):
+    """Records shard by flow-key hash; every shard folds only its own keys; the
+    concatenation of the shards' evictions equals the unsharded result."""
+    th = O.zipf_thresholds(2000, 1.1)
+    recs = O.gen_stream(30000, seed=8, n_keys=2000, thresholds=th, variant=1)
+    parts, skipped = [], 0
+    for s in range(n_shards):
+        with nf.FlowTable(max_entries=4096, n_shards=n_shards, shard_id=s) as tab:
+            assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
+            ev = tab.evict()
+            assert all(nf.shard_of(r["id"].tobytes(), n_shards) == s for r in ev[:50])
+            skipped += tab.stats().records_skipped
+            parts.append(ev)
+    assert skipped == (n_shards - 1) * len(recs)
+    got = nf.sort_by_key(np.concatenate(parts))
+    assert_records_equal(got, O.run_accounter(recs, 1 << 20)[0][1])
+
+
+def test_idempotent_refold_of_evicted_records(nf, O):
+    """Round trip: an evicted batch fed back in (one record per key) evicts unchanged."""
+    recs = O.gen_stream(20000, seed=31, n_keys=1500, variant=1)
+    with nf.FlowTable(max_entries=4096) as tab:
+        tab.ingest(recs.view(nf.FLOW_RECORD))
+        first = nf.sort_by_key(tab.evict())
+        tab.ingest(first)
+        again = nf.sort_by_key(tab.evict())
+        assert_records_equal(again, first)
