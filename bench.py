@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="records of the stream the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--max-entries", type=int, default=0)
     args = ap.parse_args()
+    if os.environ.get("NFAGG_BENCH_WATCHDOG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["NFAGG_BENCH_WATCHDOG"]), exit=True)
 
     import torch
     import torch.distributed as dist

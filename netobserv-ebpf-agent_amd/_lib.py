@@ -12,6 +12,15 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
         "(or __graft_entry__.build()). libnfagg has no CPU/Python fallback.")
 
+# PyTorch-ROCm bundles its own libamdhip64.so (same soname as /opt/rocm's). A
+# process must use ONE HIP runtime: when torch is installed, let it load first so
+# libnfagg.so binds to the runtime torch's tensors, streams and RCCL live in.
+# (A Go/C host without torch simply gets /opt/rocm's runtime.)
+try:
+    import torch  # noqa: F401
+except Exception:   # torch is optional plumbing, not a dependency of the library
+    torch = None
+
 lib = C.CDLL(LIB_PATH)
 
 OK, FULL, TRUNCATED = 0, 1, 2

@@ -139,7 +139,8 @@ int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t 
 int refresh_counters(nfagg_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->h_ctr, h->tv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (h->h_ctr->error) return fail(h, NFAGG_EDEVICE, "flow table probe overflow (table too small for the live key set)");
+    if (h->h_ctr->error)
+        return fail(h, NFAGG_EDEVICE, "flow table kernel bailed out (code %u: 1 = probe overflow / table too small, 2 = claim spin limit, 3 = slot lock spin limit)", h->h_ctr->error);
     h->live_ub = h->h_ctr->n_live;
     if (!h->must_evict) h->live = h->h_ctr->n_live;
     h->stats.records_skipped = h->h_ctr->n_skipped;

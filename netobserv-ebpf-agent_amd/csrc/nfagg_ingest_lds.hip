@@ -115,15 +115,14 @@ __global__ __launch_bounds__(T) void k_ingest_lds(TableView t, const void* __res
             p.eth_tag = et ? ((tile_seq + (et >> 16)) << 16) | (et & 0xffffu) : 0ull;   // (seq+1)<<16 | eth
             p.dscp_tag = dt ? ((tile_seq + (dt >> 8)) << 8) | (dt & 0xffu) : 0ull;
             p.samp_tag = st ? ((tile_seq + (st >> 32)) << 32) | (st & 0xffffffffull) : 0ull;
-            p.first_inv = ~(tile_seq + li);
+            p.first_inv = ~(uint32_t)(tile_seq + li);
             const uint64_t sm = L.smac_tag[rep], dm = L.dmac_tag[rep];
             p.smac = (sm != ~0ull) ? (sm & 0xffffffffffffull) : 0ull;
             p.dmac = (dm != ~0ull) ? (dm & 0xffffffffffffull) : 0ull;
-            p.smac_inv = (sm != ~0ull) ? ~(tile_seq + (sm >> 48)) : 0ull;
-            p.dmac_inv = (dm != ~0ull) ? ~(tile_seq + (dm >> 48)) : 0ull;
+            p.smac_inv = (sm != ~0ull) ? ~(uint32_t)(tile_seq + (sm >> 48)) : 0u;
+            p.dmac_inv = (dm != ~0ull) ? ~(uint32_t)(tile_seq + (dm >> 48)) : 0u;
 #pragma unroll
-            for (int k = 0; k < 7; k++) p.ident[k] = (uint64_t)r.d[21 + 2 * k] | ((uint64_t)r.d[22 + 2 * k] << 32);
-            p.ident[7] = 0;
+            for (int k = 0; k < 15; k++) p.ident[k] = r.d[21 + k];
             const uint32_t idx = find_or_claim(t, w, h);
             if (idx != kNoSlot) merge_partial(t, idx, p);
         }
@@ -138,7 +137,7 @@ hipError_t launch_ingest_lds(const TableView& t, const void* d_records, uint64_t
     constexpr int T = 256;
     uint64_t tiles = (n + T - 1) / T;
     uint64_t grid = tiles < 256ull * 8 ? tiles : 256ull * 8;
-    hipLaunchKernelGGL(k_ingest_lds<T>, dim3((unsigned)grid), dim3(T), 0, s, t, d_records, n, seq_base);
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_ingest_lds<T>, dim3((unsigned)grid), dim3(T), 0, s, t, d_records, n, seq_base);
     return hipGetLastError();
 }
 

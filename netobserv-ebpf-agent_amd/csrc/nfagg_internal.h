@@ -19,8 +19,14 @@ constexpr int kKeyBytes = 40;       // bpf/types.h:191-204
 
 // All 64-bit words of a slot are accessed with agent-scope atomics while an
 // ingest kernel runs (per-XCD L2s are not coherent with each other; see
-// DESIGN.md §coherence). Identities are zero so that eviction can reset a
-// slot by zeroing it.
+// DESIGN.md §coherence). Identities are zero so that eviction resets a slot by
+// zeroing it. Sequence numbers are epoch-relative and fit 32 bits (the API
+// refuses to let an epoch grow past 2^32-16 records).
+//
+// "Tagged word": (~seq32) << 32 | data32, combined with atomic max: the word of
+// the record with the SMALLEST sequence number wins, independently per word, so
+// a group of tagged words written by the same records ends up holding the
+// earliest record's data with no lock (all words see the same set of tags).
 struct alignas(128) SlotHot {
     uint64_t tag;        // 0 empty | (fp<<2)|2 claimed, key being written | (fp<<2)|3 ready
     uint64_t key[5];     // flow_id, byte 39 zero
@@ -32,19 +38,17 @@ struct alignas(128) SlotHot {
     uint64_t eth_tag;    // max of (seq+1)<<16 | eth_protocol  over non-zero eth   (:45-47 last non-zero)
     uint64_t dscp_tag;   // max of (seq+1)<<8  | dscp          over non-zero dscp  (:54-56)
     uint64_t samp_tag;   // max of (seq+1)<<32 | sampling      over non-zero sampling (:57-59)
-    uint64_t first_inv;  // max of ~seq: the first record of the flow in this epoch (account.go:95)
-    uint32_t lock;       // guards the cold line
-    uint32_t pad;
+    uint64_t id0;        // tagged: record dword 21 (if_index_first_seen) of the FIRST record (account.go:95);
+                         // its tag is the flow's first sequence number
+    uint64_t smac_lo;    // tagged: low 32 bits of the first non-zero src_mac (:48-50)
+    uint64_t dmac_lo;    // tagged: low 32 bits of the first non-zero dst_mac (:51-53)
 };
 static_assert(sizeof(SlotHot) == 128, "hot line");
 
 struct alignas(128) SlotCold {
-    uint64_t smac_inv;   // max of ~seq over records with non-zero src_mac (:48-50 first non-zero)
-    uint64_t dmac_inv;   // same for dst_mac (:51-53)
-    uint64_t smac;       // low 48 bits
-    uint64_t dmac;
-    uint64_t ident[8];   // record dwords 21..35 (metrics bytes 44..103) of the first record
-    uint64_t pad[4];
+    uint64_t id[14];     // tagged: record dwords 22..35 of the first record
+    uint64_t smac_hi;    // tagged: high 16 bits of the first non-zero src_mac
+    uint64_t dmac_hi;
 };
 static_assert(sizeof(SlotCold) == 128, "cold line");
 

@@ -49,14 +49,15 @@ __global__ __launch_bounds__(256) void k_claim(TableView t, const void* __restri
         if (t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id) { slot_idx[i] = kNoSlot; continue; }
         const uint32_t idx = find_or_claim(t, w, h);
         slot_idx[i] = idx;
-        if (idx != kNoSlot) amax(&t.hot[idx].first_inv, ~(seq_base + i));
+        // plant the first-record tracker (tagged dword 21) so that phase B can find first occurrences
+        if (idx != kNoSlot) amax(&t.hot[idx].id0, tagged(~(uint32_t)(seq_base + i), r.d[21]));
     }
 }
 
 // flags[i] = record i is the first record (in arrival order) of a key that was
 // not in the table before this chunk: exactly the records at which
-// len(c.entries) grows (account.go:95). A slot older than the chunk has a
-// first_inv larger than every ~seq of the chunk, so equality identifies both.
+// len(c.entries) grows (account.go:95). A slot older than the chunk carries a
+// first-record tag larger than every ~seq of the chunk, so equality identifies both.
 __global__ __launch_bounds__(kFlagBlock) void k_first_flags(TableView t, const uint32_t* __restrict__ slot_idx,
                                                             uint64_t n, uint64_t seq_base,
                                                             uint8_t* __restrict__ flags,
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kFlagBlock) void k_first_flags(TableView t, const u
     unsigned f = 0;
     if (i < n) {
         const uint32_t idx = slot_idx[i];
-        if (idx != kNoSlot) f = (t.hot[idx].first_inv == ~(seq_base + i)) ? 1u : 0u;
+        if (idx != kNoSlot) f = ((uint32_t)(t.hot[idx].id0 >> 32) == ~(uint32_t)(seq_base + i)) ? 1u : 0u;
         flags[i] = (uint8_t)f;
     }
     if (f) atomicAdd(&cnt, 1u);
@@ -90,10 +91,10 @@ __global__ __launch_bounds__(256) void k_evict(TableView t, uint64_t n_live, uin
         SlotCold* C = &t.cold[idx];
         const SlotHot hv = *H;
         const SlotCold cv = *C;
-        const uint64_t first_seq = ~hv.first_inv;
+        const uint32_t first_inv = (uint32_t)(hv.id0 >> 32);
         // A slot claimed by the careful path for a key that first appears at or
         // after the split point is not part of this epoch: drop it.
-        const bool emit = hv.first_inv != 0 && first_seq < seq_limit;
+        const bool emit = first_inv != 0 && (uint64_t)(~first_inv) < seq_limit;
         if (emit) {
             uint32_t d[kRecordDwords];
 #pragma unroll
@@ -104,12 +105,14 @@ __global__ __launch_bounds__(256) void k_evict(TableView t, uint64_t n_live, uin
             d[14] = (uint32_t)hv.bytes; d[15] = (uint32_t)(hv.bytes >> 32);
             d[16] = hv.packets;
             d[17] = (uint32_t)(hv.eth_tag & 0xffffu) | ((hv.flags & 0xffffu) << 16);
-            d[18] = (uint32_t)cv.smac;
-            d[19] = (uint32_t)((cv.smac >> 32) & 0xffffu) | (uint32_t)((cv.dmac & 0xffffu) << 16);
-            d[20] = (uint32_t)(cv.dmac >> 16);
+            const uint64_t smac = (uint64_t)(uint32_t)hv.smac_lo | ((uint64_t)(cv.smac_hi & 0xffffu) << 32);
+            const uint64_t dmac = (uint64_t)(uint32_t)hv.dmac_lo | ((uint64_t)(cv.dmac_hi & 0xffffu) << 32);
+            d[18] = (uint32_t)smac;
+            d[19] = (uint32_t)((smac >> 32) & 0xffffu) | (uint32_t)((dmac & 0xffffu) << 16);
+            d[20] = (uint32_t)(dmac >> 16);
+            d[21] = (uint32_t)hv.id0;
 #pragma unroll
-            for (int k = 0; k < 7; k++) { d[21 + 2 * k] = (uint32_t)cv.ident[k]; d[22 + 2 * k] = (uint32_t)(cv.ident[k] >> 32); }
-            d[35] = 0;
+            for (int k = 0; k < 14; k++) d[22 + k] = (uint32_t)cv.id[k];
             d[23] = (uint32_t)hv.samp_tag;                                   // sampling: last non-zero
             d[24] = (d[24] & 0xff00ffffu) | ((uint32_t)(hv.dscp_tag & 0xffu) << 16);  // dscp: last non-zero
             const unsigned long long pos = aadd(&t.ctr->n_out, 1ull);
@@ -144,14 +147,14 @@ hipError_t launch_ingest(const TableView& t, const void* d_records, uint64_t n, 
     if (n == 0) return hipSuccess;
     (void)mode;
     if (variant != 1) return launch_ingest_lds(t, d_records, n, seq_base, variant, s);
-    hipLaunchKernelGGL(k_ingest_direct, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, t, d_records, n, seq_base);
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_ingest_direct, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, t, d_records, n, seq_base);
     return hipGetLastError();
 }
 
 hipError_t launch_claim(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
                         uint32_t* d_slot_idx, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_claim, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, t, d_records, n, seq_base, d_slot_idx);
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_claim, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, t, d_records, n, seq_base, d_slot_idx);
     return hipGetLastError();
 }
 
@@ -159,17 +162,17 @@ hipError_t launch_first_flags(const TableView& t, const uint32_t* d_slot_idx, ui
                               uint8_t* d_flags, uint32_t* d_block_counts, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const int blocks = (int)((n + kFlagBlock - 1) / kFlagBlock);
-    hipLaunchKernelGGL(k_first_flags, dim3(blocks), dim3(kFlagBlock), 0, s, t, d_slot_idx, n, seq_base, d_flags, d_block_counts);
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_first_flags, dim3(blocks), dim3(kFlagBlock), 0, s, t, d_slot_idx, n, seq_base, d_flags, d_block_counts);
     return hipGetLastError();
 }
 
 hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s) {
     if (n_live) {
-        hipLaunchKernelGGL(k_evict, dim3(grid_for(n_live, 256, 256 * 8)), dim3(256), 0, s, t, n_live, seq_limit, d_out);
+        (void)hipGetLastError(); hipLaunchKernelGGL(k_evict, dim3(grid_for(n_live, 256, 256 * 8)), dim3(256), 0, s, t, n_live, seq_limit, d_out);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_reset_after_evict, dim3(1), dim3(1), 0, s, t.ctr);
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_reset_after_evict, dim3(1), dim3(1), 0, s, t.ctr);
     return hipGetLastError();
 }
 

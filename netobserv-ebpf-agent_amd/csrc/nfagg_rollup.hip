@@ -119,7 +119,7 @@ size_t rollup_struct_size(int kind) {
 
 template <typename M>
 static hipError_t run(const void* p, uint64_t nf, uint64_t nc, void* base, void* folded, hipStream_t s) {
-    hipLaunchKernelGGL(k_rollup<M>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s,
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_rollup<M>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s,
                        (const M*)p, nf, nc, (nfagg_flow_metrics*)base, (M*)folded);
     return hipGetLastError();
 }

@@ -61,18 +61,18 @@ hipError_t launch_sketch_update(const SketchView& sk, const TableView& t, const 
     if (n == 0 || sk.flags == 0) return hipSuccess;
     uint64_t g = (n + 255) / 256;
     if (g > 256 * 8) g = 256 * 8;
-    hipLaunchKernelGGL(k_sketch_update, dim3((unsigned)g), dim3(256), 0, s, sk, t, d_records, n);
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_sketch_update, dim3((unsigned)g), dim3(256), 0, s, sk, t, d_records, n);
     return hipGetLastError();
 }
 
 hipError_t launch_hll_histogram(const uint32_t* d_regs, uint32_t p, uint32_t* d_hist65, hipStream_t s) {
-    hipLaunchKernelGGL(k_hll_histogram, dim3(1), dim3(256), 0, s, d_regs, p, d_hist65);
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_hll_histogram, dim3(1), dim3(256), 0, s, d_regs, p, d_hist65);
     return hipGetLastError();
 }
 
 hipError_t launch_hll_pack(const uint32_t* d_regs, uint32_t p, uint8_t* d_out, hipStream_t s) {
     const uint32_t m = 1u << p;
-    hipLaunchKernelGGL(k_hll_pack, dim3((m + 255) / 256), dim3(256), 0, s, d_regs, m, d_out);
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_hll_pack, dim3((m + 255) / 256), dim3(256), 0, s, d_regs, m, d_out);
     return hipGetLastError();
 }
 

@@ -146,7 +146,7 @@ int nfagg_synth_stream(void* d_out, uint64_t n, uint64_t j0, uint64_t seed, uint
     if (n == 0) return 0;
     uint64_t g = (n + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
-    hipLaunchKernelGGL(k_synth, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (uint4*)d_out, n, j0, seed, n_keys,
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_synth, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (uint4*)d_out, n, j0, seed, n_keys,
                        d_thresholds, hot_permille, variant, d_pop_index);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
