@@ -170,6 +170,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "alg_bytes_per_record": ALG_BYTES_INGEST, "records_per_launch": int(recs_per_launch),
                 "launch_ms": round(ingest_ms, 4), "launches": int(st.ingest_launches),
+                "lds_cache_hit_rate": round(1.0 - st.records_bypassed / max(1, n * (args.steps + args.warmup)), 4),
                 "kernel_Mrecords_per_s": round(recs_per_launch / (ingest_ms * 1e-3) / 1e6, 1) if ingest_ms > 0 else None,
                 "evict_launch_ms": round(st.evict_kernel_ms / max(st.evict_launches, 1), 4),
                 "sketch_launch_ms": round(st.sketch_kernel_ms / max(st.sketch_launches, 1), 4) if st.sketch_launches else None,

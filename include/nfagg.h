@@ -257,7 +257,8 @@ typedef struct nfagg_stats {
     double   evict_kernel_ms;
     uint64_t sketch_launches;
     double   sketch_kernel_ms;
-    uint64_t max_probe;          /* longest probe sequence seen at eviction scans (0 if untracked) */
+    uint64_t max_probe;          /* longest probe sequence seen */
+    uint64_t records_bypassed;   /* records merged into HBM one by one (no LDS cache entry for their flow) */
 } nfagg_stats;
 
 uint32_t nfagg_abi_version(void);

@@ -50,6 +50,7 @@ class Stats(C.Structure):
         ("ingest_launches", C.c_uint64), ("ingest_kernel_ms", C.c_double),
         ("evict_launches", C.c_uint64), ("evict_kernel_ms", C.c_double),
         ("sketch_launches", C.c_uint64), ("sketch_kernel_ms", C.c_double), ("max_probe", C.c_uint64),
+        ("records_bypassed", C.c_uint64),
     ]
 
 

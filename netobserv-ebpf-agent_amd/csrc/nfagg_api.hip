@@ -144,6 +144,7 @@ int refresh_counters(nfagg_handle* h) {
     h->live_ub = h->h_ctr->n_live;
     if (!h->must_evict) h->live = h->h_ctr->n_live;
     h->stats.records_skipped = h->h_ctr->n_skipped;
+    h->stats.records_bypassed = h->h_ctr->n_bypassed;
     if (h->h_ctr->max_probe > h->stats.max_probe) h->stats.max_probe = h->h_ctr->max_probe;
     return NFAGG_OK;
 }

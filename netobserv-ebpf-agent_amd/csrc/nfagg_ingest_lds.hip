@@ -1,5 +1,6 @@
-// nfagg_ingest_lds.hip — the default ingest kernel: LDS tile fold, then one
-// global merge per distinct key of the tile.
+// nfagg_ingest_lds.hip — ingest variant 2: LDS fold per tile, then one global
+// merge per distinct key of the tile (kept for A/B; the default is the persistent
+// LDS flow cache of nfagg_ingest_cached.hip).
 //
 // Why: a Zipf(1.1) stream sends ~12 % of all records to one key and the
 // adversarial config 90 %. Merging every record straight into HBM serialises

@@ -57,7 +57,7 @@ struct DevCounters {
     unsigned long long n_live;     // claimed slots this epoch (== len(c.entries) unless a split is pending)
     unsigned long long n_out;      // records written by the evict kernel
     unsigned long long n_skipped;  // records of other shards
-    unsigned long long n_accepted;
+    unsigned long long n_bypassed; // records merged one by one (no LDS cache entry for their flow)
     unsigned int error;            // non-zero: a kernel bailed out (probe overflow)
     unsigned int max_probe;
     unsigned long long pad[2];

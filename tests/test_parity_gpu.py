@@ -115,7 +115,7 @@ def test_evict_period(nf):
 
 # ---------------------------------------------------------------- seeded streams vs the oracle
 @pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("ingest_variant", [0, 1])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("batch", [1 << 30, 1000, 257])
 def test_stream_parity(nf, O, variant, ingest_variant, batch):
     th = O.zipf_thresholds(3000, 1.1)
@@ -136,7 +136,7 @@ def test_config1_10k_records_1k_keys(nf, O):
     assert len(want[0][1]) == len(np.unique(recs["id"]["src_port"]))
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 1])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3, 4, 5])
 def test_hot_key_stream(nf, O, ingest_variant):
     """BASELINE configs[4] shape: 90 % of the records are one flow (LDS / atomic contention)."""
     th = O.zipf_thresholds(5000, 1.1)
@@ -144,21 +144,23 @@ def test_hot_key_stream(nf, O, ingest_variant):
     check_against_oracle(nf, O, recs, 1 << 16, 1 << 30, ingest_variant=ingest_variant)
 
 
-def test_wraparound_and_zero_fields(nf, O):
+@pytest.mark.parametrize("ingest_variant", [0, 1, 2])
+def test_wraparound_and_zero_fields(nf, O, ingest_variant):
     """u64 bytes / u32 packets wrap (flow_content.go:42-43) and all-zero optional fields."""
     recs = O.gen_stream(3000, seed=9, n_keys=3, variant=1)   # ~1000 records per key, wrap values injected
-    check_against_oracle(nf, O, recs, 100, 1 << 30)
+    check_against_oracle(nf, O, recs, 100, 1 << 30, ingest_variant=ingest_variant)
     z = np.zeros(10, dtype=O.FLOW_RECORD)                     # ten all-zero records: one flow, everything zero
-    check_against_oracle(nf, O, z, 100, 1 << 30)
+    check_against_oracle(nf, O, z, 100, 1 << 30, ingest_variant=ingest_variant)
 
 
+@pytest.mark.parametrize("ingest_variant", [0, 2])
 @pytest.mark.parametrize("max_entries,batch", [(2, 1 << 30), (100, 1 << 30), (100, 333), (1, 50), (999, 4096), (3000, 1 << 30)])
-def test_evict_on_full_inside_batches(nf, O, max_entries, batch):
+def test_evict_on_full_inside_batches(nf, O, max_entries, batch, ingest_variant):
     """account.go:85-94: the arrival of the (maxEntries+1)-th distinct key flushes what was
     accumulated so far — the split point must be found inside a parallel batch."""
     th = O.zipf_thresholds(1000, 1.1)
     recs = O.gen_stream(20000, seed=77, n_keys=1000, thresholds=th, variant=1)
-    want = check_against_oracle(nf, O, recs, max_entries, batch)
+    want = check_against_oracle(nf, O, recs, max_entries, batch, ingest_variant=ingest_variant)
     if max_entries < 500:
         assert sum(1 for r, _ in want if r == "full") >= 2
         assert all(len(b) == max_entries for r, b in want if r == "full")
@@ -173,9 +175,10 @@ def test_empty_and_ragged_inputs(nf, O):
         assert list(s.evictions) == [0, 0, 0]                 # an empty table does not count a timeout eviction (:64-66)
         assert len(tab.evict(nf.REASON_CLOSING)) == 0
         assert list(tab.stats().evictions) == [0, 0, 1]       # closing does (:78)
-    for n in (1, 63, 64, 65, 255, 256, 257, 1023):            # ragged tile tails
+    for n in (1, 63, 64, 65, 255, 256, 257, 1023, 1025, 2049):            # ragged tile tails
         recs = O.gen_stream(n, seed=n, n_keys=50, variant=1)
-        check_against_oracle(nf, O, recs, 1000, 1 << 30)
+        for v in (0, 2, 3):
+            check_against_oracle(nf, O, recs, 1000, 1 << 30, ingest_variant=v)
 
 
 def test_epochs_are_independent(nf, O):
@@ -223,15 +226,16 @@ def test_small_staging_ring_many_chunks(nf, O):
     check_against_oracle(nf, O, recs, 4096, 1 << 30, staging_records=1000)
 
 
+@pytest.mark.parametrize("ingest_variant", [0, 2])
 @pytest.mark.parametrize("n_shards", [2, 8])
-def test_sharded_tables_cover_the_stream(nf, O, n_shards):
+def test_sharded_tables_cover_the_stream(nf, O, n_shards, ingest_variant):
     """Records shard by flow-key hash; every shard folds only its own keys; the
     concatenation of the shards' evictions equals the unsharded result."""
     th = O.zipf_thresholds(2000, 1.1)
     recs = O.gen_stream(30000, seed=8, n_keys=2000, thresholds=th, variant=1)
     parts, skipped = [], 0
     for s in range(n_shards):
-        with nf.FlowTable(max_entries=4096, n_shards=n_shards, shard_id=s) as tab:
+        with nf.FlowTable(max_entries=4096, n_shards=n_shards, shard_id=s, ingest_variant=ingest_variant) as tab:
             assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
             ev = tab.evict()
             assert all(nf.shard_of(r["id"].tobytes(), n_shards) == s for r in ev[:50])
