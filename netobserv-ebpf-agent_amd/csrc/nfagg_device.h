@@ -103,6 +103,24 @@ NF_DEV uint64_t tag_locked(uint64_t h) { return ((h >> 2) << 2) | 2ull; }
 NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t h) {
     const uint64_t ready = tag_ready(h), locked = tag_locked(h);
     uint64_t idx = h & t.mask;
+    // Optimistic first probe with plain (cacheable) 16-byte loads: three requests
+    // instead of six coherent 8-byte ones. Safe because (a) a `ready` tag is only
+    // ever published after the key's write-through stores have been acknowledged,
+    // (b) a cache returns one line's words no older than a word it returned before,
+    // so key words read after a `ready` tag from the same 128-byte line belong to
+    // it, and (c) anything else seen here (empty, being claimed, another flow) may
+    // be stale and is re-examined coherently by the loop below.
+    {
+        const uint4* L = reinterpret_cast<const uint4*>(&t.hot[idx]);
+        const uint4 a = L[0];
+        if (((uint64_t)a.x | ((uint64_t)a.y << 32)) == ready) {
+            const uint4 b = L[1], c = L[2];
+            const bool eq = (((uint64_t)a.z | ((uint64_t)a.w << 32)) == w[0]) &
+                            (((uint64_t)b.x | ((uint64_t)b.y << 32)) == w[1]) & (((uint64_t)b.z | ((uint64_t)b.w << 32)) == w[2]) &
+                            (((uint64_t)c.x | ((uint64_t)c.y << 32)) == w[3]) & (((uint64_t)c.z | ((uint64_t)c.w << 32)) == w[4]);
+            if (eq) return (uint32_t)idx;
+        }
+    }
     uint64_t probes = 0;
     uint32_t result = kNoSlot;
     uint32_t done = 0;
@@ -170,36 +188,57 @@ NF_DEV void partial_from_record(const Rec& r, uint64_t seq, Partial& p) {
     for (int k = 0; k < 15; k++) p.ident[k] = r.d[21 + k];
 }
 
+// Possibly stale copies of the slot's monotone words, read with plain 16-byte
+// loads. Every one of these words only ever grows (max / OR) within an epoch and
+// starts at zero, so a stale value is a LOWER bound: using it to skip an atomic
+// that could not change the word is safe, a stale value merely skips less.
+struct Hints {
+    uint64_t end, start_inv, id0, smac_lo, dmac_lo;
+    uint32_t flags;
+};
+
+NF_DEV void load_hints(const SlotHot* H, Hints& x) {
+    const uint4* L = reinterpret_cast<const uint4*>(H);
+    const uint4 l3 = L[3], l4 = L[4], l6 = L[6], l7 = L[7];
+    x.end = (uint64_t)l3.z | ((uint64_t)l3.w << 32);
+    x.start_inv = (uint64_t)l4.x | ((uint64_t)l4.y << 32);
+    x.flags = l4.w;
+    x.id0 = (uint64_t)l6.z | ((uint64_t)l6.w << 32);
+    x.smac_lo = (uint64_t)l7.x | ((uint64_t)l7.y << 32);
+    x.dmac_lo = (uint64_t)l7.z | ((uint64_t)l7.w << 32);
+}
+
 // model.AccumulateBase(stored, &record.Metrics) (flow_content.go:28-61) for a
 // partial, plus "first record stored whole" (account.go:95): commutative
-// atomics and tagged-word maxima only.
+// atomics and tagged-word maxima only; atomics that the hints prove to be
+// no-ops are skipped.
 NF_DEV void merge_partial(const TableView& t, uint32_t idx, const Partial& p) {
     SlotHot* H = &t.hot[idx];
     SlotCold* C = &t.cold[idx];
+    Hints x;
+    load_hints(H, x);
     if (p.bytes) aadd(&H->bytes, p.bytes);
     if (p.packets) aadd(&H->packets, p.packets);
-    if (p.flags) aor(&H->flags, p.flags);
-    if (p.end) amax(&H->end, p.end);
-    if (p.start_inv) amax(&H->start_inv, p.start_inv);
+    if (p.flags & ~x.flags) aor(&H->flags, p.flags);
+    if (p.end > x.end) amax(&H->end, p.end);
+    if (p.start_inv > x.start_inv) amax(&H->start_inv, p.start_inv);
     if (p.eth_tag) amax(&H->eth_tag, p.eth_tag);
     if (p.dscp_tag) amax(&H->dscp_tag, p.dscp_tag);
     if (p.samp_tag) amax(&H->samp_tag, p.samp_tag);
-    // First-record identity. The value read is only a hint: tagged words grow
-    // monotonically, so an older (smaller) value can at worst cost extra
-    // atomics, never lose the earliest record.
+    // First-record identity: "<=" because the careful path plants id0 in its claim phase.
     const uint64_t my0 = tagged(p.first_inv, p.ident[0]);
-    if (ald(&H->id0) <= my0) {   // "<=": the careful path plants id0 in its claim phase
+    if (x.id0 <= my0) {
         amax(&H->id0, my0);
 #pragma unroll
         for (int k = 1; k < 15; k++) amax(&C->id[k - 1], tagged(p.first_inv, p.ident[k]));
     }
     if (p.smac_inv) {
         const uint64_t lo = tagged(p.smac_inv, (uint32_t)p.smac);
-        if (ald(&H->smac_lo) <= lo) { amax(&H->smac_lo, lo); amax(&C->smac_hi, tagged(p.smac_inv, (uint32_t)(p.smac >> 32))); }
+        if (x.smac_lo <= lo) { amax(&H->smac_lo, lo); amax(&C->smac_hi, tagged(p.smac_inv, (uint32_t)(p.smac >> 32))); }
     }
     if (p.dmac_inv) {
         const uint64_t lo = tagged(p.dmac_inv, (uint32_t)p.dmac);
-        if (ald(&H->dmac_lo) <= lo) { amax(&H->dmac_lo, lo); amax(&C->dmac_hi, tagged(p.dmac_inv, (uint32_t)(p.dmac >> 32))); }
+        if (x.dmac_lo <= lo) { amax(&H->dmac_lo, lo); amax(&C->dmac_hi, tagged(p.dmac_inv, (uint32_t)(p.dmac >> 32))); }
     }
 }
 

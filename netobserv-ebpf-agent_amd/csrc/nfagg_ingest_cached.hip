@@ -174,11 +174,13 @@ __global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, const void
         const uint32_t idx = L.gslot[e];
         if (idx == kNoSlot) continue;   // cannot happen: the entry's first record set it
         SlotHot* H = &t.hot[idx];
+        Hints x;
+        load_hints(H, x);
         if (L.bytes[e]) aadd(&H->bytes, L.bytes[e]);
         if (L.packets[e]) aadd(&H->packets, L.packets[e]);
-        if (L.flags[e]) aor(&H->flags, L.flags[e]);
-        if (L.end[e]) amax(&H->end, L.end[e]);
-        if (L.start_inv[e]) amax(&H->start_inv, L.start_inv[e]);
+        if (L.flags[e] & ~x.flags) aor(&H->flags, L.flags[e]);
+        if (L.end[e] > x.end) amax(&H->end, L.end[e]);
+        if (L.start_inv[e] > x.start_inv) amax(&H->start_inv, L.start_inv[e]);
         if (L.eth_tag[e]) amax(&H->eth_tag, L.eth_tag[e]);
         if (L.dscp_tag[e]) amax(&H->dscp_tag, L.dscp_tag[e]);
         if (L.samp_tag[e]) amax(&H->samp_tag, L.samp_tag[e]);
