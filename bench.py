@@ -107,10 +107,7 @@ def main():
             off += m
         if args.sketches and world > 1:
             tab.sync()          # the sketch kernels run on the table's stream
-            for t in cm_t:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            for t in hll_t:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            nf.distributed.merge_sketches(cm_t, hll_t)
         flows = tab.evict_device(d_out.data_ptr(), keys, nf.REASON_TIMEOUT)
         if args.sketches:
             tab.sketch_reset()

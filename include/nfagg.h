@@ -388,6 +388,9 @@ double nfagg_hll_estimate_from_histogram(const uint32_t* hist, uint32_t p);
 /* Shard of a flow key: the function that routes records to GPUs
  * (hash of the 40 key bytes with byte 39 forced to 0). */
 uint32_t nfagg_shard_of(const nfagg_flow_id* id, uint32_t n_shards);
+/* Host-side router: shard id of each of n 144-byte records (HOST memory), for a
+ * caller that feeds one handle per GPU. Pure CPU; no device needed. */
+void nfagg_shard_ids(const void* records, size_t n, uint32_t n_shards, uint32_t* out_shard);
 /* The 64-bit key hash itself (table index / fingerprint / shard all derive from it). */
 uint64_t nfagg_key_hash(const nfagg_flow_id* id);
 /* The 64-bit hash of a 16-byte IP with the given seed index (0..3), as used by

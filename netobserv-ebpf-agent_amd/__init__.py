@@ -15,3 +15,4 @@ from .table import (FlowTable, NfaggError, key_hash, shard_of, ip_hash, hll_esti
 from .accounter import (Accounter, NewAccounter, NewRecord, Record, IntfDirUdn, NewIntfDirUdn, Metrics, NoOp, CLOSE,
                         SetInterfaceNamer, SetGlobalIP)
 from . import synth
+from . import distributed

@@ -83,6 +83,7 @@ SIGNATURES = {
     "nfagg_cm_query": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(C.c_uint64)]),
     "nfagg_hll_estimate_from_histogram": (C.c_double, [_vp, C.c_uint32]),
     "nfagg_shard_of": (C.c_uint32, [_vp, C.c_uint32]),
+    "nfagg_shard_ids": (None, [_vp, _sz, C.c_uint32, _vp]),
     "nfagg_key_hash": (C.c_uint64, [_vp]),
     "nfagg_ip_hash": (C.c_uint64, [_vp, C.c_uint32]),
     "nfagg_stats_get": (C.c_int, [_vp, C.POINTER(Stats)]),

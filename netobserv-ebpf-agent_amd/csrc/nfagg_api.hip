@@ -657,6 +657,12 @@ uint64_t nfagg_key_hash(const nfagg_flow_id* id) {
     return key_hash(w);
 }
 
+void nfagg_shard_ids(const void* records, size_t n, uint32_t n_shards, uint32_t* out_shard) {
+    const char* p = static_cast<const char*>(records);
+    for (size_t i = 0; i < n; i++)
+        out_shard[i] = nfagg_shard_of(reinterpret_cast<const nfagg_flow_id*>(p + i * kRecordBytes), n_shards);
+}
+
 uint32_t nfagg_shard_of(const nfagg_flow_id* id, uint32_t n_shards) { return shard_of_hash(nfagg_key_hash(id), n_shards); }
 
 uint64_t nfagg_ip_hash(const uint8_t ip[16], uint32_t seed_index) {
