@@ -93,8 +93,57 @@ NF_DEV void load_record(const void* base, uint64_t i, Rec& r) {
 NF_DEV uint64_t tag_ready(uint64_t h) { return ((h >> 2) << 2) | 3ull; }
 NF_DEV uint64_t tag_locked(uint64_t h) { return ((h >> 2) << 2) | 2ull; }
 
+// Possibly stale copies of the slot's monotone words, read with plain 16-byte
+// loads. Every one of these words only ever grows (max / OR) within an epoch and
+// starts at zero, so a stale value is a LOWER bound: using it to skip an atomic
+// that could not change the word is safe, a stale value merely skips less.
+struct Hints {
+    uint64_t end, start_inv, id0, smac_lo, dmac_lo;
+    uint32_t flags;
+};
+
+NF_DEV void load_hints(const SlotHot* H, Hints& x) {
+    const uint4* L = reinterpret_cast<const uint4*>(H);
+    const uint4 l3 = L[3], l4 = L[4], l6 = L[6], l7 = L[7];
+    x.end = (uint64_t)l3.z | ((uint64_t)l3.w << 32);
+    x.start_inv = (uint64_t)l4.x | ((uint64_t)l4.y << 32);
+    x.flags = l4.w;
+    x.id0 = (uint64_t)l6.z | ((uint64_t)l6.w << 32);
+    x.smac_lo = (uint64_t)l7.x | ((uint64_t)l7.y << 32);
+    x.dmac_lo = (uint64_t)l7.z | ((uint64_t)l7.w << 32);
+}
+
+// One-round-trip fast path: issue the three key loads and the four hint loads of
+// the flow's home slot together (plain, cacheable 16-byte loads) and decide
+// afterwards. Returns the slot when the home slot is `ready` and holds this key
+// (then `x` holds its hints); kNoSlot means "not decided" — the caller runs the
+// coherent find_or_claim loop. Safety of the plain loads: see find_or_claim.
+NF_DEV uint32_t probe_home(const TableView& t, const uint64_t w[5], uint64_t h, Hints& x) {
+    const uint64_t idx = h & t.mask;
+    const uint4* L = reinterpret_cast<const uint4*>(&t.hot[idx]);
+    const uint4 a = L[0], b = L[1], c = L[2], l3 = L[3], l4 = L[4], l6 = L[6], l7 = L[7];
+    const bool eq = (((uint64_t)a.x | ((uint64_t)a.y << 32)) == tag_ready(h)) &
+                    (((uint64_t)a.z | ((uint64_t)a.w << 32)) == w[0]) &
+                    (((uint64_t)b.x | ((uint64_t)b.y << 32)) == w[1]) & (((uint64_t)b.z | ((uint64_t)b.w << 32)) == w[2]) &
+                    (((uint64_t)c.x | ((uint64_t)c.y << 32)) == w[3]) & (((uint64_t)c.z | ((uint64_t)c.w << 32)) == w[4]);
+    x.end = (uint64_t)l3.z | ((uint64_t)l3.w << 32);
+    x.start_inv = (uint64_t)l4.x | ((uint64_t)l4.y << 32);
+    x.flags = l4.w;
+    x.id0 = (uint64_t)l6.z | ((uint64_t)l6.w << 32);
+    x.smac_lo = (uint64_t)l7.x | ((uint64_t)l7.y << 32);
+    x.dmac_lo = (uint64_t)l7.z | ((uint64_t)l7.w << 32);
+    return eq ? (uint32_t)idx : kNoSlot;
+}
+
 // c.entries[record.Id] lookup, inserting the key when absent
-// (pkg/flow/account.go:82,95). Returns the slot index, kNoSlot on failure
+// (pkg/flow/account.go:82,95): the coherent path. Callers try probe_home first.
+// Why probe_home's plain loads are safe: (a) a `ready` tag is only ever published
+// after the key's write-through stores have been acknowledged, (b) a cache
+// returns one line's words no older than a word it returned before, so key words
+// read together with a `ready` tag from the same 128-byte line belong to it, and
+// (c) anything else it may see (empty, being claimed, another flow) may be stale
+// and is re-examined here with agent-scope atomics.
+// Returns the slot index, kNoSlot on failure
 // (error code left in the counters). Every lane advances at most one state per
 // loop trip and never waits inside a trip; the claimer publishes its key in the
 // trip in which its CAS succeeded. The empty asm keeps `done` opaque so the
@@ -103,24 +152,6 @@ NF_DEV uint64_t tag_locked(uint64_t h) { return ((h >> 2) << 2) | 2ull; }
 NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t h) {
     const uint64_t ready = tag_ready(h), locked = tag_locked(h);
     uint64_t idx = h & t.mask;
-    // Optimistic first probe with plain (cacheable) 16-byte loads: three requests
-    // instead of six coherent 8-byte ones. Safe because (a) a `ready` tag is only
-    // ever published after the key's write-through stores have been acknowledged,
-    // (b) a cache returns one line's words no older than a word it returned before,
-    // so key words read after a `ready` tag from the same 128-byte line belong to
-    // it, and (c) anything else seen here (empty, being claimed, another flow) may
-    // be stale and is re-examined coherently by the loop below.
-    {
-        const uint4* L = reinterpret_cast<const uint4*>(&t.hot[idx]);
-        const uint4 a = L[0];
-        if (((uint64_t)a.x | ((uint64_t)a.y << 32)) == ready) {
-            const uint4 b = L[1], c = L[2];
-            const bool eq = (((uint64_t)a.z | ((uint64_t)a.w << 32)) == w[0]) &
-                            (((uint64_t)b.x | ((uint64_t)b.y << 32)) == w[1]) & (((uint64_t)b.z | ((uint64_t)b.w << 32)) == w[2]) &
-                            (((uint64_t)c.x | ((uint64_t)c.y << 32)) == w[3]) & (((uint64_t)c.z | ((uint64_t)c.w << 32)) == w[4]);
-            if (eq) return (uint32_t)idx;
-        }
-    }
     uint64_t probes = 0;
     uint32_t result = kNoSlot;
     uint32_t done = 0;
@@ -188,35 +219,13 @@ NF_DEV void partial_from_record(const Rec& r, uint64_t seq, Partial& p) {
     for (int k = 0; k < 15; k++) p.ident[k] = r.d[21 + k];
 }
 
-// Possibly stale copies of the slot's monotone words, read with plain 16-byte
-// loads. Every one of these words only ever grows (max / OR) within an epoch and
-// starts at zero, so a stale value is a LOWER bound: using it to skip an atomic
-// that could not change the word is safe, a stale value merely skips less.
-struct Hints {
-    uint64_t end, start_inv, id0, smac_lo, dmac_lo;
-    uint32_t flags;
-};
-
-NF_DEV void load_hints(const SlotHot* H, Hints& x) {
-    const uint4* L = reinterpret_cast<const uint4*>(H);
-    const uint4 l3 = L[3], l4 = L[4], l6 = L[6], l7 = L[7];
-    x.end = (uint64_t)l3.z | ((uint64_t)l3.w << 32);
-    x.start_inv = (uint64_t)l4.x | ((uint64_t)l4.y << 32);
-    x.flags = l4.w;
-    x.id0 = (uint64_t)l6.z | ((uint64_t)l6.w << 32);
-    x.smac_lo = (uint64_t)l7.x | ((uint64_t)l7.y << 32);
-    x.dmac_lo = (uint64_t)l7.z | ((uint64_t)l7.w << 32);
-}
-
 // model.AccumulateBase(stored, &record.Metrics) (flow_content.go:28-61) for a
 // partial, plus "first record stored whole" (account.go:95): commutative
 // atomics and tagged-word maxima only; atomics that the hints prove to be
 // no-ops are skipped.
-NF_DEV void merge_partial(const TableView& t, uint32_t idx, const Partial& p) {
+NF_DEV void merge_partial(const TableView& t, uint32_t idx, const Partial& p, const Hints& x) {
     SlotHot* H = &t.hot[idx];
     SlotCold* C = &t.cold[idx];
-    Hints x;
-    load_hints(H, x);
     if (p.bytes) aadd(&H->bytes, p.bytes);
     if (p.packets) aadd(&H->packets, p.packets);
     if (p.flags & ~x.flags) aor(&H->flags, p.flags);
@@ -240,6 +249,18 @@ NF_DEV void merge_partial(const TableView& t, uint32_t idx, const Partial& p) {
         const uint64_t lo = tagged(p.dmac_inv, (uint32_t)p.dmac);
         if (x.dmac_lo <= lo) { amax(&H->dmac_lo, lo); amax(&C->dmac_hi, tagged(p.dmac_inv, (uint32_t)(p.dmac >> 32))); }
     }
+}
+
+// lookup-or-insert + merge of one partial: home-slot fast path, coherent loop otherwise
+NF_DEV void upsert_partial(const TableView& t, const uint64_t w[5], uint64_t h, const Partial& p) {
+    Hints x;
+    uint32_t idx = probe_home(t, w, h, x);
+    if (idx == kNoSlot) {
+        idx = find_or_claim(t, w, h);
+        if (idx == kNoSlot) return;
+        load_hints(&t.hot[idx], x);
+    }
+    merge_partial(t, idx, p, x);
 }
 
 }  // namespace nfagg

@@ -44,23 +44,23 @@ constexpr int kCacheProbe = 8;   // probe window: a flow that finds no entry wit
 
 // Merge only the identity words / MAC words (used by the records that are the
 // workgroup's earliest for their flow).
-NF_DEV void merge_ident(const TableView& t, uint32_t idx, uint32_t inv, const Rec& r) {
+NF_DEV void merge_ident(const TableView& t, uint32_t idx, uint32_t inv, const Rec& r, const Hints& x) {
     SlotHot* H = &t.hot[idx];
     SlotCold* C = &t.cold[idx];
     const uint64_t my0 = tagged(inv, r.d[21]);
-    if (ald(&H->id0) <= my0) {
+    if (x.id0 <= my0) {
         amax(&H->id0, my0);
 #pragma unroll
         for (int k = 1; k < 15; k++) amax(&C->id[k - 1], tagged(inv, r.d[21 + k]));
     }
 }
-NF_DEV void merge_smac(const TableView& t, uint32_t idx, uint32_t inv, uint64_t mac) {
+NF_DEV void merge_smac(const TableView& t, uint32_t idx, uint32_t inv, uint64_t mac, const Hints& x) {
     const uint64_t lo = tagged(inv, (uint32_t)mac);
-    if (ald(&t.hot[idx].smac_lo) <= lo) { amax(&t.hot[idx].smac_lo, lo); amax(&t.cold[idx].smac_hi, tagged(inv, (uint32_t)(mac >> 32))); }
+    if (x.smac_lo <= lo) { amax(&t.hot[idx].smac_lo, lo); amax(&t.cold[idx].smac_hi, tagged(inv, (uint32_t)(mac >> 32))); }
 }
-NF_DEV void merge_dmac(const TableView& t, uint32_t idx, uint32_t inv, uint64_t mac) {
+NF_DEV void merge_dmac(const TableView& t, uint32_t idx, uint32_t inv, uint64_t mac, const Hints& x) {
     const uint64_t lo = tagged(inv, (uint32_t)mac);
-    if (ald(&t.hot[idx].dmac_lo) <= lo) { amax(&t.hot[idx].dmac_lo, lo); amax(&t.cold[idx].dmac_hi, tagged(inv, (uint32_t)(mac >> 32))); }
+    if (x.dmac_lo <= lo) { amax(&t.hot[idx].dmac_lo, lo); amax(&t.cold[idx].dmac_hi, tagged(inv, (uint32_t)(mac >> 32))); }
 }
 
 template <int BLOCK, int K>
@@ -143,23 +143,25 @@ __global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, const void
             if (ent < 0) {
                 // bypass: this flow has no cache entry, merge the record itself
                 bypassed++;
-                const uint32_t idx = find_or_claim(t, w, h);
-                if (idx != kNoSlot) {
-                    Partial p;
-                    partial_from_record(r, seq_base + i, p);
-                    merge_partial(t, idx, p);
-                }
+                Partial p;
+                partial_from_record(r, seq_base + i, p);
+                upsert_partial(t, w, h, p);
             } else {
                 const bool is_first = L.first_seq[ent] == seq32;
                 const bool is_smac = r.smac() && L.smac_seq[ent] == seq32;
                 const bool is_dmac = r.dmac() && L.dmac_seq[ent] == seq32;
                 if (is_first || is_smac || is_dmac) {
                     // the workgroup's earliest record of this flow (or earliest with a MAC): publish its own words
-                    const uint32_t idx = find_or_claim(t, w, h);
+                    Hints x;
+                    uint32_t idx = probe_home(t, w, h, x);
+                    if (idx == kNoSlot) {
+                        idx = find_or_claim(t, w, h);
+                        if (idx != kNoSlot) load_hints(&t.hot[idx], x);
+                    }
                     if (idx != kNoSlot) {
-                        if (is_first) { L.gslot[ent] = idx; merge_ident(t, idx, ~seq32, r); }
-                        if (is_smac) merge_smac(t, idx, ~seq32, r.smac());
-                        if (is_dmac) merge_dmac(t, idx, ~seq32, r.dmac());
+                        if (is_first) { L.gslot[ent] = idx; merge_ident(t, idx, ~seq32, r, x); }
+                        if (is_smac) merge_smac(t, idx, ~seq32, r.smac(), x);
+                        if (is_dmac) merge_dmac(t, idx, ~seq32, r.dmac(), x);
                     }
                 }
             }

@@ -124,8 +124,7 @@ __global__ __launch_bounds__(T) void k_ingest_lds(TableView t, const void* __res
             p.dmac_inv = (dm != ~0ull) ? ~(uint32_t)(tile_seq + (dm >> 48)) : 0u;
 #pragma unroll
             for (int k = 0; k < 15; k++) p.ident[k] = r.d[21 + k];
-            const uint32_t idx = find_or_claim(t, w, h);
-            if (idx != kNoSlot) merge_partial(t, idx, p);
+            upsert_partial(t, w, h, p);
         }
         __syncthreads();
     }

@@ -23,11 +23,9 @@ __global__ __launch_bounds__(256) void k_ingest_direct(TableView t, const void* 
         r.key_words(w);
         const uint64_t h = key_hash(w);
         if (t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id) { skipped++; continue; }
-        const uint32_t idx = find_or_claim(t, w, h);
-        if (idx == kNoSlot) continue;
         Partial p;
         partial_from_record(r, seq_base + i, p);
-        merge_partial(t, idx, p);
+        upsert_partial(t, w, h, p);
     }
     if (skipped) aadd(&t.ctr->n_skipped, skipped);
 }
