@@ -84,7 +84,9 @@ def main():
                         hot_permille=args.hot_permille, d_pop_index=d_pop.data_ptr() if d_pop is not None else 0)
     torch.cuda.synchronize()
 
-    max_entries = args.max_entries or max(1 << 22, 4 * keys)
+    # CACHE_MAX_FLOWS. A batch is folded by ONE launch when live + batch <= max_entries (no record of it can
+    # trigger the evict-on-full of account.go:85), so a GPU deployment sets it generously: 2^27 flows = a 64 GiB table.
+    max_entries = args.max_entries or (1 << 27)
     sk_flags = (nf.SKETCH_CM | nf.SKETCH_HLL) if args.sketches else 0
     ext = None
     cm_t = hll_t = None

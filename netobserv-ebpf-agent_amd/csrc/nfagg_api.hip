@@ -123,10 +123,10 @@ int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t 
     EventPair ep{};
     const bool prof = h->cfg.profile != 0;
     if (prof) { if (h->ev_pending.size() >= 8192) prof_resolve(h); prof_begin(h, ep, 0); }
-    hipError_t e = launch_ingest(h->tv, d, n, seq_base, (int)h->cfg.mode, (int)h->cfg.ingest_variant, h->stream);
+    hipError_t e = launch_ingest(h->tv, h->sk, d, n, seq_base, (int)h->cfg.mode, (int)h->cfg.ingest_variant, h->stream);
     if (prof) prof_end(h, ep);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "ingest launch failed: %s", hipGetErrorString(e));
-    if (h->sk.flags) {
+    if (h->sk.flags && !ingest_fuses_sketches((int)h->cfg.ingest_variant)) {
         if (prof) prof_begin(h, ep, 2);
         e = launch_sketch_update(h->sk, h->tv, d, n, h->stream);
         if (prof) prof_end(h, ep);

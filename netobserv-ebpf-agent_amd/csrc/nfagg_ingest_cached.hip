@@ -63,8 +63,8 @@ NF_DEV void merge_dmac(const TableView& t, uint32_t idx, uint32_t inv, uint64_t 
     if (x.dmac_lo <= lo) { amax(&t.hot[idx].dmac_lo, lo); amax(&t.cold[idx].dmac_hi, tagged(inv, (uint32_t)(mac >> 32))); }
 }
 
-template <int BLOCK, int K>
-__global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, const void* __restrict__ recs, uint64_t n,
+template <int BLOCK, int K, bool SKETCH>
+__global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, SketchView sk, const void* __restrict__ recs, uint64_t n,
                                                          uint64_t seq_base) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     FlowCache<K>& L = *reinterpret_cast<FlowCache<K>*>(lds_raw);
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, const void
                 Partial p;
                 partial_from_record(r, seq_base + i, p);
                 upsert_partial(t, w, h, p);
+                if (SKETCH) sketch_add(sk, w, r.bytes());
             } else {
                 const bool is_first = L.first_seq[ent] == seq32;
                 const bool is_smac = r.smac() && L.smac_seq[ent] == seq32;
@@ -186,18 +187,24 @@ __global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, const void
         if (L.eth_tag[e]) amax(&H->eth_tag, L.eth_tag[e]);
         if (L.dscp_tag[e]) amax(&H->dscp_tag, L.dscp_tag[e]);
         if (L.samp_tag[e]) amax(&H->samp_tag, L.samp_tag[e]);
+        if (SKETCH) {   // the entry's records reach the sketches as one (IPs, byte sum) contribution
+            uint64_t w[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
+            sketch_add(sk, w, L.bytes[e]);
+        }
     }
     if (skipped) aadd(&t.ctr->n_skipped, skipped);
     if (bypassed) aadd(&t.ctr->n_bypassed, bypassed);
 }
 
-template <int BLOCK, int K>
-static hipError_t run_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, int blocks_per_cu,
-                             hipStream_t s) {
+template <int BLOCK, int K, bool SKETCH>
+static hipError_t run_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
+                             int blocks_per_cu, hipStream_t s) {
     const size_t lds = sizeof(FlowCache<K>);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ingest_cached<BLOCK, K>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ingest_cached<BLOCK, K, SKETCH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -206,17 +213,23 @@ static hipError_t run_cached(const TableView& t, const void* d_records, uint64_t
     uint64_t grid = 256ull * blocks_per_cu;
     if (grid > tiles) grid = tiles;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_ingest_cached<BLOCK, K>), dim3((unsigned)grid), dim3(BLOCK), lds, s, t, d_records, n, seq_base);
+    hipLaunchKernelGGL((k_ingest_cached<BLOCK, K, SKETCH>), dim3((unsigned)grid), dim3(BLOCK), lds, s, t, sk, d_records, n, seq_base);
     return hipGetLastError();
 }
 
-hipError_t launch_ingest_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
+// sk.flags != 0: the sketch updates are fused into the kernel (no separate k_sketch_update launch).
+hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                                 int variant, hipStream_t s) {
+    const bool f = sk.flags != 0;
     switch (variant) {
-        case 3: return run_cached<512, 512>(t, d_records, n, seq_base, 2, s);     // 2 WG/CU x 64 KB
-        case 4: return run_cached<256, 256>(t, d_records, n, seq_base, 4, s);     // 4 WG/CU x 32 KB
-        case 5: return run_cached<1024, 512>(t, d_records, n, seq_base, 2, s);
-        default: return run_cached<1024, 1024>(t, d_records, n, seq_base, 1, s);  // variant 0: 1 WG/CU x 120 KB
+        case 3: return f ? run_cached<512, 512, true>(t, sk, d_records, n, seq_base, 2, s)       // 2 WG/CU x 64 KB
+                         : run_cached<512, 512, false>(t, sk, d_records, n, seq_base, 2, s);
+        case 4: return f ? run_cached<256, 256, true>(t, sk, d_records, n, seq_base, 4, s)       // 4 WG/CU x 32 KB
+                         : run_cached<256, 256, false>(t, sk, d_records, n, seq_base, 4, s);
+        case 5: return f ? run_cached<1024, 512, true>(t, sk, d_records, n, seq_base, 2, s)
+                         : run_cached<1024, 512, false>(t, sk, d_records, n, seq_base, 2, s);
+        default: return f ? run_cached<1024, 1024, true>(t, sk, d_records, n, seq_base, 1, s)    // variant 0: 1 WG/CU x 120 KB
+                          : run_cached<1024, 1024, false>(t, sk, d_records, n, seq_base, 1, s);
     }
 }
 

@@ -81,8 +81,11 @@ struct SketchView {
 // ---- launch wrappers (defined in nfagg_kernels.hip) ----
 // Fold records[0..n) into the table; record i carries sequence seq_base + i.
 // variant: 0 = default, see DESIGN.md.
-hipError_t launch_ingest(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
+// When ingest_fuses_sketches(variant), the kernel also applies the sketch updates of sk
+// (pass sk.flags = 0 to disable); otherwise the caller launches launch_sketch_update itself.
+hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                          int mode, int variant, hipStream_t s);
+bool ingest_fuses_sketches(int variant);
 // Careful path, phase A: claim slots only; writes the slot index of every record.
 hipError_t launch_claim(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
                         uint32_t* d_slot_idx, hipStream_t s);

@@ -139,16 +139,18 @@ static inline int grid_for(uint64_t n, int block, int max_blocks) {
 
 hipError_t launch_ingest_lds(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
                              int variant, hipStream_t s);  // nfagg_ingest_lds.hip
-hipError_t launch_ingest_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
+hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                                 int variant, hipStream_t s);  // nfagg_ingest_cached.hip
 
-hipError_t launch_ingest(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
+bool ingest_fuses_sketches(int variant) { return variant != 1 && variant != 2; }
+
+hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                          int mode, int variant, hipStream_t s) {
     if (n == 0) return hipSuccess;
     (void)mode;
     // 0 (default) and 3..5: persistent LDS flow cache; 1: direct; 2: per-tile LDS fold
     if (variant == 2) return launch_ingest_lds(t, d_records, n, seq_base, variant, s);
-    if (variant != 1) return launch_ingest_cached(t, d_records, n, seq_base, variant, s);
+    if (variant != 1) return launch_ingest_cached(t, sk, d_records, n, seq_base, variant, s);
     (void)hipGetLastError(); hipLaunchKernelGGL(k_ingest_direct, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, t, d_records, n, seq_base);
     return hipGetLastError();
 }

@@ -21,22 +21,7 @@ __global__ __launch_bounds__(256) void k_sketch_update(SketchView sk, TableView 
         w[4] = ((uint64_t)c.x | ((uint64_t)c.y << 32)) & 0x00ffffffffffffffull;
         if (t.n_shards > 1 && shard_of_hash(key_hash(w), t.n_shards) != t.shard_id) continue;
         const uint64_t bytes = (uint64_t)d.z | ((uint64_t)d.w << 32);   // metrics.bytes @56
-#pragma unroll
-        for (int side = 0; side < 2; side++) {
-            const uint64_t lo = w[2 * side], hi = w[2 * side + 1];
-            if ((sk.flags & 1u) && bytes) {
-                const uint64_t ha = ip_hash(lo, hi, 0), hb = ip_hash(lo, hi, 1) | 1ull;
-                for (uint32_t r = 0; r < sk.cm_depth; r++)
-                    aadd(&sk.cm[side][((uint64_t)r << sk.cm_log2w) + cm_index(ha, hb, r, sk.cm_log2w)], bytes);
-            }
-            if (sk.flags & 2u) {
-                const uint64_t h = ip_hash(lo, hi, 2);
-                const uint64_t idx = h >> (64 - sk.hll_p);
-                const uint32_t rho = (uint32_t)__clzll((long long)((h << sk.hll_p) | (1ull << (sk.hll_p - 1)))) + 1u;
-                // registers only grow: a stale smaller value merely costs one atomic
-                if (sk.hll[side][idx] < rho) amax(&sk.hll[side][idx], rho);
-            }
-        }
+        sketch_add(sk, w, bytes);
     }
 }
 

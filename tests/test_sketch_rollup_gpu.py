@@ -6,11 +6,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_count_min_and_hll_match_scalar_oracle(nf, O):
+@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3])
+def test_count_min_and_hll_match_scalar_oracle(nf, O, ingest_variant):
     th = O.zipf_thresholds(20000, 1.1)
     recs = O.gen_stream(200000, seed=3, n_keys=20000, thresholds=th, variant=1)
     depth, log2w, p = 4, 16, 14
-    with nf.FlowTable(max_entries=1 << 16, sketches=nf.SKETCH_CM | nf.SKETCH_HLL, cm_depth=depth, cm_log2_width=log2w, hll_p=p) as tab:
+    with nf.FlowTable(max_entries=1 << 16, sketches=nf.SKETCH_CM | nf.SKETCH_HLL, cm_depth=depth, cm_log2_width=log2w, hll_p=p,
+                      ingest_variant=ingest_variant) as tab:
         for off in range(0, len(recs), 50000):
             tab.ingest(recs[off:off + 50000].view(nf.FLOW_RECORD))
         cm_s, cm_d, hs, hd = O.sketches(recs, depth, log2w, p)
@@ -32,7 +34,8 @@ def test_count_min_and_hll_match_scalar_oracle(nf, O):
 def test_sketches_follow_the_consumed_prefix_only(nf, O):
     """When ingest stops at a 'full' split, only the consumed records reach the sketches."""
     recs = O.gen_stream(3000, seed=4, n_keys=500, variant=1)
-    with nf.FlowTable(max_entries=100, sketches=nf.SKETCH_CM | nf.SKETCH_HLL, cm_log2_width=12, hll_p=10) as tab:
+    for v in (0, 1):
+      with nf.FlowTable(max_entries=100, sketches=nf.SKETCH_CM | nf.SKETCH_HLL, cm_log2_width=12, hll_p=10, ingest_variant=v) as tab:
         rc, c = tab.ingest(recs.view(nf.FLOW_RECORD))
         assert rc == nf.FULL and 0 < c < len(recs)
         cm_s, _, hs, _ = O.sketches(recs[:c], 4, 12, 10)
