@@ -126,7 +126,7 @@ int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t 
     hipError_t e = launch_ingest(h->tv, h->sk, d, n, seq_base, (int)h->cfg.mode, (int)h->cfg.ingest_variant, h->stream);
     if (prof) prof_end(h, ep);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "ingest launch failed: %s", hipGetErrorString(e));
-    if (h->sk.flags && !ingest_fuses_sketches((int)h->cfg.ingest_variant)) {
+    if (h->sk.flags && !ingest_fuses_sketches((int)h->cfg.mode, (int)h->cfg.ingest_variant)) {
         if (prof) prof_begin(h, ep, 2);
         e = launch_sketch_update(h->sk, h->tv, d, n, h->stream);
         if (prof) prof_end(h, ep);
@@ -261,8 +261,8 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, NFAGG_ENODEV, "device %d is %s; libnfagg is built for gfx950 (MI355X) only", cfg.device, prop.gcnArchName);
     if (cfg.max_entries == 0) cfg.max_entries = 5000;   // CACHE_MAX_FLOWS default (pkg/config/config.go:146)
-    if (cfg.mode != NFAGG_MODE_ACCOUNTER)
-        return fail(nullptr, NFAGG_EINVAL, "mode %u not available in this build (kernel-dedup merge is on the roadmap, DESIGN.md)", cfg.mode);
+    if (cfg.mode != NFAGG_MODE_ACCOUNTER && cfg.mode != NFAGG_MODE_KERNEL_DEDUP)
+        return fail(nullptr, NFAGG_EINVAL, "unknown mode %u", cfg.mode);
     if (cfg.cm_depth == 0) cfg.cm_depth = 4;
     if (cfg.cm_log2_width == 0) cfg.cm_log2_width = 20;
     if (cfg.hll_p == 0) cfg.hll_p = 14;
@@ -298,6 +298,10 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
     CREATE_TRY(hipMalloc((void**)&h->tv.ctr, sizeof(DevCounters)));
     CREATE_TRY(hipMemsetAsync(h->tv.hot, 0, slots * sizeof(SlotHot), h->stream));
     CREATE_TRY(hipMemsetAsync(h->tv.cold, 0, slots * sizeof(SlotCold), h->stream));
+    if (cfg.mode == NFAGG_MODE_KERNEL_DEDUP) {
+        CREATE_TRY(hipMalloc((void**)&h->tv.aux, slots * sizeof(SlotAux)));
+        CREATE_TRY(hipMemsetAsync(h->tv.aux, 0, slots * sizeof(SlotAux), h->stream));
+    }
     CREATE_TRY(hipMemsetAsync(h->tv.ctr, 0, sizeof(DevCounters), h->stream));
     CREATE_TRY(hipHostMalloc((void**)&h->h_ctr, sizeof(DevCounters), hipHostMallocDefault));
     h->tv.mask = slots - 1; h->tv.n_shards = cfg.n_shards; h->tv.shard_id = cfg.shard_id;
@@ -329,7 +333,7 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     h->stats.table_slots = slots;
-    h->stats.table_bytes = slots * (sizeof(SlotHot) + sizeof(SlotCold));
+    h->stats.table_bytes = slots * (sizeof(SlotHot) + sizeof(SlotCold) + (h->tv.aux ? sizeof(SlotAux) : 0));
     *out = h;
     return NFAGG_OK;
 }
@@ -357,6 +361,7 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->d_block_counts) hipFree(h->d_block_counts);
     if (h->tv.hot) hipFree(h->tv.hot);
     if (h->tv.cold) hipFree(h->tv.cold);
+    if (h->tv.aux) hipFree(h->tv.aux);
     if (h->tv.live_list) hipFree(h->tv.live_list);
     if (h->tv.ctr) hipFree(h->tv.ctr);
     if (h->h_ctr) hipHostFree(h->h_ctr);

@@ -1,0 +1,324 @@
+// nfagg_dedup.hip — NFAGG_MODE_KERNEL_DEDUP: the merge the eBPF datapath applies
+// when one flow is seen on several interfaces ("direction dedup"),
+// bpf/flows.c:98-143 update_existing_flow + :76-96 add_observed_intf, applied to
+// whole records: the incoming record plays the role of one observation
+// (packet + if_index + direction + tls info).
+//
+// Sequential semantics being reproduced, for the records r0,r1,... of one key in
+// one eviction epoch (r0 is stored whole, account.go:95; F = r0.if_index_first_seen):
+//   r.if_index == F ("counted")  : packets/bytes +=, end = r.end, flags |=, dscp = r.dscp,
+//                                  sampling = r.sampling, ssl/tls rules of flows.c:112-126
+//   r.if_index != F, != 0 ("side"): end = r.end, flags |=, add_observed_intf(if_index, direction)
+//   r.if_index == 0 != F          : ignored
+// Everything is resolved from per-record sequence numbers with order-free
+// operations, in two passes over a batch:
+//   pass 1 k_dedup_claim : claim the slot, resolve the first record (tagged max, as in
+//                          accounter mode) and the seven interfaces that appear earliest;
+//   pass 2 k_dedup_fold  : F and the first record are now known exactly — sums, ORs,
+//                          "last value" tags, first-record identity, and for side records
+//                          the two earliest distinct directions of their interface.
+// k_evict_dedup replays add_observed_intf over those (at most 14) events in sequence
+// order, starting from r0's own observed list, which reproduces capacity cut-off
+// (MAX_OBSERVED_INTERFACES, flows.c:79) and the merge to OBSERVED_DIRECTION_BOTH exactly.
+//
+// Why seven candidates suffice: F (when non-zero) is the earliest interface of the
+// flow, so six of the seven are side interfaces; an interface outside the earliest
+// seven arrives after six other side interfaces, each of which is in the list
+// already (from r0) or was appended — the list is full and flows.c:79 ignores it.
+#include "nfagg_device.h"
+
+namespace nfagg {
+
+constexpr uint32_t kObservedMax = 6;      // MAX_OBSERVED_INTERFACES (bpf/types.h)
+constexpr uint32_t kDirBoth = 3;          // OBSERVED_DIRECTION_BOTH
+constexpr uint32_t kTlsServerHello = 2;   // TLSTRACKER_BF_SERVER_HELLO (bpf/tls_tracker.h)
+constexpr uint32_t kMiscSslMismatch = 1;  // MISC_FLAGS_SSL_MISMATCH
+constexpr int kCand = 7;
+
+// Keep the K largest words among the best word per distinct match-key (the bits under
+// MATCH) in w[0..K). Larger word = earlier record ((~seq) in the high bits). Lock-free:
+//   * a word with my key and a value >= mine: nothing to do;
+//   * a word with my key and a smaller value: CAS it up;
+//   * otherwise replace the smallest word (ties: lowest index; empty = 0) when mine is larger.
+// Every position only ever grows, and a word is installed by a CAS on the smallest
+// position of a snapshot, so one key can never sit in two positions (if it did, both
+// installers would have seen the other's position as small as their own, which strict
+// growth only allows for two empty positions — excluded by the lowest-index rule).
+// A failed CAS means another lane made progress; nobody waits on anybody.
+template <int K, uint64_t MATCH>
+NF_DEV void topk_insert(const TableView& t, uint64_t* w, uint64_t v) {
+    for (uint32_t trip = 0; trip < kSpinLimit; trip++) {
+        // snapshot; pos/cur = the word holding my key if any, else the smallest word (lowest index on ties)
+        uint64_t cur = ald(&w[0]);
+        int pos = 0;
+        bool hit = cur != 0 && ((cur ^ v) & MATCH) == 0;
+#pragma unroll
+        for (int k = 1; k < K; k++) {
+            const uint64_t c = ald(&w[k]);
+            const bool mine = c != 0 && ((c ^ v) & MATCH) == 0;
+            if (mine || (!hit && c < cur)) { cur = c; pos = k; }
+            hit |= mine;
+        }
+        if (cur >= v) return;
+        if (acas(&w[pos], cur, v) == cur) return;
+    }
+    atomicExch(&t.ctr->error, 4u);
+}
+
+NF_DEV bool record_prologue(const TableView& t, const void* recs, uint64_t i, Rec& r, uint64_t w[5], uint64_t& h) {
+    load_record(recs, i, r);
+    r.canonicalize();
+    r.key_words(w);
+    h = key_hash(w);
+    return !(t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id);
+}
+
+// ---- pass 1: c.entries[id] lookup-or-insert; first record; earliest interfaces
+__global__ __launch_bounds__(256) void k_dedup_claim(TableView t, const void* __restrict__ recs, uint64_t n, uint64_t seq_base) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long skipped = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Rec r;
+        uint64_t w[5], h;
+        if (!record_prologue(t, recs, i, r, w, h)) { skipped++; continue; }
+        Hints x;
+        uint32_t idx = probe_home(t, w, h, x);
+        if (idx == kNoSlot) {
+            idx = find_or_claim(t, w, h);
+            if (idx == kNoSlot) continue;
+            x.id0 = 0;
+        }
+        const uint32_t inv = ~(uint32_t)(seq_base + i);
+        const uint64_t my0 = tagged(inv, r.d[21]);
+        if (x.id0 < my0) amax(&t.hot[idx].id0, my0);
+        const uint32_t ifx = r.d[21];
+        if (ifx != 0) {
+            const uint64_t v = tagged(inv, ifx);
+            // cheap exit on possibly stale plain loads: a word that once held this interface with an
+            // earlier-or-equal record makes this record irrelevant for good (see topk_insert)
+            const uint64_t* cw = t.aux[idx].cand;
+            bool known = false;
+#pragma unroll
+            for (int k = 0; k < kCand; k++) { const uint64_t c = cw[k]; known |= ((uint32_t)c == ifx) & (c >= v); }
+            if (!known) topk_insert<kCand, 0xffffffffull>(t, t.aux[idx].cand, v);
+        }
+    }
+    if (skipped) aadd(&t.ctr->n_skipped, skipped);
+}
+
+// ---- pass 2: update_existing_flow for every record (the first record included: it
+// contributes exactly what "stored whole" keeps, see the header of this file)
+__global__ __launch_bounds__(256) void k_dedup_fold(TableView t, const void* __restrict__ recs, uint64_t n, uint64_t seq_base) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Rec r;
+        uint64_t w[5], h;
+        if (!record_prologue(t, recs, i, r, w, h)) continue;
+        Hints x;
+        uint32_t idx = probe_home(t, w, h, x);
+        if (idx == kNoSlot) {
+            idx = find_or_claim(t, w, h);          // pass 1 claimed it: this only walks the probe sequence
+            if (idx == kNoSlot) continue;
+            load_hints(&t.hot[idx], x);
+        }
+        SlotHot* H = &t.hot[idx];
+        SlotCold* C = &t.cold[idx];
+        SlotAux* A = &t.aux[idx];
+        const uint32_t seq32 = (uint32_t)(seq_base + i);
+        const uint32_t inv = ~seq32;
+        const uint64_t s1 = (uint64_t)seq32 + 1;
+        // id0 was resolved by pass 1 (a previous kernel): plain load is exact here
+        const uint32_t first_inv = (uint32_t)(x.id0 >> 32);
+        const uint32_t F = (uint32_t)x.id0;
+        const uint32_t ifx = r.d[21];
+        const uint32_t dirn = r.d[24] & 0xffu;
+        if (first_inv == inv) {
+            // the first record of the flow in this epoch: stored whole (account.go:95)
+            ast(&H->start_inv, r.start());                       // raw start
+            ast(&H->eth_tag, (uint64_t)r.eth());                 // raw eth_protocol
+            ast(&H->smac_lo, tagged(inv, (uint32_t)r.smac()));
+            ast(&C->smac_hi, tagged(inv, (uint32_t)(r.smac() >> 32)));
+            ast(&H->dmac_lo, tagged(inv, (uint32_t)r.dmac()));
+            ast(&C->dmac_hi, tagged(inv, (uint32_t)(r.dmac() >> 32)));
+#pragma unroll
+            for (int k = 1; k < 15; k++) ast(&C->id[k - 1], tagged(inv, r.d[21 + k]));
+        }
+        const bool counted = ifx == F;
+        if (!counted && ifx == 0) continue;                      // flows.c:126: `else if (if_index != 0)`
+        // end = r.end, by the LAST record that reaches either branch (flows.c:108,128)
+        const uint64_t e = r.end();
+        amax(&A->endl_lo, (s1 << 32) | (uint32_t)e);
+        amax(&A->endl_hi, (s1 << 32) | (uint32_t)(e >> 32));
+        uint32_t fl = r.flags();
+        if (counted) {
+            if (r.bytes()) aadd(&H->bytes, r.bytes());
+            if (r.packets()) aadd(&H->packets, r.packets());
+            fl |= ((r.d[34] >> 16) & 0xffu) << 16;               // tls_types |= (flows.c:125)
+            amax(&H->dscp_tag, (s1 << 8) | r.dscp());            // dscp = pkt->dscp (zero included)
+            amax(&H->samp_tag, (s1 << 32) | r.sampling());       // sampling = sampling
+            const uint32_t ssl = r.d[33] & 0xffffu;
+            if (ssl) {
+                amax(&A->ssl_first, tagged(inv, ssl));
+                atomicMax(&A->ssl_max, ssl);
+                atomicMax(&A->ssl_minv, 0x10000u - ssl);
+            }
+            const uint32_t types = (r.d[34] >> 16) & 0xffu;
+            const uint32_t cs = r.d[33] >> 16, ks = r.d[34] & 0xffffu;
+            if (cs && types == kTlsServerHello) amax(&A->cs_tag, (s1 << 16) | cs);
+            if (ks && types == kTlsServerHello) amax(&A->ks_tag, (s1 << 16) | ks);
+        } else {
+            // side record: remember the two earliest distinct directions of its interface
+            int pos = -1;
+#pragma unroll
+            for (int k = 0; k < kCand; k++) { const uint64_t c = A->cand[k]; if (c != 0 && (uint32_t)c == ifx) pos = k; }
+            if (pos >= 0) {
+                const uint64_t v = ((uint64_t)inv << 8) | dirn;
+                uint64_t* dw = A->dir[pos];
+                const uint64_t d0 = dw[0], d1 = dw[1];           // stale copies are lower bounds per direction
+                const bool known = (((uint32_t)d0 & 0xffu) == dirn && d0 >= v) || (((uint32_t)d1 & 0xffu) == dirn && d1 >= v);
+                if (!known) topk_insert<2, 0xffull>(t, dw, v);
+            }
+        }
+        if (fl & ~x.flags) aor(&H->flags, fl);
+    }
+}
+
+// ---- evict: rebuild the record; replay add_observed_intf over the recorded events
+__global__ __launch_bounds__(256) void k_evict_dedup(TableView t, uint64_t n_live, uint64_t seq_limit, void* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_live; i += stride) {
+        const uint32_t idx = t.live_list[i];
+        SlotHot* H = &t.hot[idx];
+        SlotCold* C = &t.cold[idx];
+        SlotAux* A = &t.aux[idx];
+        const SlotHot hv = *H;
+        const SlotCold cv = *C;
+        const SlotAux av = *A;
+        const uint32_t first_inv = (uint32_t)(hv.id0 >> 32);
+        const bool emit = first_inv != 0 && (uint64_t)(~first_inv) < seq_limit;
+        if (emit) {
+            uint32_t d[kRecordDwords];
+#pragma unroll
+            for (int k = 0; k < 5; k++) { d[2 * k] = (uint32_t)hv.key[k]; d[2 * k + 1] = (uint32_t)(hv.key[k] >> 32); }
+            d[10] = (uint32_t)hv.start_inv; d[11] = (uint32_t)(hv.start_inv >> 32);
+            d[12] = (uint32_t)av.endl_lo; d[13] = (uint32_t)av.endl_hi;
+            d[14] = (uint32_t)hv.bytes; d[15] = (uint32_t)(hv.bytes >> 32);
+            d[16] = hv.packets;
+            d[17] = (uint32_t)(hv.eth_tag & 0xffffu) | ((hv.flags & 0xffffu) << 16);
+            const uint64_t smac = (uint64_t)(uint32_t)hv.smac_lo | ((uint64_t)(cv.smac_hi & 0xffffu) << 32);
+            const uint64_t dmac = (uint64_t)(uint32_t)hv.dmac_lo | ((uint64_t)(cv.dmac_hi & 0xffffu) << 32);
+            d[18] = (uint32_t)smac;
+            d[19] = (uint32_t)((smac >> 32) & 0xffffu) | (uint32_t)((dmac & 0xffffu) << 16);
+            d[20] = (uint32_t)(dmac >> 16);
+            d[21] = (uint32_t)hv.id0;
+#pragma unroll
+            for (int k = 0; k < 14; k++) d[22 + k] = (uint32_t)cv.id[k];
+            d[23] = (uint32_t)hv.samp_tag;
+            d[24] = (d[24] & 0xff00ffffu) | ((uint32_t)(hv.dscp_tag & 0xffu) << 16);
+            // tls / ssl (flows.c:112-125)
+            const uint32_t ssl = (uint32_t)av.ssl_first & 0xffffu;
+            uint32_t cs = d[33] >> 16, ks = d[34] & 0xffffu, misc = d[34] >> 24;
+            if (av.cs_tag) cs = (uint32_t)av.cs_tag & 0xffffu;
+            if (av.ks_tag) ks = (uint32_t)av.ks_tag & 0xffffu;
+            if (av.ssl_max && (0x10000u - av.ssl_minv) != av.ssl_max) misc |= kMiscSslMismatch;
+            d[33] = ssl | (cs << 16);
+            d[34] = ks | (((hv.flags >> 16) & 0xffu) << 16) | (misc << 24);
+            // observed interfaces: start from the first record's own list, replay the events
+            uint32_t nb = d[24] >> 24;
+            uint32_t oi[kObservedMax], od[kObservedMax];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                oi[k] = d[27 + k];
+                od[k] = k < 4 ? (d[25] >> (8 * k)) & 0xffu : (d[26] >> (8 * (k - 4))) & 0xffu;
+            }
+            const uint32_t F = d[21];
+            uint64_t ev[2 * kCand];      // (~seq)<<8 | dir : larger = earlier
+            uint32_t ex[2 * kCand];
+#pragma unroll
+            for (int k = 0; k < kCand; k++) {
+                const uint32_t ifx = (uint32_t)av.cand[k];
+                const bool side = av.cand[k] != 0 && ifx != F;
+                ev[2 * k] = side ? av.dir[k][0] : 0; ev[2 * k + 1] = side ? av.dir[k][1] : 0;
+                ex[2 * k] = ifx; ex[2 * k + 1] = ifx;
+            }
+            for (int round = 0; round < 2 * kCand && nb < kObservedMax; round++) {
+                int best = 0;
+                uint64_t bv = ev[0]; uint32_t bx = ex[0];
+#pragma unroll
+                for (int k = 1; k < 2 * kCand; k++) { if (ev[k] > bv) { bv = ev[k]; bx = ex[k]; best = k; } }
+                if (bv == 0) break;
+#pragma unroll
+                for (int k = 0; k < 2 * kCand; k++) if (k == best) ev[k] = 0;
+                const uint32_t dirn = (uint32_t)bv & 0xffu;
+                // add_observed_intf (flows.c:76-96); nb < 6 holds here
+                bool found = false;
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    if (!found && (uint32_t)k < nb && oi[k] == bx) {
+                        found = true;
+                        if (od[k] != dirn && od[k] != kDirBoth) od[k] = kDirBoth;
+                    }
+                }
+                if (!found) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) if ((uint32_t)k == nb) { oi[k] = bx; od[k] = dirn; }
+                    nb++;
+                }
+            }
+            d[24] = (d[24] & 0x00ffffffu) | (nb << 24);
+            d[25] = od[0] | (od[1] << 8) | (od[2] << 16) | (od[3] << 24);
+            d[26] = (d[26] & 0xffff0000u) | od[4] | (od[5] << 8);
+#pragma unroll
+            for (int k = 0; k < 6; k++) d[27 + k] = oi[k];
+            const unsigned long long pos = aadd(&t.ctr->n_out, 1ull);
+            uint4* o = reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + pos * kRecordBytes);
+#pragma unroll
+            for (int k = 0; k < 9; k++) o[k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+        }
+        uint4* hz = reinterpret_cast<uint4*>(H);
+        uint4* cz = reinterpret_cast<uint4*>(C);
+        uint4* az = reinterpret_cast<uint4*>(A);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { hz[k] = make_uint4(0, 0, 0, 0); cz[k] = make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int k = 0; k < 16; k++) az[k] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+static inline int grid_for(uint64_t n, int block, int max_blocks) {
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+hipError_t launch_ingest_dedup(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    if (!t.aux) return hipErrorInvalidValue;
+    const int grid = grid_for(n, 256, 256 * 8);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_dedup_claim, dim3(grid), dim3(256), 0, s, t, d_records, n, seq_base);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_dedup_fold, dim3(grid), dim3(256), 0, s, t, d_records, n, seq_base);
+    return hipGetLastError();
+}
+
+__global__ void k_reset_after_evict_dedup(DevCounters* c) {
+    c->n_live = 0;
+    c->max_probe = 0;
+}
+
+hipError_t launch_evict_dedup(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s) {
+    if (n_live) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_evict_dedup, dim3(grid_for(n_live, 256, 256 * 8)), dim3(256), 0, s, t, n_live, seq_limit, d_out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_reset_after_evict_dedup, dim3(1), dim3(1), 0, s, t.ctr);
+    return hipGetLastError();
+}
+
+}  // namespace nfagg

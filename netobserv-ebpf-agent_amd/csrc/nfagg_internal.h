@@ -52,6 +52,33 @@ struct alignas(128) SlotCold {
 };
 static_assert(sizeof(SlotCold) == 128, "cold line");
 
+// Kernel-dedup mode only (NFAGG_MODE_KERNEL_DEDUP, bpf/flows.c:76-143): two more
+// lines per slot. In this mode the hot line's start_inv holds the FIRST record's raw
+// start, eth_tag its raw eth_protocol (update_existing_flow never touches them),
+// `end` is unused, flags carries tls_types in bits 16..23, and dscp/sampling tags
+// are fed by every counted record (zero values included: "last", not "last non-zero").
+//
+// cand[]: the (up to) seven interfaces with the earliest first appearance in the
+// epoch, one word (~seq)<<32 | if_index each, maintained by a lock-free CAS protocol
+// (nfagg_dedup.hip topk_insert) — the flow's own if_index_first_seen is always one
+// of them, which leaves the six that observed_intf[] can take (flows.c:79).
+// dir[j][]: for candidate j the two earliest DISTINCT direction values,
+// (~seq)<<8 | direction — all add_observed_intf needs to replay the merge to
+// OBSERVED_DIRECTION_BOTH (flows.c:84-88) in arrival order at eviction.
+struct alignas(128) SlotAux {
+    uint64_t cand[7];
+    uint64_t endl_lo;     // max of (seq+1)<<32 | low  32 bits of end : end is ASSIGNED by the last record (flows.c:108,127)
+    uint64_t endl_hi;     // max of (seq+1)<<32 | high 32 bits
+    uint64_t ssl_first;   // tagged: first non-zero ssl_version among the counted records (flows.c:112-119)
+    uint32_t ssl_max;     // max / min over the non-zero ssl versions: they differ <=> MISC_FLAGS_SSL_MISMATCH
+    uint32_t ssl_minv;    // max of 0x10000 - ssl (0 = none seen)
+    uint64_t cs_tag;      // max of (seq+1)<<16 | tls_cipher_suite over server hellos (flows.c:120-122)
+    uint64_t ks_tag;      // same for tls_key_share (flows.c:123-125)
+    uint64_t dir[7][2];
+    uint64_t pad[5];
+};
+static_assert(sizeof(SlotAux) == 256, "aux lines");
+
 // Device-resident counters, mirrored to pinned host memory on demand.
 struct DevCounters {
     unsigned long long n_live;     // claimed slots this epoch (== len(c.entries) unless a split is pending)
@@ -66,6 +93,7 @@ struct DevCounters {
 struct TableView {
     SlotHot* hot;
     SlotCold* cold;
+    SlotAux* aux;                  // non-null only in kernel-dedup mode
     uint32_t* live_list;           // slot indices claimed this epoch, in claim order
     DevCounters* ctr;
     uint64_t mask;                 // slots - 1
@@ -85,7 +113,10 @@ struct SketchView {
 // (pass sk.flags = 0 to disable); otherwise the caller launches launch_sketch_update itself.
 hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                          int mode, int variant, hipStream_t s);
-bool ingest_fuses_sketches(int variant);
+bool ingest_fuses_sketches(int mode, int variant);
+// Kernel-dedup mode (nfagg_dedup.hip): two passes over the batch (claim + earliest interfaces, then fold).
+hipError_t launch_ingest_dedup(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
+hipError_t launch_evict_dedup(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);
 // Careful path, phase A: claim slots only; writes the slot index of every record.
 hipError_t launch_claim(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
                         uint32_t* d_slot_idx, hipStream_t s);

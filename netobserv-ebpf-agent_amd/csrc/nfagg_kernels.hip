@@ -142,12 +142,12 @@ hipError_t launch_ingest_lds(const TableView& t, const void* d_records, uint64_t
 hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                                 int variant, hipStream_t s);  // nfagg_ingest_cached.hip
 
-bool ingest_fuses_sketches(int variant) { return variant != 1 && variant != 2; }
+bool ingest_fuses_sketches(int mode, int variant) { return mode == 0 && variant != 1 && variant != 2; }
 
 hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                          int mode, int variant, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    (void)mode;
+    if (mode == 1) return launch_ingest_dedup(t, d_records, n, seq_base, s);   // NFAGG_MODE_KERNEL_DEDUP
     // 0 (default) and 3..5: persistent LDS flow cache; 1: direct; 2: per-tile LDS fold
     if (variant == 2) return launch_ingest_lds(t, d_records, n, seq_base, variant, s);
     if (variant != 1) return launch_ingest_cached(t, sk, d_records, n, seq_base, variant, s);
@@ -171,6 +171,7 @@ hipError_t launch_first_flags(const TableView& t, const uint32_t* d_slot_idx, ui
 }
 
 hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s) {
+    if (t.aux) return launch_evict_dedup(t, n_live, seq_limit, d_out, s);
     if (n_live) {
         (void)hipGetLastError(); hipLaunchKernelGGL(k_evict, dim3(grid_for(n_live, 256, 256 * 8)), dim3(256), 0, s, t, n_live, seq_limit, d_out);
         hipError_t e = hipGetLastError();

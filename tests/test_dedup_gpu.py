@@ -1,0 +1,131 @@
+"""NFAGG_MODE_KERNEL_DEDUP parity: the HIP two-pass dedup merge (csrc/nfagg_dedup.hip),
+called through the C ABI, against the oracle's sequential restatement of
+bpf/flows.c:76-143 (update_existing_flow + add_observed_intf) — bit-exact on all
+144 bytes. The reference has no unit test for this merge (SURVEY.md §8(c):
+parity unpinned); the oracle follows the source text line by line."""
+import numpy as np
+import pytest
+
+from conftest import assert_records_equal
+from test_parity_gpu import drive_product
+
+pytestmark = pytest.mark.gpu
+
+
+def dedup_stream(O, n, seed, n_keys, thresholds=None, hot_permille=0, style=0):
+    """Scrambled records (variant 1: if_index 1..8, direction 0/1, first-record observed
+    lists of 0..6 entries, ssl/tls fields) re-shaped per `style` to reach every branch
+    of flows.c:98-143."""
+    r = O.gen_stream(n, seed=seed, n_keys=n_keys, thresholds=thresholds, hot_permille=hot_permille, variant=1)
+    m = r["metrics"]
+    rng = np.random.default_rng(seed)
+    if style == 1:      # few interfaces, clean first records: the common shape (two interfaces, both directions)
+        m["if_index_first_seen"] = 2 + rng.integers(0, 2, n)
+        m["nb_observed_intf"] = 0
+        m["observed_intf"] = 0
+        m["observed_direction"] = 0
+    elif style == 2:    # many interfaces (capacity cut-off), zero if_index, odd direction bytes, BOTH pre-set
+        m["if_index_first_seen"] = rng.integers(0, 14, n)
+        m["direction_first_seen"] = rng.choice(np.array([0, 1, 1, 0, 2, 3, 7], dtype=np.uint8), n)
+        m["nb_observed_intf"] = rng.choice(np.array([0, 0, 1, 2, 5, 6, 7, 255], dtype=np.uint8), n)
+        m["observed_intf"] = rng.integers(0, 14, (n, 6))
+        m["observed_direction"] = rng.integers(0, 4, (n, 6))
+        m["ssl_version"] = rng.choice(np.array([0, 0, 0, 0x0303, 0x0304], dtype=np.uint16), n)
+        m["tls_types"] = rng.choice(np.array([0, 1, 2, 2, 4], dtype=np.uint8), n)
+        m["tls_cipher_suite"] = rng.choice(np.array([0, 0x1301, 0x1302, 0xc02f], dtype=np.uint16), n)
+        m["tls_key_share"] = rng.choice(np.array([0, 0x001d, 0x0017], dtype=np.uint16), n)
+    elif style == 3:    # 64-bit end values (both tagged halves matter), end going backwards
+        m["end"] = rng.integers(0, 1 << 63, n, dtype=np.uint64) * rng.integers(0, 2, n, dtype=np.uint64)
+        m["if_index_first_seen"] = rng.integers(0, 4, n)
+    return r
+
+
+def check_dedup(nf, O, records, max_entries, batch, **kw):
+    want = O.run_accounter(records, max_entries, mode=1)
+    with nf.FlowTable(max_entries=max_entries, mode=nf.MODE_KERNEL_DEDUP, **kw) as tab:
+        got = drive_product(tab, records.view(nf.FLOW_RECORD), batch)
+    assert [r for r, _ in got] == [r for r, _ in want], "eviction sequence differs"
+    for k, ((_, g), (_, w)) in enumerate(zip(got, want)):
+        assert_records_equal(g, w, f"dedup eviction #{k}")
+    return want
+
+
+@pytest.mark.parametrize("style", [0, 1, 2, 3])
+@pytest.mark.parametrize("batch", [1 << 30, 1000, 257])
+def test_dedup_stream_parity(nf, O, style, batch):
+    th = O.zipf_thresholds(300, 1.1)
+    recs = dedup_stream(O, 40000, seed=200 + style, n_keys=300, thresholds=th, style=style)
+    want = check_dedup(nf, O, recs, 1 << 16, batch)
+    ev = want[0][1]
+    assert len(ev) > 150
+    if style in (0, 2):
+        assert (ev["metrics"]["nb_observed_intf"] == 6).any() and (ev["metrics"]["observed_direction"] == 3).any()
+
+
+def test_dedup_differs_from_accounter_mode(nf, O):
+    """The two modes must not be the same function: bytes are only counted on the first interface."""
+    recs = dedup_stream(O, 5000, seed=3, n_keys=20, style=1)
+    a = O.run_accounter(recs, 1000, mode=0)[0][1]
+    d = check_dedup(nf, O, recs, 1000, 1 << 30)[0][1]
+    assert len(a) == len(d) and (a["metrics"]["bytes"] != d["metrics"]["bytes"]).any()
+    assert (d["metrics"]["nb_observed_intf"] >= 1).all()
+
+
+def test_dedup_single_record_batches(nf, O):
+    recs = dedup_stream(O, 500, seed=5, n_keys=12, style=2)
+    check_dedup(nf, O, recs, 1000, 1)
+
+
+def test_dedup_hot_key(nf, O):
+    """BASELINE configs[4]: 90 % of the records are one flow, dedup on, interfaces alternating."""
+    th = O.zipf_thresholds(2000, 1.1)
+    recs = dedup_stream(O, 60000, seed=6, n_keys=2000, thresholds=th, hot_permille=900, style=1)
+    check_dedup(nf, O, recs, 1 << 16, 1 << 30)
+    recs = dedup_stream(O, 60000, seed=7, n_keys=2000, thresholds=th, hot_permille=900, style=2)
+    check_dedup(nf, O, recs, 1 << 16, 1 << 30)
+
+
+@pytest.mark.parametrize("max_entries,batch", [(2, 1 << 30), (50, 333), (1, 50), (250, 4096)])
+def test_dedup_evict_on_full_inside_batches(nf, O, max_entries, batch):
+    th = O.zipf_thresholds(400, 1.1)
+    recs = dedup_stream(O, 12000, seed=77, n_keys=400, thresholds=th, style=2)
+    want = check_dedup(nf, O, recs, max_entries, batch)
+    assert sum(1 for r, _ in want if r == "full") >= 2
+
+
+def test_dedup_epochs_and_ragged_sizes(nf, O):
+    for n in (1, 63, 65, 257, 1025):
+        check_dedup(nf, O, dedup_stream(O, n, seed=n, n_keys=9, style=2), 1000, 1 << 30)
+    a = dedup_stream(O, 4000, seed=11, n_keys=50, style=0)
+    b = dedup_stream(O, 4000, seed=12, n_keys=50, style=2)
+    with nf.FlowTable(max_entries=1000, mode=nf.MODE_KERNEL_DEDUP) as tab:
+        for part in (a, b, a):
+            assert tab.ingest(part.view(nf.FLOW_RECORD)) == (nf.OK, len(part))
+            got = nf.sort_by_key(tab.evict(nf.REASON_TIMEOUT))
+            assert_records_equal(got, O.run_accounter(part, 1000, mode=1)[0][1])
+            assert len(tab) == 0
+
+
+@pytest.mark.parametrize("n_shards", [2, 8])
+def test_dedup_sharded(nf, O, n_shards):
+    th = O.zipf_thresholds(500, 1.1)
+    recs = dedup_stream(O, 20000, seed=8, n_keys=500, thresholds=th, style=2)
+    parts = []
+    for s in range(n_shards):
+        with nf.FlowTable(max_entries=4096, mode=nf.MODE_KERNEL_DEDUP, n_shards=n_shards, shard_id=s) as tab:
+            assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
+            parts.append(tab.evict())
+    assert_records_equal(nf.sort_by_key(np.concatenate(parts)), O.run_accounter(recs, 1 << 20, mode=1)[0][1])
+
+
+def test_dedup_with_sketches(nf, O):
+    """Sketches run as their own kernel in dedup mode and see every record."""
+    recs = dedup_stream(O, 20000, seed=9, n_keys=300, style=1)
+    with nf.FlowTable(max_entries=4096, mode=nf.MODE_KERNEL_DEDUP, sketches=nf.SKETCH_CM | nf.SKETCH_HLL) as tab:
+        assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
+        cm = tab.sketch_snapshot(nf.CM_SRC)
+        hll = tab.sketch_snapshot(nf.HLL_DST)
+        got = nf.sort_by_key(tab.evict())
+    cs, _, _, hd = O.sketches(recs)
+    assert np.array_equal(cm, cs) and np.array_equal(hll, hd)
+    assert_records_equal(got, O.run_accounter(recs, 4096, mode=1)[0][1])
