@@ -61,6 +61,9 @@ struct nfagg_handle {
     void* d_roll[3] = {nullptr, nullptr, nullptr};
     size_t d_roll_cap[3] = {0, 0, 0};
     uint32_t* d_hist = nullptr;
+    // spill queues of the two-pass ingest
+    void* d_spill = nullptr;
+    size_t d_spill_cap = 0;
     // accounting
     uint64_t epoch_seq = 0;
     uint64_t live = 0;       // exact when live_exact
@@ -119,9 +122,28 @@ void prof_resolve(nfagg_handle* h) {
     h->ev_pending.clear();
 }
 
+int ensure_bytes(nfagg_handle* h, void** p, size_t* cap, size_t need);
+
 int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t seq_base) {
     EventPair ep{};
     const bool prof = h->cfg.profile != 0;
+    if (ingest_needs_spill((int)h->cfg.mode, (int)h->cfg.ingest_variant)) {
+        // room for twice the even share of a batch in which every record spills; beyond that the kernel merges directly
+        uint64_t qcap = (2 * n / kSpillParts + 1024 + 3) & ~3ull;
+        // overflow list: every record may overflow, plus one padded group per partition per workgroup
+        const uint64_t ovf_cap = ((n + 3) & ~3ull) + 256ull * kSpillParts * 4;
+        if (qcap > h->tv.spill.qcap || ovf_cap > h->tv.spill.ovf_cap) {
+            if (qcap < h->tv.spill.qcap) qcap = h->tv.spill.qcap;
+            const size_t qbytes = (size_t)kSpillParts * qcap * sizeof(uint32_t);
+            int rc = ensure_bytes(h, &h->d_spill, &h->d_spill_cap, qbytes + ovf_cap * sizeof(uint32_t));
+            if (rc != NFAGG_OK) return rc;
+            h->tv.spill.queue = (uint32_t*)h->d_spill;
+            h->tv.spill.qcap = (uint32_t)qcap;
+            h->tv.spill.ovf = (uint32_t*)((char*)h->d_spill + qbytes);
+            h->tv.spill.ovf_cap = (uint32_t)((h->d_spill_cap - qbytes) / sizeof(uint32_t) > 0xfffffff0ull ? 0xfffffff0ull
+                                             : ((h->d_spill_cap - qbytes) / sizeof(uint32_t)) & ~3ull);
+        }
+    }
     if (prof) { if (h->ev_pending.size() >= 8192) prof_resolve(h); prof_begin(h, ep, 0); }
     hipError_t e = launch_ingest(h->tv, h->sk, d, n, seq_base, (int)h->cfg.mode, (int)h->cfg.ingest_variant, h->stream);
     if (prof) prof_end(h, ep);
@@ -330,6 +352,10 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
         }
     }
     CREATE_TRY(hipMalloc((void**)&h->d_hist, 65 * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc((void**)&h->tv.spill.qtail, (kSpillParts + 1) * sizeof(uint32_t)));
+    CREATE_TRY(hipMemsetAsync(h->tv.spill.qtail, 0, (kSpillParts + 1) * sizeof(uint32_t), h->stream));
+    h->tv.spill.ovf_tail = h->tv.spill.qtail + kSpillParts;
+    h->tv.spill.error = &h->tv.ctr->error;
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     h->stats.table_slots = slots;
@@ -355,6 +381,8 @@ void nfagg_destroy(nfagg_handle* h) {
     }
     for (int k = 0; k < 3; k++) if (h->d_roll[k]) hipFree(h->d_roll[k]);
     if (h->d_hist) hipFree(h->d_hist);
+    if (h->d_spill) hipFree(h->d_spill);
+    if (h->tv.spill.qtail) hipFree(h->tv.spill.qtail);
     if (h->d_evict) hipFree(h->d_evict);
     if (h->d_slot_idx) hipFree(h->d_slot_idx);
     if (h->d_flags) hipFree(h->d_flags);
@@ -694,6 +722,16 @@ int nfagg_stats_get(nfagg_handle* h, nfagg_stats* out) {
     h->stats.entries = h->live;
     h->stats.epoch_seq = h->epoch_seq;
     *out = h->stats;
+    return NFAGG_OK;
+}
+
+// Diagnostics (not part of the drop-in ABI): per-phase wave-cycle sums of ingest_variant 6.
+int nfagg_debug_phase_cycles(nfagg_handle* h, uint64_t out[8]) {
+    if (!h || !out) return NFAGG_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = refresh_counters(h);
+    if (rc != NFAGG_OK) return rc;
+    for (int k = 0; k < 8; k++) out[k] = h->h_ctr->phase[k];
     return NFAGG_OK;
 }
 

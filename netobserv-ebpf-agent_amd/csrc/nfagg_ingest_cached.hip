@@ -63,7 +63,7 @@ NF_DEV void merge_dmac(const TableView& t, uint32_t idx, uint32_t inv, uint64_t 
     if (x.dmac_lo <= lo) { amax(&t.hot[idx].dmac_lo, lo); amax(&t.cold[idx].dmac_hi, tagged(inv, (uint32_t)(mac >> 32))); }
 }
 
-template <int BLOCK, int K, bool SKETCH>
+template <int BLOCK, int K, bool SKETCH, bool TIMING = false>
 __global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, SketchView sk, const void* __restrict__ recs, uint64_t n,
                                                          uint64_t seq_base) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -78,6 +78,9 @@ __global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, SketchView
 
     const uint64_t n_tiles = (n + BLOCK - 1) / BLOCK;
     unsigned long long skipped = 0, bypassed = 0;
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, tp = 0;   // TIMING: load+hash, A, barrier, B, barrier, C, flush
+#define NF_TICK(k) do { if (TIMING) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
+    if (TIMING) tp = __builtin_readcyclecounter();
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t i = tile * BLOCK + tid;
         bool valid = i < n;
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, SketchView
             if (t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id) { valid = false; skipped++; }
         }
         const uint32_t seq32 = (uint32_t)(seq_base + i);
+        if (TIMING) { asm volatile("" :: "v"(h)); NF_TICK(0); }
         // ---- phase A: find or claim a cache entry by the 64-bit hash
         int ent = -1;
         bool creator = false;
@@ -113,7 +117,9 @@ __global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, SketchView
                 for (int k = 0; k < 5; k++) L.key[k][ent] = w[k];
             }
         }
+        NF_TICK(1);
         __syncthreads();
+        NF_TICK(2);
         // ---- phase B: verify the full key (two flows may share a 64-bit hash), fold into the entry
         if (valid && ent >= 0) {
             bool same = true;
@@ -137,7 +143,9 @@ __global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, SketchView
             if (r.smac() && L.smac_seq[ent] > seq32) atomicMin(&L.smac_seq[ent], seq32);
             if (r.dmac() && L.dmac_seq[ent] > seq32) atomicMin(&L.dmac_seq[ent], seq32);
         }
+        NF_TICK(3);
         __syncthreads();
+        NF_TICK(4);
         // ---- phase C: HBM work of this tile
         if (valid) {
             if (ent < 0) {
@@ -167,6 +175,7 @@ __global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, SketchView
                 }
             }
         }
+        if (TIMING) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); NF_TICK(5); }
         // the next tile's phase A only reads/claims h64 and writes keys of NEW entries: no barrier needed here,
         // phase B of the next tile is separated from this phase C's LDS reads by the barrier after phase A
     }
@@ -194,17 +203,23 @@ __global__ __launch_bounds__(BLOCK) void k_ingest_cached(TableView t, SketchView
             sketch_add(sk, w, L.bytes[e]);
         }
     }
+    if (TIMING) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NF_TICK(6);
+        if ((tid & 63) == 0) for (int k = 0; k < 7; k++) aadd(&t.ctr->phase[k], ph[k]);
+    }
+#undef NF_TICK
     if (skipped) aadd(&t.ctr->n_skipped, skipped);
     if (bypassed) aadd(&t.ctr->n_bypassed, bypassed);
 }
 
-template <int BLOCK, int K, bool SKETCH>
+template <int BLOCK, int K, bool SKETCH, bool TIMING = false>
 static hipError_t run_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                              int blocks_per_cu, hipStream_t s) {
     const size_t lds = sizeof(FlowCache<K>);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ingest_cached<BLOCK, K, SKETCH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ingest_cached<BLOCK, K, SKETCH, TIMING>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -213,7 +228,7 @@ static hipError_t run_cached(const TableView& t, const SketchView& sk, const voi
     uint64_t grid = 256ull * blocks_per_cu;
     if (grid > tiles) grid = tiles;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_ingest_cached<BLOCK, K, SKETCH>), dim3((unsigned)grid), dim3(BLOCK), lds, s, t, sk, d_records, n, seq_base);
+    hipLaunchKernelGGL((k_ingest_cached<BLOCK, K, SKETCH, TIMING>), dim3((unsigned)grid), dim3(BLOCK), lds, s, t, sk, d_records, n, seq_base);
     return hipGetLastError();
 }
 
@@ -228,7 +243,8 @@ hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const 
                          : run_cached<256, 256, false>(t, sk, d_records, n, seq_base, 4, s);
         case 5: return f ? run_cached<1024, 512, true>(t, sk, d_records, n, seq_base, 2, s)
                          : run_cached<1024, 512, false>(t, sk, d_records, n, seq_base, 2, s);
-        default: return f ? run_cached<1024, 1024, true>(t, sk, d_records, n, seq_base, 1, s)    // variant 0: 1 WG/CU x 120 KB
+        case 6: return run_cached<1024, 1024, false, true>(t, sk, d_records, n, seq_base, 1, s);    // diagnostics: phase timing
+        default: return f ? run_cached<1024, 1024, true>(t, sk, d_records, n, seq_base, 1, s)    // 7 (and 0 for small batches): 1 WG/CU x 120 KB
                           : run_cached<1024, 1024, false>(t, sk, d_records, n, seq_base, 1, s);
     }
 }

@@ -1,0 +1,384 @@
+// nfagg_ingest_part.hip — two-pass partitioned ingest (ingest_variant 7).
+//
+// The single-pass cached kernel (nfagg_ingest_cached.hip) folds the hot head of a
+// Zipf stream in LDS, but every record of the cold tail (40 % of configs[1]) goes to
+// the HBM table one by one: 4-5 agent-scope atomics each, and the chip retires only
+// ~24 G random atomics/s (profiles/r01_ubench_atomics.txt) — that, not HBM
+// bandwidth, bounds the kernel. Here the tail is not merged record by record:
+//
+//   pass 1  k_fold<.., false>  streams the batch once. Hot flows are folded in the
+//           workgroup's LDS flow cache exactly as before; a record whose flow gets no
+//           cache entry is SPILLED: its 32-bit index is appended to the queue of its
+//           key-hash partition (2048 partitions), staged four at a time in LDS so a
+//           spill costs one 16-byte store and a quarter of an atomic.
+//   pass 2  k_fold<.., true>   one workgroup per partition gathers the spilled
+//           records by index and folds them in ITS LDS cache. A partition holds
+//           ~1/2048 of the flows, so (almost) every flow of it gets an entry.
+//   Both passes end by merging each cache entry into the table ONCE.
+//
+// Exactness (pkg/model/flow_content.go:28-61, pkg/flow/account.go:95) is unchanged:
+// a cache entry is a partial (nfagg_device.h) carrying sequence-tagged fields, and
+// merging partials is associative and commutative. "First record" data (and the first
+// non-zero MACs) never enter the cache: an entry only tracks the smallest sequence
+// number, and the flush gathers that record again from the batch (still in HBM — the
+// caller owns it until the call returns) to publish its identity words.
+#include "nfagg_device.h"
+
+namespace nfagg {
+namespace part {
+
+constexpr int kBlock = 1024;
+constexpr int kEntries = 1024;
+constexpr int kProbe = 8;         // cache probe window
+constexpr int kStage = 4;         // staged spills per partition = one 16-byte store
+
+struct Cache {
+    uint64_t h64[kEntries];       // 0 = free, else key hash | 1
+    uint64_t key[5][kEntries];
+    uint64_t bytes[kEntries];
+    uint64_t end[kEntries];
+    uint64_t start_inv[kEntries];
+    uint64_t eth_tag[kEntries];
+    uint64_t dscp_tag[kEntries];
+    uint64_t samp_tag[kEntries];
+    uint32_t packets[kEntries];
+    uint32_t flags[kEntries];
+    uint32_t first_seq[kEntries]; // min seq32 of the records folded into the entry
+    uint32_t smac_seq[kEntries];  // min seq32 over those with a non-zero src_mac
+    uint32_t dmac_seq[kEntries];
+};
+
+struct Stage {
+    uint32_t buf[kSpillParts][kStage];
+    uint32_t cnt[kSpillParts];
+};
+
+NF_DEV uint32_t part_of(uint64_t h) { return (uint32_t)(h >> 29) & (kSpillParts - 1); }
+
+NF_DEV void cache_init(Cache& L, int tid) {
+    for (int e = tid; e < kEntries; e += kBlock) {
+        L.h64[e] = 0; L.bytes[e] = 0; L.end[e] = 0; L.start_inv[e] = 0; L.eth_tag[e] = 0; L.dscp_tag[e] = 0;
+        L.samp_tag[e] = 0; L.packets[e] = 0; L.flags[e] = 0;
+        L.first_seq[e] = 0xffffffffu; L.smac_seq[e] = 0xffffffffu; L.dmac_seq[e] = 0xffffffffu;
+    }
+}
+
+// phase A: find or claim the entry of hash h (the creator writes the key); -1 = window full
+NF_DEV int cache_claim(Cache& L, uint64_t h, const uint64_t w[5]) {
+    const uint64_t hk = h | 1ull;
+    uint32_t e = (uint32_t)(h >> 40) & (kEntries - 1);
+#pragma unroll 1
+    for (int p = 0; p < kProbe; p++) {
+        uint64_t cur = L.h64[e];
+        if (cur == 0) {
+            cur = atomicCAS((unsigned long long*)&L.h64[e], 0ull, (unsigned long long)hk);
+            if (cur == 0) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) L.key[k][e] = w[k];
+                return (int)e;
+            }
+        }
+        if (cur == hk) return (int)e;
+        e = (e + 1) & (kEntries - 1);
+    }
+    return -1;
+}
+
+// phase B (after a barrier): full-key check, then AccumulateBase into the entry
+NF_DEV int cache_fold(Cache& L, int ent, const Rec& r, const uint64_t w[5], uint32_t seq32) {
+    bool same = true;
+#pragma unroll
+    for (int k = 0; k < 5; k++) same &= (L.key[k][ent] == w[k]);
+    if (!same) return -1;         // two flows with one 64-bit hash: the later one is spilled / merged directly
+    if (r.bytes()) atomicAdd((unsigned long long*)&L.bytes[ent], (unsigned long long)r.bytes());
+    if (r.packets()) atomicAdd(&L.packets[ent], r.packets());
+    if (r.flags() & ~L.flags[ent]) atomicOr(&L.flags[ent], r.flags());
+    if (r.end() > L.end[ent]) atomicMax((unsigned long long*)&L.end[ent], (unsigned long long)r.end());
+    if (r.start() && ~r.start() > L.start_inv[ent])
+        atomicMax((unsigned long long*)&L.start_inv[ent], (unsigned long long)~r.start());
+    const uint64_t s1 = (uint64_t)seq32 + 1;
+    if (r.eth()) atomicMax((unsigned long long*)&L.eth_tag[ent], (unsigned long long)((s1 << 16) | r.eth()));
+    if (r.dscp()) atomicMax((unsigned long long*)&L.dscp_tag[ent], (unsigned long long)((s1 << 8) | r.dscp()));
+    if (r.sampling()) atomicMax((unsigned long long*)&L.samp_tag[ent], (unsigned long long)((s1 << 32) | r.sampling()));
+    if (L.first_seq[ent] > seq32) atomicMin(&L.first_seq[ent], seq32);
+    if (r.smac() && L.smac_seq[ent] > seq32) atomicMin(&L.smac_seq[ent], seq32);
+    if (r.dmac() && L.dmac_seq[ent] > seq32) atomicMin(&L.dmac_seq[ent], seq32);
+    return ent;
+}
+
+// Overflow list: spills that found their partition queue (or staging group) full.
+// Sized by the API for the worst case; pass 3 merges its records one by one.
+NF_DEV void overflow_push(const SpillView& q, uint4 v) {
+    const uint32_t at = aadd(q.ovf_tail, 4u);
+    if (at + 4 <= q.ovf_cap) *reinterpret_cast<uint4*>(q.ovf + at) = v;
+    else atomicExch(q.error, 5u);
+}
+
+NF_DEV uint4 rec_chunk(const void* recs, uint64_t i, int k) {
+    return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + i * kRecordBytes)[k];
+}
+
+// Merge cache entry e into the table: one partial per entry. The identity dwords of
+// the entry's earliest record (and its earliest non-zero MACs) are gathered from the batch.
+template <bool SKETCH>
+NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L, int e, const void* recs, uint32_t seq_base32) {
+    if (L.h64[e] == 0) return;
+    uint64_t w[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
+    const uint64_t h = key_hash(w);
+    Hints x;
+    uint32_t idx = probe_home(t, w, h, x);
+    if (idx == kNoSlot) {
+        idx = find_or_claim(t, w, h);
+        if (idx == kNoSlot) return;
+        load_hints(&t.hot[idx], x);
+    }
+    Partial p;
+    p.bytes = L.bytes[e]; p.end = L.end[e]; p.start_inv = L.start_inv[e];
+    p.packets = L.packets[e]; p.flags = L.flags[e];
+    p.eth_tag = L.eth_tag[e]; p.dscp_tag = L.dscp_tag[e]; p.samp_tag = L.samp_tag[e];
+    const uint32_t fs = L.first_seq[e], ss = L.smac_seq[e], ds = L.dmac_seq[e];
+    p.first_inv = ~fs;
+#pragma unroll
+    for (int k = 0; k < 15; k++) p.ident[k] = 0;
+    if ((uint32_t)(x.id0 >> 32) <= p.first_inv) {
+        // this entry's earliest record is (so far) the flow's first: fetch its dwords 20..35
+        const uint64_t ri = (uint64_t)(fs - seq_base32);
+        const uint4 c5 = rec_chunk(recs, ri, 5), c6 = rec_chunk(recs, ri, 6), c7 = rec_chunk(recs, ri, 7), c8 = rec_chunk(recs, ri, 8);
+        p.ident[0] = c5.y; p.ident[1] = c5.z; p.ident[2] = c5.w;
+        p.ident[3] = c6.x; p.ident[4] = c6.y; p.ident[5] = c6.z & 0x0000ffffu; p.ident[6] = c6.w;    // [5] = dword 26: pad2 cleared
+        p.ident[7] = c7.x; p.ident[8] = c7.y; p.ident[9] = c7.z; p.ident[10] = c7.w;
+        p.ident[11] = c8.x; p.ident[12] = c8.y; p.ident[13] = c8.z; p.ident[14] = 0;                 // dword 35: pad4 cleared
+    } else {
+        p.first_inv = 0;   // tagged(0, 0) = 0 never wins: merge_partial skips the identity words
+    }
+    p.smac_inv = 0; p.dmac_inv = 0; p.smac = 0; p.dmac = 0;
+    if (ss != 0xffffffffu && (uint32_t)(x.smac_lo >> 32) <= ~ss) {
+        const uint64_t ri = (uint64_t)(ss - seq_base32);
+        const uint4 c4 = rec_chunk(recs, ri, 4);
+        p.smac = (uint64_t)c4.z | ((uint64_t)(c4.w & 0xffffu) << 32);
+        p.smac_inv = ~ss;
+    }
+    if (ds != 0xffffffffu && (uint32_t)(x.dmac_lo >> 32) <= ~ds) {
+        const uint64_t ri = (uint64_t)(ds - seq_base32);
+        const uint4 c4 = rec_chunk(recs, ri, 4), c5 = rec_chunk(recs, ri, 5);
+        p.dmac = (uint64_t)(c4.w >> 16) | ((uint64_t)c5.x << 16);
+        p.dmac_inv = ~ds;
+    }
+    merge_partial(t, idx, p, x);
+    if (SKETCH) sketch_add(sk, w, p.bytes);
+}
+
+// QUEUE == false: pass 1 over records[0..n). QUEUE == true: pass 2, workgroup b folds
+// the records whose indices pass 1 queued for partition b.
+template <bool SKETCH, bool QUEUE, bool TIMING>
+__global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
+                                                 uint64_t n, uint64_t seq_base) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    Cache& L = *reinterpret_cast<Cache*>(lds_raw);
+    Stage& S = *reinterpret_cast<Stage*>(lds_raw + sizeof(Cache));   // pass 1 only
+    const int tid = threadIdx.x;
+    const uint32_t seq_base32 = (uint32_t)seq_base;
+    uint64_t count = n;
+    const uint32_t* my_queue = nullptr;
+    if (QUEUE) {
+        const uint32_t tail = q.qtail[blockIdx.x];                    // written by pass 1 (previous kernel)
+        count = tail < q.qcap ? tail : q.qcap;
+        if (count == 0) return;
+        my_queue = q.queue + (uint64_t)blockIdx.x * q.qcap;
+    }
+    cache_init(L, tid);
+    if (!QUEUE) for (int p = tid; p < kSpillParts; p += kBlock) S.cnt[p] = 0;
+    __syncthreads();
+    if (QUEUE && tid == 0) q.qtail[blockIdx.x] = 0;                    // every lane has read it: ready for the next batch
+
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, tp = 0;          // TIMING: load+hash, A, barrier, B, barrier, C, flush
+#define NF_TICK(k) do { if (TIMING) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
+    if (TIMING) tp = __builtin_readcyclecounter();
+    const uint64_t n_tiles = (count + kBlock - 1) / kBlock;
+    const uint64_t tile0 = QUEUE ? 0 : blockIdx.x, tile_step = QUEUE ? 1 : gridDim.x;
+    unsigned long long skipped = 0, spilled = 0, direct = 0;
+    // pass 1 drain state: this lane serves partitions tid and tid + kBlock. A drained group is stored one tile
+    // later, when the reservation (a returning atomic) has long arrived: no HBM round trip inside a tile.
+    constexpr int kMine = kSpillParts / kBlock;
+    uint4 pend_v[kMine];
+    uint32_t pend_at[kMine];
+    bool pend[kMine];
+#pragma unroll
+    for (int k = 0; k < kMine; k++) { pend[k] = false; pend_at[k] = 0; pend_v[k] = make_uint4(0, 0, 0, 0); }
+    uint32_t carry = 0xffffffffu, carry_p = 0;                         // a spill that found its group full: retried next tile
+    for (uint64_t tile = tile0; tile < n_tiles; tile += tile_step) {
+        const uint64_t pos = tile * kBlock + tid;
+        bool valid = pos < count;
+        uint64_t i = pos;
+        if (QUEUE) {
+            const uint32_t qi = valid ? my_queue[pos] : 0xffffffffu;
+            valid = qi != 0xffffffffu;                                // padding of partially filled 16-byte groups
+            i = qi;
+        }
+        Rec r;
+        uint64_t w[5];
+        uint64_t h = 0;
+        if (valid) {
+            load_record(recs, i, r);
+            r.canonicalize();
+            r.key_words(w);
+            h = key_hash(w);
+            if (!QUEUE && t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id) { valid = false; skipped++; }
+        }
+        const uint32_t seq32 = seq_base32 + (uint32_t)i;
+        if (TIMING) { asm volatile("" :: "v"(h)); NF_TICK(0); }
+        int ent = valid ? cache_claim(L, h, w) : -1;
+        NF_TICK(1);
+        __syncthreads();
+        NF_TICK(2);
+        if (valid && ent >= 0) ent = cache_fold(L, ent, r, w, seq32);
+        if (!QUEUE) {
+#pragma unroll
+            for (int k = 0; k < kMine; k++) {
+                const int p = tid + k * kBlock;
+                if (pend[k]) {
+                    if (pend_at[k] + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)p * q.qcap + pend_at[k]) = pend_v[k];
+                    else overflow_push(q, pend_v[k]);                 // partition queue full (adversarial skew)
+                    pend[k] = false;
+                }
+                if (S.cnt[p] >= (uint32_t)kStage) {
+                    pend_v[k] = *reinterpret_cast<const uint4*>(S.buf[p]);
+                    S.cnt[p] = 0;
+                    pend_at[k] = aadd(&q.qtail[p], (uint32_t)kStage);
+                    pend[k] = true;
+                }
+            }
+        }
+        NF_TICK(3);
+        __syncthreads();
+        NF_TICK(4);
+        if (!QUEUE) {
+            if (carry != 0xffffffffu) {
+                const uint32_t at = atomicAdd(&S.cnt[carry_p], 1u);
+                if (at < (uint32_t)kStage) S.buf[carry_p][at] = carry;
+                else overflow_push(q, make_uint4(carry, 0xffffffffu, 0xffffffffu, 0xffffffffu));   // full twice in a row: very rare
+                carry = 0xffffffffu;
+            }
+            if (valid && ent < 0) {
+                const uint32_t p = part_of(h);
+                const uint32_t at = atomicAdd(&S.cnt[p], 1u);
+                spilled++;
+                if (at < (uint32_t)kStage) S.buf[p][at] = (uint32_t)i;
+                else { carry = (uint32_t)i; carry_p = p; }
+            }
+        } else if (valid && ent < 0) {
+            // no cache entry even here (probe window full): merge the record itself
+            direct++;
+            Partial p;
+            partial_from_record(r, seq_base + i, p);
+            upsert_partial(t, w, h, p);
+            if (SKETCH) sketch_add(sk, w, r.bytes());
+        }
+        if (TIMING) { if (QUEUE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); NF_TICK(5); }
+        // next tile: phase A touches only h64/key of NEW entries, the barrier after it orders phase B/C as before;
+        // staging appends of this tile are drained after the next tile's first barrier
+    }
+    __syncthreads();
+    if (!QUEUE) {
+        if (carry != 0xffffffffu) {
+            const uint32_t at = atomicAdd(&S.cnt[carry_p], 1u);
+            if (at < (uint32_t)kStage) S.buf[carry_p][at] = carry;
+            else overflow_push(q, make_uint4(carry, 0xffffffffu, 0xffffffffu, 0xffffffffu));
+        }
+        __syncthreads();
+        // pending groups, then whatever is staged (padded with invalid indices)
+#pragma unroll
+        for (int k = 0; k < kMine; k++) {
+            const int p = tid + k * kBlock;
+            if (pend[k]) {
+                if (pend_at[k] + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)p * q.qcap + pend_at[k]) = pend_v[k];
+                else overflow_push(q, pend_v[k]);
+            }
+            uint32_t c = S.cnt[p];
+            if (c > (uint32_t)kStage) c = kStage;
+            if (c) {
+                const uint32_t at = aadd(&q.qtail[p], (uint32_t)kStage);
+                uint4 v = *reinterpret_cast<const uint4*>(S.buf[p]);
+                if (c < 2) v.y = 0xffffffffu;
+                if (c < 3) v.z = 0xffffffffu;
+                if (c < 4) v.w = 0xffffffffu;
+                if (at + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)p * q.qcap + at) = v;
+                else overflow_push(q, v);
+            }
+        }
+    }
+    for (int e = tid; e < kEntries; e += kBlock) cache_flush_entry<SKETCH>(t, sk, L, e, recs, seq_base32);
+    if (TIMING) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NF_TICK(6);
+        if ((tid & 63) == 0) for (int k = 0; k < 7; k++) aadd(&t.ctr->phase[k], ph[k]);
+    }
+#undef NF_TICK
+    if (skipped) aadd(&t.ctr->n_skipped, skipped);
+    if (spilled) aadd(&t.ctr->n_bypassed, spilled);
+    if (direct) aadd(&t.ctr->pad[0], direct);
+}
+
+// pass 3: the (normally empty) overflow list, one record per lane, merged directly.
+template <bool SKETCH>
+__global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs, uint64_t seq_base) {
+    uint32_t count = *q.ovf_tail;
+    if (count > q.ovf_cap) count = q.ovf_cap;
+    unsigned long long direct = 0;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = q.ovf[k];
+        if (i == 0xffffffffu) continue;
+        Rec r; uint64_t w[5];
+        load_record(recs, i, r); r.canonicalize(); r.key_words(w);
+        Partial p;
+        partial_from_record(r, seq_base + i, p);
+        upsert_partial(t, w, key_hash(w), p);
+        if (SKETCH) sketch_add(sk, w, r.bytes());
+        direct++;
+    }
+    if (direct) aadd(&t.ctr->pad[0], direct);
+}
+
+template <bool SKETCH, bool T1 = false, bool T2 = false>
+static hipError_t run(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
+                      uint64_t seq_base, hipStream_t s) {
+    const size_t lds1 = sizeof(Cache) + sizeof(Stage), lds2 = sizeof(Cache);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold<SKETCH, false, T1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold<SKETCH, true, T2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const uint64_t tiles = (n + kBlock - 1) / kBlock;
+    uint64_t grid = 256;
+    if (grid > tiles) grid = tiles;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((k_fold<SKETCH, false, T1>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_fold<SKETCH, true, T2>), dim3(kSpillParts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_merge_overflow<SKETCH>), dim3(256), dim3(256), 0, s, t, sk, q, d_records, seq_base);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(q.ovf_tail, 0, sizeof(uint32_t), s);
+}
+
+}  // namespace part
+
+hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
+                              uint64_t seq_base, int variant, hipStream_t s) {
+    if (!q.queue || !q.qtail || !q.ovf || !q.ovf_tail || q.qcap < 4 || (q.qcap & 3u)) return hipErrorInvalidValue;
+    if (variant == 8) return part::run<false, true, false>(t, sk, q, d_records, n, seq_base, s);   // diagnostics: pass-1 phase timing
+    if (variant == 9) return part::run<false, false, true>(t, sk, q, d_records, n, seq_base, s);   // diagnostics: pass-2 phase timing
+    return sk.flags ? part::run<true>(t, sk, q, d_records, n, seq_base, s) : part::run<false>(t, sk, q, d_records, n, seq_base, s);
+}
+
+}  // namespace nfagg

@@ -88,6 +88,19 @@ struct DevCounters {
     unsigned int error;            // non-zero: a kernel bailed out (probe overflow)
     unsigned int max_probe;
     unsigned long long pad[2];
+    unsigned long long phase[8];   // ingest_variant 6 only: per-phase wave-cycle sums (diagnostics)
+};
+
+// Two-pass partitioned ingest (nfagg_ingest_part.hip): per-partition queues of spilled record indices.
+constexpr int kSpillParts = 2048;
+struct SpillView {
+    uint32_t* queue;               // kSpillParts x qcap record indices (0xffffffff = padding)
+    uint32_t* qtail;               // kSpillParts reserved-entry counters; zero between launches
+    uint32_t qcap;                 // entries per partition, multiple of 4
+    uint32_t* ovf;                 // overflow list (partition queue or staging group full), groups of 4
+    uint32_t* ovf_tail;
+    uint32_t ovf_cap;
+    unsigned int* error;           // = &DevCounters.error
 };
 
 struct TableView {
@@ -98,6 +111,7 @@ struct TableView {
     DevCounters* ctr;
     uint64_t mask;                 // slots - 1
     uint32_t n_shards, shard_id;
+    SpillView spill;               // set by the API for ingest_variant 7
 };
 
 struct SketchView {
@@ -114,6 +128,9 @@ struct SketchView {
 hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                          int mode, int variant, hipStream_t s);
 bool ingest_fuses_sketches(int mode, int variant);
+bool ingest_needs_spill(int mode, int variant);
+hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
+                              uint64_t seq_base, int variant, hipStream_t s);
 // Kernel-dedup mode (nfagg_dedup.hip): two passes over the batch (claim + earliest interfaces, then fold).
 hipError_t launch_ingest_dedup(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
 hipError_t launch_evict_dedup(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);

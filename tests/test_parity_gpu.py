@@ -115,7 +115,7 @@ def test_evict_period(nf):
 
 # ---------------------------------------------------------------- seeded streams vs the oracle
 @pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3, 4, 5, 7, 10])
 @pytest.mark.parametrize("batch", [1 << 30, 1000, 257])
 def test_stream_parity(nf, O, variant, ingest_variant, batch):
     th = O.zipf_thresholds(3000, 1.1)
@@ -136,7 +136,7 @@ def test_config1_10k_records_1k_keys(nf, O):
     assert len(want[0][1]) == len(np.unique(recs["id"]["src_port"]))
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3, 4, 5, 7, 10])
 def test_hot_key_stream(nf, O, ingest_variant):
     """BASELINE configs[4] shape: 90 % of the records are one flow (LDS / atomic contention)."""
     th = O.zipf_thresholds(5000, 1.1)
@@ -144,7 +144,7 @@ def test_hot_key_stream(nf, O, ingest_variant):
     check_against_oracle(nf, O, recs, 1 << 16, 1 << 30, ingest_variant=ingest_variant)
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 1, 2])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 7, 10])
 def test_wraparound_and_zero_fields(nf, O, ingest_variant):
     """u64 bytes / u32 packets wrap (flow_content.go:42-43) and all-zero optional fields."""
     recs = O.gen_stream(3000, seed=9, n_keys=3, variant=1)   # ~1000 records per key, wrap values injected
@@ -153,7 +153,7 @@ def test_wraparound_and_zero_fields(nf, O, ingest_variant):
     check_against_oracle(nf, O, z, 100, 1 << 30, ingest_variant=ingest_variant)
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 2])
+@pytest.mark.parametrize("ingest_variant", [0, 2, 7, 10])
 @pytest.mark.parametrize("max_entries,batch", [(2, 1 << 30), (100, 1 << 30), (100, 333), (1, 50), (999, 4096), (3000, 1 << 30)])
 def test_evict_on_full_inside_batches(nf, O, max_entries, batch, ingest_variant):
     """account.go:85-94: the arrival of the (maxEntries+1)-th distinct key flushes what was
@@ -177,7 +177,7 @@ def test_empty_and_ragged_inputs(nf, O):
         assert list(tab.stats().evictions) == [0, 0, 1]       # closing does (:78)
     for n in (1, 63, 64, 65, 255, 256, 257, 1023, 1025, 2049):            # ragged tile tails
         recs = O.gen_stream(n, seed=n, n_keys=50, variant=1)
-        for v in (0, 2, 3):
+        for v in (0, 2, 3, 7, 10):
             check_against_oracle(nf, O, recs, 1000, 1 << 30, ingest_variant=v)
 
 
@@ -226,7 +226,7 @@ def test_small_staging_ring_many_chunks(nf, O):
     check_against_oracle(nf, O, recs, 4096, 1 << 30, staging_records=1000)
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 2])
+@pytest.mark.parametrize("ingest_variant", [0, 2, 7, 10])
 @pytest.mark.parametrize("n_shards", [2, 8])
 def test_sharded_tables_cover_the_stream(nf, O, n_shards, ingest_variant):
     """Records shard by flow-key hash; every shard folds only its own keys; the
@@ -255,3 +255,45 @@ def test_idempotent_refold_of_evicted_records(nf, O):
         tab.ingest(first)
         again = nf.sort_by_key(tab.evict())
         assert_records_equal(again, first)
+
+
+def _np_key_hash(words):
+    """DESIGN.md §5 key hash, vectorised (uint64 wrap-around arithmetic)."""
+    mul, seed = np.uint64(0x9E3779B97F4A7C15), np.uint64(0x6E66616767206B31)
+    h = np.full(len(words), seed, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for i in range(5):
+            h = (((h << np.uint64(27)) | (h >> np.uint64(37))) ^ words[:, i]) * mul
+        h ^= h >> np.uint64(33); h *= np.uint64(0xff51afd7ed558ccd)
+        h ^= h >> np.uint64(33); h *= np.uint64(0xc4ceb9fe1a85ec53)
+        h ^= h >> np.uint64(33)
+    return h
+
+
+def test_partition_skew_overflows_the_spill_queues(nf, O):
+    """Two-pass ingest, adversarial case: thousands of flows whose key hashes fall into ONE spill
+    partition. The partition queue overflows into the overflow list (third pass), staging groups
+    fill up within a tile (carry path) — the result must still be bit-exact."""
+    c = np.arange(6_000_000, dtype=np.uint64)
+    ids = np.zeros((len(c), 5), dtype=np.uint64)
+    ids[:, 0] = c * np.uint64(0x10001) + np.uint64(7)
+    ids[:, 3] = c ^ np.uint64(0xabcdef)
+    ids[:, 4] = c & np.uint64(0xffffff)                      # byte 39 stays zero
+    h = _np_key_hash(ids)
+    assert int(h[12345]) == nf.key_hash(ids[12345].tobytes())
+    sel = ids[((h >> np.uint64(29)) & np.uint64(2047)) == 7][:2500]
+    assert len(sel) == 2500
+    n = 200_000
+    th = O.zipf_thresholds(2500, 0.3)                         # nearly uniform: most flows miss the LDS caches
+    recs = O.gen_stream(n, seed=41, n_keys=2500, thresholds=th, variant=1)
+    recs["id"]["pad"] = 0                                     # variant 1 dirties byte 39; it is not part of the identity
+    raw = np.ascontiguousarray(recs["id"]).view(np.dtype((np.void, 40)))
+    _, inverse = np.unique(raw, return_inverse=True)
+    recs["id"] = sel[inverse.ravel()].view(O.FLOW_ID).ravel()
+    want = O.run_accounter(recs, 1 << 20)[0][1]
+    assert len(want) > 2400
+    with nf.FlowTable(max_entries=1 << 20, ingest_variant=10) as tab:
+        assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, n)
+        st = tab.stats()
+        assert st.records_bypassed > 2 * (2 * n // 2048 + 1024), "the stream was meant to overflow one partition queue"
+        assert_records_equal(nf.sort_by_key(tab.evict()), want)
