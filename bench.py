@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--hot-permille", type=int, default=0, help="configs[4]: share of records hitting one flow")
     ap.add_argument("--sketches", action="store_true", help="configs[2]/[3]: CM(d=4,w=2^20)+HLL(p=14), all-reduced per step when N>1")
     ap.add_argument("--variant", type=int, default=0, help="ingest kernel variant (DESIGN.md)")
+    ap.add_argument("--dedup", action="store_true", help="configs[4]: NFAGG_MODE_KERNEL_DEDUP, every flow seen on two interfaces (stream variant 2)")
     ap.add_argument("--chunk", type=int, default=0, help="records per nfagg_ingest_device call (0 = whole stream)")
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="records of the stream the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--max-entries", type=int, default=0)
@@ -81,7 +82,8 @@ def main():
     torch.cuda.synchronize()
     seed = 2 + 1000 * rank
     synth.stream_device(d_recs.data_ptr(), n, seed=seed, n_keys=keys, d_thresholds=d_th.data_ptr(),
-                        hot_permille=args.hot_permille, d_pop_index=d_pop.data_ptr() if d_pop is not None else 0)
+                        hot_permille=args.hot_permille, variant=2 if args.dedup else 0,
+                        d_pop_index=d_pop.data_ptr() if d_pop is not None else 0)
     torch.cuda.synchronize()
 
     # CACHE_MAX_FLOWS. A batch is folded by ONE launch when live + batch <= max_entries (no record of it can
@@ -96,6 +98,7 @@ def main():
         ext = [cm_t[0].data_ptr(), cm_t[1].data_ptr(), hll_t[0].data_ptr(), hll_t[1].data_ptr()]
         torch.cuda.synchronize()
     tab = nf.FlowTable(max_entries=max_entries, device=local_rank, sketches=sk_flags, profile=True,
+                       mode=nf.MODE_KERNEL_DEDUP if args.dedup else nf.MODE_ACCOUNTER,
                        ingest_variant=args.variant, n_shards=world, shard_id=rank, ext_sketch=ext)
     d_out = torch.empty(keys * 144 + 16, dtype=torch.uint8, device="cuda")
     chunk = args.chunk or n
@@ -156,15 +159,20 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {
-                "workload": ("configs[1]: %dM-record Zipf(%.1f) stream, %dk unique flows per GPU, hash-aggregate%s, device-resident input"
-                             % (n // 1_000_000, args.zipf, keys // 1000, "+CM(d=4,w=2^20)+HLL(p=14)" if args.sketches else " only")),
+                "workload": ("configs[%d]: %dM-record Zipf(%.1f) stream, %dk unique flows per GPU, hash-aggregate%s%s, device-resident input"
+                             % (4 if args.dedup else (2 if args.sketches else 1), n // 1_000_000, args.zipf, keys // 1000,
+                                "+CM(d=4,w=2^20)+HLL(p=14)" if args.sketches else " only",
+                                ", kernel-dedup merge on" if args.dedup else "")),
                 "records_per_gpu_per_step": n, "unique_flows_per_gpu": keys, "hot_permille": args.hot_permille,
                 "parallelism": "key-hash shards x%d" % world, "ingest_variant": args.variant,
                 "evictions_per_step": 1, "evicted_flows_per_step": flows_total,
                 "evictions_per_s": round(steps / dt, 3), "evicted_flows_per_s": round(flows_total * steps / dt, 1),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_ingest (hash-insert/fold)",
+                "bound": "hbm",
+                "kernel": ("k_dedup_claim + k_dedup_fold (one ingest call)" if args.dedup else
+                           "part::k_fold pass 1 + pass 2 (+ k_merge_overflow) = one hash-insert/fold call" if args.variant == 0 else
+                           "ingest variant %d" % args.variant),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "alg_bytes_per_record": ALG_BYTES_INGEST, "records_per_launch": int(recs_per_launch),
@@ -175,13 +183,28 @@ def main():
                 "sketch_launch_ms": round(st.sketch_kernel_ms / max(st.sketch_launches, 1), 4) if st.sketch_launches else None,
             },
         }
+        # ---- HBM traffic of one ingest call, from rocprofv3 PMC passes of this same command line
+        # (tools/profile_bench.sh + tools/summarize_prof.py -> profiles/<tag>_traffic.json; FETCH_SIZE/WRITE_SIZE
+        # calibrated on known byte counts in the same session). Reported only for the workload it was measured on.
+        import glob
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+            try:
+                tj = json.load(open(tf))
+            except Exception:
+                continue
+            if tj.get("workload") == out["config"]["workload"] and tj.get("records_per_call") == int(recs_per_launch) \
+                    and args.variant == 0 and ingest_ms > 0:
+                out["roofline"]["traffic"] = round(tj["traffic_bytes_per_call"] / (ingest_ms * 1e-3) / 1e9, 1)
+                out["roofline"]["traffic_bytes_per_launch"] = int(tj["traffic_bytes_per_call"])
+                out["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
+                break
         # ---- CPU baseline: the oracle (C restatement of pkg/flow.Accounter), 1 core, bounded sample
         if args.cpu_sample > 0:
             from oracle import oracle as O
             O.build()
             m = min(args.cpu_sample, n)
             sample = d_recs[: m * 144].cpu().numpy()
-            acc = O.Accounter(max_entries)
+            acc = O.Accounter(max_entries, 1 if args.dedup else 0)
             t1 = time.perf_counter()
             consumed = acc.ingest(sample)
             ev = acc.evict()

@@ -114,6 +114,17 @@ NF_DEV void overflow_push(const SpillView& q, uint4 v) {
     else atomicExch(q.error, 5u);
 }
 
+// The fold loops need dwords 0..27 of a record only (key, counters, MACs, sampling, dscp):
+// identity dwords are gathered at flush time. Seven 16-byte loads instead of nine.
+NF_DEV void load_record_head(const void* base, uint64_t i, Rec& r) {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + i * kRecordBytes);
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const uint4 v = p[k];
+        r.d[4 * k] = v.x; r.d[4 * k + 1] = v.y; r.d[4 * k + 2] = v.z; r.d[4 * k + 3] = v.w;
+    }
+}
+
 NF_DEV uint4 rec_chunk(const void* recs, uint64_t i, int k) {
     return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + i * kRecordBytes)[k];
 }
@@ -208,20 +219,38 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
 #pragma unroll
     for (int k = 0; k < kMine; k++) { pend[k] = false; pend_at[k] = 0; pend_v[k] = make_uint4(0, 0, 0, 0); }
     uint32_t carry = 0xffffffffu, carry_p = 0;                         // a spill that found its group full: retried next tile
-    for (uint64_t tile = tile0; tile < n_tiles; tile += tile_step) {
-        const uint64_t pos = tile * kBlock + tid;
-        bool valid = pos < count;
-        uint64_t i = pos;
+    // Software pipeline: the records of tile k+1 are requested before tile k is folded (and in pass 2 the
+    // queue entries of tile k+2 before that), so no HBM latency is exposed inside a tile. Loads are
+    // unconditional on a clamped index; `valid` only gates the fold.
+    bool valid; uint64_t i; Rec r;
+    uint32_t qi_next = 0xffffffffu;
+    {
+        const uint64_t pos = tile0 * kBlock + tid;
+        valid = pos < count; i = valid ? pos : 0;
         if (QUEUE) {
             const uint32_t qi = valid ? my_queue[pos] : 0xffffffffu;
-            valid = qi != 0xffffffffu;                                // padding of partially filled 16-byte groups
-            i = qi;
+            valid = qi != 0xffffffffu; i = valid ? qi : 0;            // 0xffffffff = padding of a partial group
+            const uint64_t p1 = pos + kBlock;
+            if (p1 < count) qi_next = my_queue[p1];
         }
-        Rec r;
+        load_record_head(recs, i, r);
+    }
+    for (uint64_t tile = tile0; tile < n_tiles; tile += tile_step) {
+        bool valid_n = false; uint64_t i_n = 0; Rec r_n; uint32_t qi_nn = 0xffffffffu;
+        {
+            const uint64_t pos = (tile + tile_step) * kBlock + tid;
+            if (QUEUE) {
+                valid_n = qi_next != 0xffffffffu; i_n = valid_n ? qi_next : 0;
+                const uint64_t p2 = pos + kBlock;
+                if (p2 < count) qi_nn = my_queue[p2];
+            } else {
+                valid_n = pos < count; i_n = valid_n ? pos : 0;
+            }
+            load_record_head(recs, i_n, r_n);
+        }
         uint64_t w[5];
         uint64_t h = 0;
         if (valid) {
-            load_record(recs, i, r);
             r.canonicalize();
             r.key_words(w);
             h = key_hash(w);
@@ -269,14 +298,20 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
                 else { carry = (uint32_t)i; carry_p = p; }
             }
         } else if (valid && ent < 0) {
-            // no cache entry even here (probe window full): merge the record itself
+            // no cache entry even here (probe window full): merge the record itself (all 144 bytes needed)
             direct++;
+            Rec full;
+            load_record(recs, i, full);
+            full.canonicalize();
             Partial p;
-            partial_from_record(r, seq_base + i, p);
+            partial_from_record(full, seq_base + i, p);
             upsert_partial(t, w, h, p);
-            if (SKETCH) sketch_add(sk, w, r.bytes());
+            if (SKETCH) sketch_add(sk, w, full.bytes());
         }
-        if (TIMING) { if (QUEUE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); NF_TICK(5); }
+        if (TIMING) NF_TICK(5);
+        valid = valid_n; i = i_n; qi_next = qi_nn;
+#pragma unroll
+        for (int k = 0; k < 28; k++) r.d[k] = r_n.d[k];
         // next tile: phase A touches only h64/key of NEW entries, the barrier after it orders phase B/C as before;
         // staging appends of this tile are drained after the next tile's first barrier
     }

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void k_synth(uint4* __restrict__ out, uint64_t
         R36 r;
         bench_record(r, i, j);
         if (variant == 1) scramble(r, seed, j);
+        if (variant == 2) { put32(r, M + 44, (uint32_t)(2 + (j & 1))); put8(r, M + 56, (uint32_t)((j >> 1) & 1)); }  // configs[4]: two interfaces, both directions
         uint4* o = out + t * 9;
 #pragma unroll
         for (int k = 0; k < 9; k++) o[k] = make_uint4(r.d[4 * k], r.d[4 * k + 1], r.d[4 * k + 2], r.d[4 * k + 3]);
@@ -190,6 +191,7 @@ void nfagg_synth_stream_host(void* out, uint64_t n, uint64_t j0, uint64_t seed, 
         R36 r;
         bench_record(r, i, j);
         if (variant == 1) scramble(r, seed, j);
+        if (variant == 2) { put32(r, M + 44, (uint32_t)(2 + (j & 1))); put8(r, M + 56, (uint32_t)((j >> 1) & 1)); }  // configs[4]: two interfaces, both directions
         memcpy((char*)out + t * 144, r.d, 144);
     }
 }

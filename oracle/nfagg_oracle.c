@@ -529,5 +529,9 @@ void orc_gen_stream(uint64_t seed, uint64_t j0, size_t n, uint64_t n_keys,
         if (pop_index) i = pop_index[i];   /* rank -> population member (sharded populations) */
         orc_bench_record(i, j, &r[t]);
         if (variant == 1) variant1_scramble(seed, j, &r[t]);
+        if (variant == 2) {   /* configs[4]: every flow is seen on two interfaces, in both directions */
+            r[t].metrics.if_index_first_seen = (uint32_t)(2 + (j & 1));
+            r[t].metrics.direction_first_seen = (uint8_t)((j >> 1) & 1);
+        }
     }
 }

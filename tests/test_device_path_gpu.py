@@ -32,7 +32,7 @@ def test_device_generator_matches_host_generator(nf, O, torch):
     synth = nf.synth
     th = synth.zipf_thresholds(5000, 1.1)
     pop = synth.shard_population(5000, 4, 2)
-    for kw in (dict(variant=0), dict(variant=1, hot_permille=900), dict(variant=1, pop_index=pop)):
+    for kw in (dict(variant=0), dict(variant=1, hot_permille=900), dict(variant=1, pop_index=pop), dict(variant=2, hot_permille=900)):
         d = dev_stream(torch, synth, 20000, j0=123, seed=9, n_keys=5000, thresholds=th, **dict(kw))
         h = O.gen_stream(20000, j0=123, seed=9, n_keys=5000, thresholds=th, **kw)
         assert d.cpu().numpy().tobytes() == h.tobytes(), kw

@@ -1,17 +1,24 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run from the repo root via gpurun).
-# 1) kernel-trace + stats  2) PMC passes (each in its own run, no other trace domains).
+# 1) kernel-trace + stats  2) PMC passes (each in its own run, no other trace domains)
+# 3) the same FETCH_SIZE / WRITE_SIZE passes over tools/pmc_calib (known byte counts) for calibration.
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="${BENCH_ARGS:---steps 3 --warmup 1 --cpu-sample 0}"
+PMC_ARGS="${PMC_BENCH_ARGS:---steps 1 --warmup 0 --cpu-sample 0}"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py $ARGS > $OUT/trace_bench.json 2> $OUT/trace_err.txt
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   tag=$(echo $c | tr ' ' '_' | cut -c1-24)
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$tag -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/pmc_${tag}_bench.json 2> $OUT/pmc_${tag}_err.txt
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$tag -- python $R/bench.py $PMC_ARGS > $OUT/pmc_${tag}_bench.json 2> $OUT/pmc_${tag}_err.txt
 done
+if [ -x $R/tools/pmc_calib ]; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/calib_$c -- $R/tools/pmc_calib > $OUT/calib_${c}_out.txt 2> $OUT/calib_${c}_err.txt
+  done
+fi
 cd $R
-find $OUT -name "*.csv" | head -40
+find $OUT -name "*.csv" | wc -l

@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/prof (written by tools/profile_bench.sh on the GPU box) into
-profiles/<tag>_*: the rocprofv3 kernel-stats CSV as is, and one markdown table with the
-per-launch PMC averages of the nfagg kernels."""
+profiles/<tag>_*: the rocprofv3 kernel-stats CSV as is, one markdown table with the
+per-launch PMC averages of the nfagg kernels, and <tag>_traffic.json — HBM bytes per
+ingest call from FETCH_SIZE/WRITE_SIZE, corrected with the factors measured in the SAME
+session on tools/pmc_calib (kernels with exactly known byte counts in the ingest path's
+access patterns), as MI355X_MICROARCH.md §HBM prescribes."""
 import collections
 import csv
 import glob
+import json
 import os
 import shutil
 import sys
@@ -17,25 +21,70 @@ if ks:
     shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
 for j in glob.glob(f"{src}/trace_bench.json"):
     shutil.copy(j, f"profiles/{tag}_bench_under_rocprof.json")
-rows = []
+
+
+def collect(d, want=None):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            agg[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return agg
+
+
+rows, per_kernel = [], collections.defaultdict(dict)
 for d in sorted(glob.glob(f"{src}/pmc_*")):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
-        agg = collections.defaultdict(lambda: collections.defaultdict(list))
-        for row in csv.DictReader(open(f)):
-            agg[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-        for k, v in agg.items():
-            if "nfagg" not in k:
-                continue
-            name = k.split("(")[0].replace("void ", "")
-            for c, x in v.items():
-                rows.append((name, c, len(x), sum(x) / len(x)))
+    for k, v in collect(d).items():
+        if "nfagg" not in k:
+            continue
+        name = k.split("(")[0].replace("void ", "")
+        for c, x in v.items():
+            rows.append((name, c, len(x), sum(x) / len(x)))
+            per_kernel[name][c] = (len(x), sum(x))
+# calibration: known bytes / counter KiB
+KNOWN = 30000000 * 144
+calib = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for k, v in collect(f"{src}/calib_{c}").items():
+        name = k.split("(")[0].replace("void ", "")
+        if c in v and sum(v[c]) > 0:
+            calib[(name, c)] = KNOWN / (sum(v[c]) / len(v[c]) * 1024.0)
 with open(f"profiles/{tag}_pmc_summary.md", "w") as o:
     o.write(f"# rocprofv3 PMC averages per launch ({tag})\n\n")
     o.write("Collected by tools/profile_bench.sh: one `rocprofv3 --pmc <counters>` run per counter group, `bench.py --steps 1 --warmup 0`.\n")
-    o.write("FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them (see DESIGN.md for the gfx950 correction).\n\n")
+    o.write("FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them; calibration factors below.\n\n")
     o.write("| kernel | counter | launches | average per launch |\n|---|---|---|---|\n")
     for r in rows:
         o.write(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]:.1f} |\n")
+    if calib:
+        o.write("\n## Calibration (tools/pmc_calib, 4.32 GB per kernel, same session)\n\n")
+        o.write("true bytes / (counter x 1024):\n\n| kernel | counter | factor |\n|---|---|---|\n")
+        for (k, c), f in sorted(calib.items()):
+            o.write(f"| {k} | {c} | {f:.3f} |\n")
 print(open(f"profiles/{tag}_pmc_summary.md").read())
+# traffic per ingest call = sum over the ingest kernels of (FETCH x f_read + WRITE x f_write)
+f_read = calib.get(("calib_read_records", "FETCH_SIZE"))
+f_write = calib.get(("calib_write_records", "WRITE_SIZE"))
+if f_read and f_write:
+    try:
+        bench = json.load(open(f"{src}/pmc_FETCH_SIZE_bench.json"))
+    except Exception:
+        bench = None
+    ingest = [k for k in per_kernel if any(s in k for s in ("k_fold", "k_merge_overflow", "k_ingest", "k_dedup_claim", "k_dedup_fold"))]
+    calls = max(1, bench["roofline"]["launches"]) if bench else 1
+    fetch_kib = sum(per_kernel[k].get("FETCH_SIZE", (0, 0))[1] for k in ingest)
+    write_kib = sum(per_kernel[k].get("WRITE_SIZE", (0, 0))[1] for k in ingest)
+    traffic = (fetch_kib * f_read + write_kib * f_write) * 1024.0 / calls
+    out = {
+        "tag": tag, "ingest_calls": calls, "kernels": ingest,
+        "fetch_kib_per_call": fetch_kib / calls, "write_kib_per_call": write_kib / calls,
+        "factor_read": f_read, "factor_write": f_write,
+        "traffic_bytes_per_call": traffic,
+        "workload": bench["config"]["workload"] if bench else None,
+        "records_per_call": bench["roofline"]["records_per_launch"] if bench else None,
+        "note": "FETCH_SIZE/WRITE_SIZE summed over the ingest kernels of one nfagg_ingest_device call, each multiplied by the "
+                "factor measured on tools/pmc_calib (lane-strided 144-byte record reads / 144-byte record writes).",
+    }
+    json.dump(out, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+    print(json.dumps(out, indent=1))
