@@ -25,53 +25,9 @@
 // flow, so six of the seven are side interfaces; an interface outside the earliest
 // seven arrives after six other side interfaces, each of which is in the list
 // already (from r0) or was appended — the list is full and flows.c:79 ignores it.
-#include "nfagg_device.h"
+#include "nfagg_dedup.h"
 
 namespace nfagg {
-
-constexpr uint32_t kObservedMax = 6;      // MAX_OBSERVED_INTERFACES (bpf/types.h)
-constexpr uint32_t kDirBoth = 3;          // OBSERVED_DIRECTION_BOTH
-constexpr uint32_t kTlsServerHello = 2;   // TLSTRACKER_BF_SERVER_HELLO (bpf/tls_tracker.h)
-constexpr uint32_t kMiscSslMismatch = 1;  // MISC_FLAGS_SSL_MISMATCH
-constexpr int kCand = 7;
-
-// Keep the K largest words among the best word per distinct match-key (the bits under
-// MATCH) in w[0..K). Larger word = earlier record ((~seq) in the high bits). Lock-free:
-//   * a word with my key and a value >= mine: nothing to do;
-//   * a word with my key and a smaller value: CAS it up;
-//   * otherwise replace the smallest word (ties: lowest index; empty = 0) when mine is larger.
-// Every position only ever grows, and a word is installed by a CAS on the smallest
-// position of a snapshot, so one key can never sit in two positions (if it did, both
-// installers would have seen the other's position as small as their own, which strict
-// growth only allows for two empty positions — excluded by the lowest-index rule).
-// A failed CAS means another lane made progress; nobody waits on anybody.
-template <int K, uint64_t MATCH>
-NF_DEV void topk_insert(const TableView& t, uint64_t* w, uint64_t v) {
-    for (uint32_t trip = 0; trip < kSpinLimit; trip++) {
-        // snapshot; pos/cur = the word holding my key if any, else the smallest word (lowest index on ties)
-        uint64_t cur = ald(&w[0]);
-        int pos = 0;
-        bool hit = cur != 0 && ((cur ^ v) & MATCH) == 0;
-#pragma unroll
-        for (int k = 1; k < K; k++) {
-            const uint64_t c = ald(&w[k]);
-            const bool mine = c != 0 && ((c ^ v) & MATCH) == 0;
-            if (mine || (!hit && c < cur)) { cur = c; pos = k; }
-            hit |= mine;
-        }
-        if (cur >= v) return;
-        if (acas(&w[pos], cur, v) == cur) return;
-    }
-    atomicExch(&t.ctr->error, 4u);
-}
-
-NF_DEV bool record_prologue(const TableView& t, const void* recs, uint64_t i, Rec& r, uint64_t w[5], uint64_t& h) {
-    load_record(recs, i, r);
-    r.canonicalize();
-    r.key_words(w);
-    h = key_hash(w);
-    return !(t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id);
-}
 
 // ---- pass 1: c.entries[id] lookup-or-insert; first record; earliest interfaces
 __global__ __launch_bounds__(256) void k_dedup_claim(TableView t, const void* __restrict__ recs, uint64_t n, uint64_t seq_base) {
@@ -81,27 +37,7 @@ __global__ __launch_bounds__(256) void k_dedup_claim(TableView t, const void* __
         Rec r;
         uint64_t w[5], h;
         if (!record_prologue(t, recs, i, r, w, h)) { skipped++; continue; }
-        Hints x;
-        uint32_t idx = probe_home(t, w, h, x);
-        if (idx == kNoSlot) {
-            idx = find_or_claim(t, w, h);
-            if (idx == kNoSlot) continue;
-            x.id0 = 0;
-        }
-        const uint32_t inv = ~(uint32_t)(seq_base + i);
-        const uint64_t my0 = tagged(inv, r.d[21]);
-        if (x.id0 < my0) amax(&t.hot[idx].id0, my0);
-        const uint32_t ifx = r.d[21];
-        if (ifx != 0) {
-            const uint64_t v = tagged(inv, ifx);
-            // cheap exit on possibly stale plain loads: a word that once held this interface with an
-            // earlier-or-equal record makes this record irrelevant for good (see topk_insert)
-            const uint64_t* cw = t.aux[idx].cand;
-            bool known = false;
-#pragma unroll
-            for (int k = 0; k < kCand; k++) { const uint64_t c = cw[k]; known |= ((uint32_t)c == ifx) & (c >= v); }
-            if (!known) topk_insert<kCand, 0xffffffffull>(t, t.aux[idx].cand, v);
-        }
+        dedup_claim_record(t, r, w, h, (uint32_t)(seq_base + i));
     }
     if (skipped) aadd(&t.ctr->n_skipped, skipped);
 }
@@ -114,72 +50,7 @@ __global__ __launch_bounds__(256) void k_dedup_fold(TableView t, const void* __r
         Rec r;
         uint64_t w[5], h;
         if (!record_prologue(t, recs, i, r, w, h)) continue;
-        Hints x;
-        uint32_t idx = probe_home(t, w, h, x);
-        if (idx == kNoSlot) {
-            idx = find_or_claim(t, w, h);          // pass 1 claimed it: this only walks the probe sequence
-            if (idx == kNoSlot) continue;
-            load_hints(&t.hot[idx], x);
-        }
-        SlotHot* H = &t.hot[idx];
-        SlotCold* C = &t.cold[idx];
-        SlotAux* A = &t.aux[idx];
-        const uint32_t seq32 = (uint32_t)(seq_base + i);
-        const uint32_t inv = ~seq32;
-        const uint64_t s1 = (uint64_t)seq32 + 1;
-        // id0 was resolved by pass 1 (a previous kernel): plain load is exact here
-        const uint32_t first_inv = (uint32_t)(x.id0 >> 32);
-        const uint32_t F = (uint32_t)x.id0;
-        const uint32_t ifx = r.d[21];
-        const uint32_t dirn = r.d[24] & 0xffu;
-        if (first_inv == inv) {
-            // the first record of the flow in this epoch: stored whole (account.go:95)
-            ast(&H->start_inv, r.start());                       // raw start
-            ast(&H->eth_tag, (uint64_t)r.eth());                 // raw eth_protocol
-            ast(&H->smac_lo, tagged(inv, (uint32_t)r.smac()));
-            ast(&C->smac_hi, tagged(inv, (uint32_t)(r.smac() >> 32)));
-            ast(&H->dmac_lo, tagged(inv, (uint32_t)r.dmac()));
-            ast(&C->dmac_hi, tagged(inv, (uint32_t)(r.dmac() >> 32)));
-#pragma unroll
-            for (int k = 1; k < 15; k++) ast(&C->id[k - 1], tagged(inv, r.d[21 + k]));
-        }
-        const bool counted = ifx == F;
-        if (!counted && ifx == 0) continue;                      // flows.c:126: `else if (if_index != 0)`
-        // end = r.end, by the LAST record that reaches either branch (flows.c:108,128)
-        const uint64_t e = r.end();
-        amax(&A->endl_lo, (s1 << 32) | (uint32_t)e);
-        amax(&A->endl_hi, (s1 << 32) | (uint32_t)(e >> 32));
-        uint32_t fl = r.flags();
-        if (counted) {
-            if (r.bytes()) aadd(&H->bytes, r.bytes());
-            if (r.packets()) aadd(&H->packets, r.packets());
-            fl |= ((r.d[34] >> 16) & 0xffu) << 16;               // tls_types |= (flows.c:125)
-            amax(&H->dscp_tag, (s1 << 8) | r.dscp());            // dscp = pkt->dscp (zero included)
-            amax(&H->samp_tag, (s1 << 32) | r.sampling());       // sampling = sampling
-            const uint32_t ssl = r.d[33] & 0xffffu;
-            if (ssl) {
-                amax(&A->ssl_first, tagged(inv, ssl));
-                atomicMax(&A->ssl_max, ssl);
-                atomicMax(&A->ssl_minv, 0x10000u - ssl);
-            }
-            const uint32_t types = (r.d[34] >> 16) & 0xffu;
-            const uint32_t cs = r.d[33] >> 16, ks = r.d[34] & 0xffffu;
-            if (cs && types == kTlsServerHello) amax(&A->cs_tag, (s1 << 16) | cs);
-            if (ks && types == kTlsServerHello) amax(&A->ks_tag, (s1 << 16) | ks);
-        } else {
-            // side record: remember the two earliest distinct directions of its interface
-            int pos = -1;
-#pragma unroll
-            for (int k = 0; k < kCand; k++) { const uint64_t c = A->cand[k]; if (c != 0 && (uint32_t)c == ifx) pos = k; }
-            if (pos >= 0) {
-                const uint64_t v = ((uint64_t)inv << 8) | dirn;
-                uint64_t* dw = A->dir[pos];
-                const uint64_t d0 = dw[0], d1 = dw[1];           // stale copies are lower bounds per direction
-                const bool known = (((uint32_t)d0 & 0xffu) == dirn && d0 >= v) || (((uint32_t)d1 & 0xffu) == dirn && d1 >= v);
-                if (!known) topk_insert<2, 0xffull>(t, dw, v);
-            }
-        }
-        if (fl & ~x.flags) aor(&H->flags, fl);
+        dedup_fold_record(t, r, w, h, (uint32_t)(seq_base + i));
     }
 }
 

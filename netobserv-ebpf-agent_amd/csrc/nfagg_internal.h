@@ -133,6 +133,7 @@ hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const Sp
                               uint64_t seq_base, int variant, hipStream_t s);
 // Kernel-dedup mode (nfagg_dedup.hip): two passes over the batch (claim + earliest interfaces, then fold).
 hipError_t launch_ingest_dedup(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
+hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
 hipError_t launch_evict_dedup(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);
 // Careful path, phase A: claim slots only; writes the slot index of every record.
 hipError_t launch_claim(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,

@@ -149,7 +149,10 @@ bool ingest_fuses_sketches(int mode, int variant) { return mode == 0 && variant 
 hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                          int mode, int variant, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    if (mode == 1) return launch_ingest_dedup(t, d_records, n, seq_base, s);   // NFAGG_MODE_KERNEL_DEDUP
+    if (mode == 1) {   // NFAGG_MODE_KERNEL_DEDUP: LDS-cached passes; direct per-record passes for small batches (variant 1: always, 10: never)
+        if (variant == 1 || (variant != 10 && n < kPartMinBatch)) return launch_ingest_dedup(t, d_records, n, seq_base, s);
+        return launch_ingest_dedup_cached(t, d_records, n, seq_base, s);
+    }
     // 0 (default): two-pass partitioned fold (nfagg_ingest_part.hip; 8/9 = its phase-timing builds) — batches too
     // small to amortise its extra launches take the single-pass cached kernel, which is what variant 7 always runs.
     // 3..5: other geometries of the cached kernel, 6: its phase-timing build; 1: direct; 2: per-tile LDS fold.

@@ -50,12 +50,13 @@ def check_dedup(nf, O, records, max_entries, batch, **kw):
     return want
 
 
+@pytest.mark.parametrize("ingest_variant", [1, 10])   # 1 = direct per-record passes, 10 = LDS-cached passes (0 picks by batch size)
 @pytest.mark.parametrize("style", [0, 1, 2, 3])
 @pytest.mark.parametrize("batch", [1 << 30, 1000, 257])
-def test_dedup_stream_parity(nf, O, style, batch):
+def test_dedup_stream_parity(nf, O, style, batch, ingest_variant):
     th = O.zipf_thresholds(300, 1.1)
     recs = dedup_stream(O, 40000, seed=200 + style, n_keys=300, thresholds=th, style=style)
-    want = check_dedup(nf, O, recs, 1 << 16, batch)
+    want = check_dedup(nf, O, recs, 1 << 16, batch, ingest_variant=ingest_variant)
     ev = want[0][1]
     assert len(ev) > 150
     if style in (0, 2):
@@ -76,20 +77,30 @@ def test_dedup_single_record_batches(nf, O):
     check_dedup(nf, O, recs, 1000, 1)
 
 
-def test_dedup_hot_key(nf, O):
+@pytest.mark.parametrize("ingest_variant", [1, 10])
+def test_dedup_hot_key(nf, O, ingest_variant):
     """BASELINE configs[4]: 90 % of the records are one flow, dedup on, interfaces alternating."""
     th = O.zipf_thresholds(2000, 1.1)
     recs = dedup_stream(O, 60000, seed=6, n_keys=2000, thresholds=th, hot_permille=900, style=1)
-    check_dedup(nf, O, recs, 1 << 16, 1 << 30)
+    check_dedup(nf, O, recs, 1 << 16, 1 << 30, ingest_variant=ingest_variant)
     recs = dedup_stream(O, 60000, seed=7, n_keys=2000, thresholds=th, hot_permille=900, style=2)
-    check_dedup(nf, O, recs, 1 << 16, 1 << 30)
+    check_dedup(nf, O, recs, 1 << 16, 1 << 30, ingest_variant=ingest_variant)
 
 
+def test_dedup_cached_passes_with_many_flows(nf, O):
+    """More sub-flows than the workgroup caches hold: cached and direct records of one flow must merge exactly."""
+    th = O.zipf_thresholds(30000, 1.1)
+    recs = dedup_stream(O, 300000, seed=17, n_keys=30000, thresholds=th, style=2)
+    check_dedup(nf, O, recs, 1 << 17, 100_000)             # 0: batches >= 65536 records take the cached passes
+    check_dedup(nf, O, recs, 1 << 17, 1 << 30, ingest_variant=10)
+
+
+@pytest.mark.parametrize("ingest_variant", [0, 10])
 @pytest.mark.parametrize("max_entries,batch", [(2, 1 << 30), (50, 333), (1, 50), (250, 4096)])
-def test_dedup_evict_on_full_inside_batches(nf, O, max_entries, batch):
+def test_dedup_evict_on_full_inside_batches(nf, O, max_entries, batch, ingest_variant):
     th = O.zipf_thresholds(400, 1.1)
     recs = dedup_stream(O, 12000, seed=77, n_keys=400, thresholds=th, style=2)
-    want = check_dedup(nf, O, recs, max_entries, batch)
+    want = check_dedup(nf, O, recs, max_entries, batch, ingest_variant=ingest_variant)
     assert sum(1 for r, _ in want if r == "full") >= 2
 
 
