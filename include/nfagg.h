@@ -233,7 +233,9 @@ typedef struct nfagg_config {
                                     skipped on ingest and counted in stats */
     uint32_t shard_id;
     uint32_t profile;            /* 1 -> bracket kernels with HIP events (stats) */
-    uint32_t ingest_variant;     /* 0 -> default kernel; others: see DESIGN.md */
+    uint32_t ingest_variant;     /* 0 -> default kernels (two-pass partitioned fold for batches >= 65536
+                                    records, single-pass LDS-cached kernel below); others are A/B and
+                                    diagnostic builds, see DESIGN.md §4.1b */
     /* Optional caller-owned DEVICE buffers for the sketches (so that another
      * library, e.g. RCCL via torch.distributed, can all-reduce them in place).
      * NULL -> the library allocates. Sizes as listed under NFAGG_CM_* above,
@@ -258,7 +260,8 @@ typedef struct nfagg_stats {
     uint64_t sketch_launches;
     double   sketch_kernel_ms;
     uint64_t max_probe;          /* longest probe sequence seen */
-    uint64_t records_bypassed;   /* records merged into HBM one by one (no LDS cache entry for their flow) */
+    uint64_t records_bypassed;   /* records that found no entry in a pass-1 LDS flow cache (spilled to the
+                                    second pass, or merged into HBM one by one by the single-pass kernel) */
 } nfagg_stats;
 
 uint32_t nfagg_abi_version(void);
