@@ -385,6 +385,59 @@ int nfagg_cm_query(nfagg_handle* h, int which, const uint8_t ip[16], uint64_t* e
 double nfagg_hll_estimate_from_histogram(const uint32_t* hist, uint32_t p);
 
 /* ------------------------------------------------------------------ */
+/* Export encode — replaces, for evicted records, model.NewRecord's time */
+/* and interface derivation (pkg/model/record.go:82-125), pbflow.FlowToPB */
+/* / FlowsToPB (pkg/pbflow/proto.go:18-149), proto.Marshal of each        */
+/* pbflow.Record (pkg/exporter/kafka_proto.go:53; gRPC marshalling of     */
+/* pbflow.Records) and getFlowKey (pkg/exporter/kafka_proto.go:37-47).    */
+/* ------------------------------------------------------------------ */
+
+/* One row of the interface namer as a table: what
+ * registerer.IfaceNameForIndexAndMAC (pkg/agent/interfaces_listener.go:74-80)
+ * returns for (if_index, mac), and the UDN NewIntfDirUdn (record.go:167-183)
+ * resolves for that name ("" = none). Lookup: the row with this index and MAC,
+ * else the first row with this index and has_mac == 0, else unknown_name. */
+typedef struct nfagg_intf_name {
+    uint32_t if_index;
+    uint8_t  mac[6];
+    uint8_t  has_mac;
+    uint8_t  name_len;           /* <= 16 */
+    char     name[16];
+    uint8_t  udn_len;            /* <= 63 */
+    char     udn[63];
+} nfagg_intf_name;               /* 92 bytes */
+
+typedef struct nfagg_pb_options {
+    uint32_t struct_size;        /* sizeof(nfagg_pb_options) */
+    uint32_t n_names;
+    int64_t  now_unix_ns;        /* currentTime   (account.go:103 c.clock())     */
+    uint64_t mono_now_ns;        /* monotonicCurrentTime (account.go:104)        */
+    uint8_t  agent_ip[16];       /* Record.AgentIP as a 16-byte net.IP           */
+    const nfagg_intf_name* names;/* HOST memory, n_names rows (copied per call)  */
+    char     unknown_name[16];   /* the namer's answer for an unknown interface  */
+    uint8_t  unknown_len;
+    uint8_t  pad_[7];
+} nfagg_pb_options;
+
+/* Serialise n evicted flow_record_t. Frame i = 0x0A varint(body_len[i]) body
+ * starts at frame_offsets[i]; frame_offsets[n] = *out_bytes. Any run of frames
+ * [a,b) is a serialized pbflow.Records{entries a..b-1}; the last body_len[i]
+ * bytes of frame i are the serialized pbflow.Record (the Kafka message value).
+ * kafka_keys (optional): n x 32 bytes, getFlowKey. Records carry only
+ * BpfFlowMetrics (what Accounter evicts); the per-feature messages of the
+ * MapTracer branch are not produced here. Returns NFAGG_TRUNCATED with
+ * *out_bytes = bytes needed when out_cap is too small (nothing written).
+ * All pointers HOST memory: */
+int nfagg_encode_pb(nfagg_handle* h, const void* records, size_t n, const nfagg_pb_options* opt,
+                    void* out, size_t out_cap, uint64_t* frame_offsets, uint32_t* body_len,
+                    void* kafka_keys, size_t* out_bytes);
+/* Same with d_records / d_out / d_frame_offsets / d_body_len / d_kafka_keys in
+ * DEVICE memory (16-byte aligned), e.g. straight from nfagg_evict_device. */
+int nfagg_encode_pb_device(nfagg_handle* h, const void* d_records, size_t n, const nfagg_pb_options* opt,
+                           void* d_out, size_t out_cap, uint64_t* d_frame_offsets, uint32_t* d_body_len,
+                           void* d_kafka_keys, size_t* out_bytes);
+
+/* ------------------------------------------------------------------ */
 /* Sharding, stats, sync                                                */
 /* ------------------------------------------------------------------ */
 

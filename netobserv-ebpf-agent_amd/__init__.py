@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import (OK, FULL, TRUNCATED, REASON_TIMEOUT, REASON_FULL, REASON_CLOSING, SKETCH_CM, SKETCH_HLL,
                    CM_SRC, CM_DST, HLL_SRC, HLL_DST, MODE_ACCOUNTER, MODE_KERNEL_DEDUP)
 from .records import (FLOW_ID, FLOW_METRICS, FLOW_RECORD, ADDITIONAL, DNS, PKT_DROP, NETWORK_EVENTS, XLAT, QUIC,
-                      ROLLUP_KINDS, sort_by_key)
+                      ROLLUP_KINDS, sort_by_key, INTF_NAME, intf_table)
 from .table import (FlowTable, NfaggError, key_hash, shard_of, ip_hash, hll_estimate_from_histogram, record_times)
 from .accounter import (Accounter, NewAccounter, NewRecord, Record, IntfDirUdn, NewIntfDirUdn, Metrics, NoOp, CLOSE,
                         SetInterfaceNamer, SetGlobalIP)

@@ -42,6 +42,15 @@ class Config(C.Structure):
     ]
 
 
+class PbOptions(C.Structure):
+    """nfagg_pb_options (include/nfagg.h)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_names", C.c_uint32), ("now_unix_ns", C.c_int64), ("mono_now_ns", C.c_uint64),
+        ("agent_ip", C.c_uint8 * 16), ("names", C.c_void_p), ("unknown_name", C.c_char * 16), ("unknown_len", C.c_uint8),
+        ("pad_", C.c_uint8 * 7),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("records_ingested", C.c_uint64), ("records_skipped", C.c_uint64), ("entries", C.c_uint64),
@@ -82,6 +91,8 @@ SIGNATURES = {
     "nfagg_hll_estimate": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     "nfagg_cm_query": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(C.c_uint64)]),
     "nfagg_hll_estimate_from_histogram": (C.c_double, [_vp, C.c_uint32]),
+    "nfagg_encode_pb": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
+    "nfagg_encode_pb_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
     "nfagg_shard_of": (C.c_uint32, [_vp, C.c_uint32]),
     "nfagg_shard_ids": (None, [_vp, _sz, C.c_uint32, _vp]),
     "nfagg_key_hash": (C.c_uint64, [_vp]),

@@ -12,6 +12,7 @@
 
 #include "../../include/nfagg.h"
 #include "nfagg_internal.h"
+#include "nfagg_pb.h"
 
 using namespace nfagg;
 
@@ -61,6 +62,9 @@ struct nfagg_handle {
     void* d_roll[3] = {nullptr, nullptr, nullptr};
     size_t d_roll_cap[3] = {0, 0, 0};
     uint32_t* d_hist = nullptr;
+    // protobuf encode scratch: local offsets, block sums, block bases, namer table, (host variant) records/out/offsets/lens/keys
+    void* d_pb[9] = {};
+    size_t d_pb_cap[9] = {};
     // spill queues of the two-pass ingest
     void* d_spill = nullptr;
     size_t d_spill_cap = 0;
@@ -382,6 +386,7 @@ void nfagg_destroy(nfagg_handle* h) {
     for (int k = 0; k < 3; k++) if (h->d_roll[k]) hipFree(h->d_roll[k]);
     if (h->d_hist) hipFree(h->d_hist);
     if (h->d_spill) hipFree(h->d_spill);
+    for (int k = 0; k < 9; k++) if (h->d_pb[k]) hipFree(h->d_pb[k]);
     if (h->tv.spill.qtail) hipFree(h->tv.spill.qtail);
     if (h->d_evict) hipFree(h->d_evict);
     if (h->d_slot_idx) hipFree(h->d_slot_idx);
@@ -722,6 +727,71 @@ int nfagg_stats_get(nfagg_handle* h, nfagg_stats* out) {
     h->stats.entries = h->live;
     h->stats.epoch_seq = h->epoch_seq;
     *out = h->stats;
+    return NFAGG_OK;
+}
+
+// ---- record -> protobuf (nfagg_pb.hip)
+int nfagg_encode_pb_device(nfagg_handle* h, const void* d_records, size_t n, const nfagg_pb_options* opt,
+                           void* d_out, size_t out_cap, uint64_t* d_frame_offsets, uint32_t* d_body_len,
+                           void* d_kafka_keys, size_t* out_bytes) {
+    if (!h || !opt || !out_bytes || !d_frame_offsets || (n && (!d_records || !d_body_len))) return fail(h, NFAGG_EINVAL, "null argument");
+    if (opt->struct_size != sizeof(nfagg_pb_options)) return fail(h, NFAGG_EINVAL, "nfagg_pb_options.struct_size mismatch");
+    if (opt->unknown_len > 16 || (opt->n_names && !opt->names)) return fail(h, NFAGG_EINVAL, "bad namer table");
+    if ((((uintptr_t)d_records | (uintptr_t)d_out | (uintptr_t)d_kafka_keys) & 15u) != 0) return fail(h, NFAGG_EINVAL, "device buffers must be 16-byte aligned");
+    for (uint32_t k = 0; k < opt->n_names; k++)
+        if (opt->names[k].name_len > 16 || opt->names[k].udn_len > 63) return fail(h, NFAGG_EINVAL, "namer row %u: name/udn too long", k);
+    HIP_TRY(h, hipSetDevice(h->device));
+    *out_bytes = 0;
+    if (n == 0) { HIP_TRY(h, hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), h->stream)); HIP_TRY(h, hipStreamSynchronize(h->stream)); return NFAGG_OK; }
+    const size_t blocks = (n + 1023) / 1024;
+    int rc;
+    if ((rc = ensure_bytes(h, &h->d_pb[0], &h->d_pb_cap[0], n * sizeof(uint32_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_pb[1], &h->d_pb_cap[1], blocks * sizeof(uint32_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_pb[2], &h->d_pb_cap[2], (blocks + 1) * sizeof(uint64_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_pb[3], &h->d_pb_cap[3], (size_t)(opt->n_names + 1) * sizeof(nfagg_intf_name))) != NFAGG_OK) return rc;
+    if (opt->n_names) HIP_TRY(h, hipMemcpyAsync(h->d_pb[3], opt->names, opt->n_names * sizeof(nfagg_intf_name), hipMemcpyHostToDevice, h->stream));
+    PbParams P{};
+    P.now_sec = opt->now_unix_ns / 1000000000ll; P.now_nsec = opt->now_unix_ns % 1000000000ll;
+    if (P.now_nsec < 0) { P.now_nsec += 1000000000ll; P.now_sec -= 1; }
+    P.mono_now = opt->mono_now_ns;
+    memcpy(P.agent_ip, opt->agent_ip, 16);
+    static const uint8_t v4pre[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0xff, 0xff};
+    P.agent_is_v4 = memcmp(opt->agent_ip, v4pre, 12) == 0;     // net.IP.To4() != nil (proto.go:255-261)
+    P.names = (const nfagg_intf_name*)h->d_pb[3]; P.n_names = opt->n_names;
+    P.unknown_len = opt->unknown_len; memcpy(P.unknown, opt->unknown_name, 16);
+    hipError_t e = launch_pb_size(d_records, n, P, d_body_len, (uint32_t*)h->d_pb[0], (uint32_t*)h->d_pb[1], (uint64_t*)h->d_pb[2], h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "protobuf size launch failed: %s", hipGetErrorString(e));
+    uint64_t total = 0;
+    HIP_TRY(h, hipMemcpyAsync(&total, (uint64_t*)h->d_pb[2] + blocks, sizeof total, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *out_bytes = (size_t)total;
+    if (total > out_cap || !d_out) return NFAGG_TRUNCATED;
+    e = launch_pb_write(d_records, n, P, d_body_len, (const uint32_t*)h->d_pb[0], (const uint64_t*)h->d_pb[2], d_out, d_frame_offsets, d_kafka_keys, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "protobuf encode launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NFAGG_OK;
+}
+
+int nfagg_encode_pb(nfagg_handle* h, const void* records, size_t n, const nfagg_pb_options* opt,
+                    void* out, size_t out_cap, uint64_t* frame_offsets, uint32_t* body_len,
+                    void* kafka_keys, size_t* out_bytes) {
+    if (!h || !opt || !out_bytes || !frame_offsets || (n && (!records || !body_len))) return fail(h, NFAGG_EINVAL, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure_bytes(h, &h->d_pb[4], &h->d_pb_cap[4], n * kRecordBytes + 16)) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_pb[5], &h->d_pb_cap[5], out_cap + 32)) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_pb[6], &h->d_pb_cap[6], (n + 1) * sizeof(uint64_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_pb[7], &h->d_pb_cap[7], (n + 1) * sizeof(uint32_t))) != NFAGG_OK) return rc;
+    if (kafka_keys && (rc = ensure_bytes(h, &h->d_pb[8], &h->d_pb_cap[8], n * 32 + 32)) != NFAGG_OK) return rc;
+    if (n) HIP_TRY(h, hipMemcpyAsync(h->d_pb[4], records, n * kRecordBytes, hipMemcpyHostToDevice, h->stream));
+    rc = nfagg_encode_pb_device(h, h->d_pb[4], n, opt, out ? h->d_pb[5] : nullptr, out_cap, (uint64_t*)h->d_pb[6], (uint32_t*)h->d_pb[7],
+                                kafka_keys ? h->d_pb[8] : nullptr, out_bytes);
+    if (rc != NFAGG_OK) return rc;
+    if (*out_bytes) HIP_TRY(h, hipMemcpyAsync(out, h->d_pb[5], *out_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(frame_offsets, h->d_pb[6], (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    if (n) HIP_TRY(h, hipMemcpyAsync(body_len, h->d_pb[7], n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    if (n && kafka_keys) HIP_TRY(h, hipMemcpyAsync(kafka_keys, h->d_pb[8], n * 32, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NFAGG_OK;
 }
 

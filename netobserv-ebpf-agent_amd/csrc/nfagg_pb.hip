@@ -1,0 +1,291 @@
+// nfagg_pb.hip — evicted flow_record_t -> serialized pbflow.Record, in bulk on the GPU
+// (SURVEY.md §8(f) rank 1). Replaces, for the records Accounter.evict produces,
+//   pkg/model/record.go:82-125      NewRecord (flow start/end wall-clock times, interface list)
+//   pkg/pbflow/proto.go:18-149      FlowsToPB / FlowToPB
+//   proto.Marshal of pbflow.Record  (pkg/exporter/kafka_proto.go:53, grpc marshalling of pbflow.Records)
+//   pkg/exporter/kafka_proto.go:37-47 getFlowKey
+// Output: for record i the frame `0x0A varint(len) body` at frame_offsets[i]; any run of frames
+// [a, b) is a serialized pbflow.Records{entries[a..b)} (proto/flow.proto:16-18, what GRPCProto sends,
+// split at will for GRPC_MESSAGE_MAX_FLOWS); the body alone is the Kafka message value.
+// Wire rules as google.golang.org/protobuf applies them: fields in field-number order, proto3
+// scalars omitted at zero, message fields emitted whenever FlowToPB sets the pointer (DataLink,
+// Network, Transport, both Timestamps, agent_ip, time_flow_rtt = durationpb.New(0) -> empty message),
+// oneof members emitted even at their zero value (IP.ipv4 = 0).
+//
+// Byte-granular, HBM-bound streaming work: 144 B read + ~150 B written per record. Three
+// kernels: sizes + block-local scan, scan of the block sums, encode. A wave encodes its 64
+// records into LDS at their final relative byte positions (consecutive records are contiguous
+// in the output) and then copies the packed range out with aligned 16-byte stores.
+#include "nfagg_device.h"
+#include "nfagg_pb.h"
+
+namespace nfagg {
+
+// ---- byte sinks: one counts, one writes (LDS or global bytes)
+struct CountSink {
+    uint32_t n = 0;
+    NF_DEV void put(uint8_t) { n++; }
+};
+struct ByteSink {
+    uint8_t* p;
+    NF_DEV void put(uint8_t b) { *p++ = b; }
+};
+
+NF_DEV uint32_t varint_len(uint64_t v) {
+    uint32_t n = 1;
+    while (v >= 0x80) { v >>= 7; n++; }
+    return n;
+}
+template <typename S> NF_DEV void put_varint(S& s, uint64_t v) {
+    while (v >= 0x80) { s.put((uint8_t)(v | 0x80)); v >>= 7; }
+    s.put((uint8_t)v);
+}
+template <typename S> NF_DEV void put_tag(S& s, uint32_t field, uint32_t wt) { put_varint(s, ((uint64_t)field << 3) | wt); }
+template <typename S> NF_DEV void put_uint(S& s, uint32_t field, uint64_t v) { if (v) { put_tag(s, field, 0); put_varint(s, v); } }
+NF_DEV uint32_t uint_len(uint32_t field, uint64_t v) { return v ? varint_len((uint64_t)field << 3) + varint_len(v) : 0; }
+
+// message IP { oneof { fixed32 ipv4 = 1; bytes ipv6 = 2; } } as a sub-message of `field`
+template <typename S> NF_DEV void put_ip(S& s, uint32_t field, const uint8_t ip[16], bool v6) {
+    put_tag(s, field, 2);
+    if (v6) {
+        s.put(18); s.put(0x12); s.put(16);
+        for (int k = 0; k < 16; k++) s.put(ip[k]);
+    } else {   // model.IntEncodeV4 (record.go:202-204): big-endian value of the last four bytes; fixed32 is little-endian on the wire
+        s.put(5); s.put(0x0D);
+        s.put(ip[15]); s.put(ip[14]); s.put(ip[13]); s.put(ip[12]);
+    }
+}
+
+// google.protobuf.Timestamp of currentTime.Add(-Duration(mono_now - ts)) (record.go:90-97, proto.go:61-68)
+struct TimeParts { int64_t sec, nsec; };
+NF_DEV TimeParts flow_time(const PbParams& P, uint64_t ts) {
+    const int64_t delta = (int64_t)(P.mono_now - ts);
+    const int64_t d = (int64_t)(0ull - (uint64_t)delta);
+    int64_t dsec = d / 1000000000ll, nsec = P.now_nsec + d % 1000000000ll;   // time.Time.Add
+    if (nsec >= 1000000000ll) { dsec++; nsec -= 1000000000ll; } else if (nsec < 0) { dsec--; nsec += 1000000000ll; }
+    return TimeParts{P.now_sec + dsec, nsec};
+}
+template <typename S> NF_DEV void put_time(S& s, uint32_t field, const TimeParts& t) {
+    put_tag(s, field, 2);
+    s.put((uint8_t)(uint_len(1, (uint64_t)t.sec) + uint_len(2, (uint64_t)t.nsec)));
+    put_uint(s, 1, (uint64_t)t.sec);      // int64: a negative value takes ten bytes
+    put_uint(s, 2, (uint64_t)t.nsec);
+}
+
+// interfaceNamer(ifIndex, mac) + udnsCache lookup, as a table: exact (index, MAC) row first,
+// then the row of that index that matches any MAC; no row -> the "unknown" name, no UDN.
+NF_DEV const nfagg_intf_name* lookup_name(const PbParams& P, uint32_t if_index, uint64_t mac48) {
+    const nfagg_intf_name* any = nullptr;
+    for (uint32_t k = 0; k < P.n_names; k++) {
+        const nfagg_intf_name* e = &P.names[k];
+        if (e->if_index != if_index) continue;
+        if (e->has_mac) {
+            uint64_t m = 0;
+            for (int b = 0; b < 6; b++) m = (m << 8) | e->mac[b];
+            if (m == mac48) return e;
+        } else if (!any) any = e;
+    }
+    return any;
+}
+
+// message DupMapEntry { string interface = 1; Direction direction = 2; string udn = 3; } as Record.dup_list (26)
+template <typename S> NF_DEV void put_dup(S& s, const PbParams& P, uint32_t if_index, uint64_t mac48, uint32_t dir) {
+    const nfagg_intf_name* e = lookup_name(P, if_index, mac48);
+    const char* name = e ? e->name : P.unknown;
+    const uint32_t nlen = e ? e->name_len : P.unknown_len;
+    const uint32_t ulen = e ? e->udn_len : 0;
+    const uint32_t body = (nlen ? 2 + nlen : 0) + uint_len(2, dir) + (ulen ? 2 + ulen : 0);
+    put_tag(s, 26, 2);
+    s.put((uint8_t)body);                  // < 128 by the table's field widths
+    if (nlen) { s.put(0x0A); s.put((uint8_t)nlen); for (uint32_t k = 0; k < nlen; k++) s.put((uint8_t)name[k]); }
+    put_uint(s, 2, dir);
+    if (ulen) { s.put(0x1A); s.put((uint8_t)ulen); for (uint32_t k = 0; k < ulen; k++) s.put((uint8_t)e->udn[k]); }
+}
+
+NF_DEV uint64_t mac_be(uint64_t mac_le48) {   // Rec::smac() holds byte 0 in the low bits; macToUint64 (proto.go:246-253) wants it on top
+    uint64_t v = 0;
+    for (int b = 0; b < 6; b++) v = (v << 8) | ((mac_le48 >> (8 * b)) & 0xff);
+    return v;
+}
+
+// The body of pbflow.Record for one evicted record. Same code sizes (CountSink) and writes (ByteSink).
+template <typename S> NF_DEV void encode_record(S& s, const Rec& r, const PbParams& P) {
+    const uint32_t eth = r.eth();
+    const uint32_t dirn = r.d[24] & 0xffu;
+    put_uint(s, 1, eth);
+    put_uint(s, 2, dirn);
+    put_time(s, 3, flow_time(P, r.start()));
+    put_time(s, 4, flow_time(P, r.end()));
+    const uint64_t smac = mac_be(r.smac()), dmac = mac_be(r.dmac());
+    put_tag(s, 5, 2); s.put((uint8_t)(uint_len(1, smac) + uint_len(2, dmac)));
+    put_uint(s, 1, smac); put_uint(s, 2, dmac);
+    {   // Network: addresses by eth_protocol (proto.go:125-139), dscp
+        const bool v6 = eth == 0x86DDu;    // model.IPv6Type
+        uint8_t sip[16], dip[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { sip[k] = (uint8_t)(r.d[k / 4] >> (8 * (k & 3))); dip[k] = (uint8_t)(r.d[4 + k / 4] >> (8 * (k & 3))); }
+        const uint32_t ipl = v6 ? 20 : 7;   // tag + len + body of one IP sub-message
+        put_tag(s, 6, 2); s.put((uint8_t)(2 * ipl + uint_len(3, r.dscp())));
+        put_ip(s, 1, sip, v6); put_ip(s, 2, dip, v6);
+        put_uint(s, 3, r.dscp());
+    }
+    {   // Transport
+        const uint32_t sp = r.d[8] & 0xffffu, dp = r.d[8] >> 16, pr = r.d[9] & 0xffu;
+        put_tag(s, 7, 2); s.put((uint8_t)(uint_len(1, sp) + uint_len(2, dp) + uint_len(3, pr)));
+        put_uint(s, 1, sp); put_uint(s, 2, dp); put_uint(s, 3, pr);
+    }
+    put_uint(s, 8, r.bytes());
+    put_uint(s, 9, r.packets());
+    put_ip(s, 12, P.agent_ip, !P.agent_is_v4);
+    put_uint(s, 13, r.flags());
+    put_uint(s, 14, (r.d[9] >> 8) & 0xffu);      // icmp_type
+    put_uint(s, 15, (r.d[9] >> 16) & 0xffu);     // icmp_code
+    put_tag(s, 24, 2); s.put(0);                 // time_flow_rtt = durationpb.New(0)
+    {   // dup_list = record.Interfaces (record.go:100-114)
+        const uint64_t lmac = mac_be(dirn == 0 ? r.dmac() : r.smac());
+        put_dup(s, P, r.d[21], lmac, dirn);
+        uint32_t nb = r.d[24] >> 24; if (nb > 6) nb = 6;
+        for (uint32_t k = 0; k < nb; k++) {
+            const uint32_t od = k < 4 ? (r.d[25] >> (8 * k)) & 0xffu : (r.d[26] >> (8 * (k - 4))) & 0xffu;
+            uint32_t oi = r.d[27];
+#pragma unroll
+            for (int q = 1; q < 6; q++) oi = ((uint32_t)q == k) ? r.d[27 + q] : oi;
+            put_dup(s, P, oi, lmac, od);
+        }
+    }
+    put_uint(s, 29, r.sampling());
+    put_uint(s, 33, r.d[33] & 0xffffu);          // ssl_version
+    put_uint(s, 34, (r.d[34] >> 24) & 1u);       // HasSSLMismatch (record.go:255-257)
+    put_uint(s, 35, (r.d[34] >> 16) & 0xffu);    // tls_types
+    put_uint(s, 36, r.d[33] >> 16);              // tls_cipher_suite
+    put_uint(s, 37, r.d[34] & 0xffffu);          // tls_key_share
+}
+
+constexpr int kScanBlock = 1024;
+
+// ---- kernel 1: body length per record, frame length, block-local exclusive scan of the frame lengths
+__global__ __launch_bounds__(kScanBlock) void k_pb_size(const void* __restrict__ recs, uint64_t n, PbParams P,
+                                                        uint32_t* __restrict__ body_len, uint32_t* __restrict__ local_off,
+                                                        uint32_t* __restrict__ block_sum) {
+    __shared__ uint32_t wave_tot[kScanBlock / 64];
+    const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x;
+    uint32_t frame = 0;
+    if (i < n) {
+        Rec r;
+        load_record(recs, i, r);
+        r.canonicalize();
+        CountSink c;
+        encode_record(c, r, P);
+        body_len[i] = c.n;
+        frame = 1 + varint_len(c.n) + c.n;
+    }
+    // inclusive scan inside the wave, then across the 16 waves
+    uint32_t v = frame;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+    if (lane == 63) wave_tot[wave] = v;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += wave_tot[w];
+    if (i < n) local_off[i] = base + v - frame;
+    if (threadIdx.x == kScanBlock - 1) block_sum[blockIdx.x] = base + v;
+}
+
+// ---- kernel 2: exclusive scan of the block sums (one workgroup), total in block_base[n_blocks]
+__global__ __launch_bounds__(1024) void k_pb_scan_blocks(const uint32_t* __restrict__ block_sum, uint32_t n_blocks,
+                                                         uint64_t* __restrict__ block_base) {
+    __shared__ uint64_t part[1024];
+    const uint32_t per = (n_blocks + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = (lo + per < n_blocks) ? lo + per : n_blocks;
+    uint64_t s = 0;
+    for (uint32_t k = lo; k < hi; k++) s += block_sum[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint64_t acc = 0; for (int k = 0; k < 1024; k++) { const uint64_t x = part[k]; part[k] = acc; acc += x; } block_base[n_blocks] = acc; }
+    __syncthreads();
+    uint64_t acc = part[threadIdx.x];
+    for (uint32_t k = lo; k < hi; k++) { block_base[k] = acc; acc += block_sum[k]; }
+}
+
+// ---- kernel 3: encode. One wave per 64 consecutive records.
+constexpr int kPbMaxFrame = 832;   // upper bound of one frame, multiple of 16
+
+__global__ __launch_bounds__(64) void k_pb_write(const void* __restrict__ recs, uint64_t n, PbParams P,
+                                                 const uint32_t* __restrict__ body_len, const uint32_t* __restrict__ local_off,
+                                                 const uint64_t* __restrict__ block_base, uint8_t* __restrict__ out,
+                                                 uint64_t* __restrict__ frame_offsets, uint8_t* __restrict__ kafka_keys) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const uint64_t i0 = (uint64_t)blockIdx.x * 64, i = i0 + threadIdx.x;
+    const uint64_t wave_base = block_base[i0 / kScanBlock] + local_off[i0];
+    const uint32_t shift = (uint32_t)(wave_base & 15);       // LDS image has the alignment of the destination
+    uint64_t my_off = 0; uint32_t my_len = 0;
+    if (i < n) {
+        Rec r;
+        load_record(recs, i, r);
+        r.canonicalize();
+        my_off = block_base[i / kScanBlock] + local_off[i];
+        const uint32_t bl = body_len[i];
+        my_len = 1 + varint_len(bl) + bl;
+        frame_offsets[i] = my_off;
+        ByteSink s{lds + shift + (uint32_t)(my_off - wave_base)};
+        s.put(0x0A);                                          // Records.entries = 1, length-delimited
+        put_varint(s, bl);
+        encode_record(s, r, P);
+        if (kafka_keys) {
+            // getFlowKey (kafka_proto.go:37-47): the two 16-byte addresses, the smaller one first
+            int c = 0;
+            for (int k = 0; k < 16 && c == 0; k++) {
+                const int a = (r.d[k / 4] >> (8 * (k & 3))) & 0xff, b = (r.d[4 + k / 4] >> (8 * (k & 3))) & 0xff;
+                c = a - b;
+            }
+            uint4* kk = reinterpret_cast<uint4*>(kafka_keys + i * 32);
+            const uint4 sip = make_uint4(r.d[0], r.d[1], r.d[2], r.d[3]), dip = make_uint4(r.d[4], r.d[5], r.d[6], r.d[7]);
+            kk[0] = c <= 0 ? sip : dip; kk[1] = c <= 0 ? dip : sip;
+        }
+        if (i == n - 1) frame_offsets[n] = my_off + my_len;
+    }
+    // total bytes of this wave = end of its last valid record
+    uint64_t end = my_off + my_len;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint64_t o = __shfl_xor(end, d, 64); end = o > end ? o : end; }
+    __syncthreads();
+    const uint32_t total = (uint32_t)(end - wave_base);
+    uint8_t* dst = out + (wave_base - shift);                 // 16-byte aligned
+    const uint32_t span = shift + total;                      // image bytes [shift, span)
+    for (uint32_t c = threadIdx.x * 16; c < span; c += 64 * 16) {
+        if (c >= shift && c + 16 <= span) {
+            *reinterpret_cast<uint4*>(dst + c) = *reinterpret_cast<const uint4*>(lds + c);
+        } else {
+            for (uint32_t b = c < shift ? shift : c; b < c + 16 && b < span; b++) dst[b] = lds[b];
+        }
+    }
+}
+
+hipError_t launch_pb_size(const void* d_recs, uint64_t n, const PbParams& P, uint32_t* d_body_len, uint32_t* d_local_off,
+                          uint32_t* d_block_sum, uint64_t* d_block_base, hipStream_t s) {
+    const uint32_t blocks = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_pb_size, dim3(blocks), dim3(kScanBlock), 0, s, d_recs, n, P, d_body_len, d_local_off, d_block_sum);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_pb_scan_blocks, dim3(1), dim3(1024), 0, s, d_block_sum, blocks, d_block_base);
+    return hipGetLastError();
+}
+
+hipError_t launch_pb_write(const void* d_recs, uint64_t n, const PbParams& P, const uint32_t* d_body_len, const uint32_t* d_local_off,
+                           const uint64_t* d_block_base, void* d_out, uint64_t* d_frame_offsets, void* d_kafka_keys, hipStream_t s) {
+    const size_t lds = 16 + 64 * (size_t)kPbMaxFrame;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pb_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_pb_write, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, s, d_recs, n, P, d_body_len, d_local_off, d_block_base,
+                       (uint8_t*)d_out, d_frame_offsets, (uint8_t*)d_kafka_keys);
+    return hipGetLastError();
+}
+
+}  // namespace nfagg

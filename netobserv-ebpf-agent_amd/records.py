@@ -63,3 +63,26 @@ def sort_by_key(records: np.ndarray) -> np.ndarray:
     keys = raw[:, :40]
     order = np.lexsort(tuple(keys[:, c] for c in range(39, -1, -1)))
     return records[order]
+
+
+# nfagg_intf_name (include/nfagg.h): one row of the interface namer table used by the protobuf encoder
+INTF_NAME = np.dtype({"names": ["if_index", "mac", "has_mac", "name_len", "name", "udn_len", "udn"],
+                      "formats": ["<u4", ("u1", 6), "u1", "u1", "S16", "u1", "S63"],
+                      "offsets": [0, 4, 10, 11, 12, 28, 29], "itemsize": 92})
+
+
+def intf_table(rows) -> np.ndarray:
+    """rows: iterable of (if_index, mac bytes or None, name str, udn str) -> INTF_NAME array."""
+    rows = list(rows)
+    t = np.zeros(len(rows), dtype=INTF_NAME)
+    for k, (ifx, mac, name, udn) in enumerate(rows):
+        nb, ub = name.encode(), udn.encode()
+        if len(nb) > 16 or len(ub) > 63:
+            raise ValueError("interface name <= 16 bytes, udn <= 63 bytes")
+        t[k]["if_index"] = ifx
+        if mac is not None:
+            t[k]["mac"] = np.frombuffer(bytes(mac), dtype=np.uint8)
+            t[k]["has_mac"] = 1
+        t[k]["name"], t[k]["name_len"] = nb, len(nb)
+        t[k]["udn"], t[k]["udn_len"] = ub, len(ub)
+    return t

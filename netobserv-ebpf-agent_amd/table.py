@@ -170,6 +170,55 @@ class FlowTable:
         return v.value
 
     # -- misc
+    # -- export encode (record -> protobuf), nfagg_encode_pb
+    def _pb_options(self, now_unix_ns, mono_now_ns, agent_ip16, names, unknown):
+        o = L.PbOptions()
+        o.struct_size = C.sizeof(L.PbOptions)
+        o.now_unix_ns, o.mono_now_ns = now_unix_ns, mono_now_ns
+        o.agent_ip[:] = list(bytes(agent_ip16))
+        names = np.ascontiguousarray(names)
+        o.names, o.n_names = (names.ctypes.data if len(names) else None), len(names)
+        o.unknown_name, o.unknown_len = unknown, len(unknown)
+        return o, names
+
+    def encode_pb(self, records: np.ndarray, now_unix_ns: int, mono_now_ns: int, agent_ip16: bytes, names: np.ndarray,
+                  unknown: bytes = b"unknown", kafka_keys=False):
+        """FlowsToPB + proto.Marshal of evicted records on the GPU. Returns (buf, frame_offsets, body_len[, keys]):
+        buf[frame_offsets[a]:frame_offsets[b]] is a serialized pbflow.Records of entries a..b-1; the last body_len[i]
+        bytes of frame i are the serialized pbflow.Record."""
+        r = np.ascontiguousarray(records)
+        n = r.nbytes // 144
+        o, keep = self._pb_options(now_unix_ns, mono_now_ns, agent_ip16, names, unknown)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        blen = np.zeros(max(n, 1), dtype=np.uint32)
+        keys = np.zeros((max(n, 1), 32), dtype=np.uint8) if kafka_keys else None
+        need = C.c_size_t(0)
+        cap = max(256 * n, 64)
+        while True:
+            buf = np.zeros(cap, dtype=np.uint8)
+            rc = L.lib.nfagg_encode_pb(self._h, r.ctypes.data_as(C.c_void_p), n, C.byref(o), buf.ctypes.data_as(C.c_void_p), cap,
+                                       off.ctypes.data_as(C.c_void_p), blen.ctypes.data_as(C.c_void_p),
+                                       keys.ctypes.data_as(C.c_void_p) if kafka_keys else None, C.byref(need))
+            if rc == L.TRUNCATED:
+                cap = need.value
+                continue
+            self._check(rc)
+            break
+        out = (buf[: need.value], off, blen[:n])
+        return out + (keys[:n],) if kafka_keys else out
+
+    def encode_pb_device(self, d_records: int, n: int, now_unix_ns: int, mono_now_ns: int, agent_ip16: bytes, names: np.ndarray,
+                         d_out: int, out_cap: int, d_frame_offsets: int, d_body_len: int, d_kafka_keys: int = 0,
+                         unknown: bytes = b"unknown"):
+        """Device-resident variant (raw device pointers). Returns (rc, bytes needed/written)."""
+        o, keep = self._pb_options(now_unix_ns, mono_now_ns, agent_ip16, names, unknown)
+        need = C.c_size_t(0)
+        rc = L.lib.nfagg_encode_pb_device(self._h, C.c_void_p(d_records), n, C.byref(o), C.c_void_p(d_out or None), out_cap,
+                                          C.c_void_p(d_frame_offsets), C.c_void_p(d_body_len), C.c_void_p(d_kafka_keys or None),
+                                          C.byref(need))
+        self._check(rc, ok=(L.OK, L.TRUNCATED))
+        return rc, need.value
+
     def stats(self) -> L.Stats:
         s = L.Stats()
         self._check(L.lib.nfagg_stats_get(self._h, C.byref(s)))

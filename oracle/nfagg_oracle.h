@@ -147,6 +147,33 @@ void orc_gen_stream(uint64_t seed, uint64_t j0, size_t n, uint64_t n_keys,
                     const uint64_t* thresholds, uint32_t hot_permille, uint32_t variant,
                     const uint64_t* pop_index, void* out);
 
+/* ---- record -> protobuf (oracle/nfagg_oracle_pb.c): pkg/pbflow/proto.go:40-149 FlowToPB over the
+ * model.Record that model.NewRecord (pkg/model/record.go:82-125) builds from one evicted
+ * flow_record_t, serialised as google.golang.org/protobuf does (fields in number order, proto3
+ * zero-value omission, message fields present whenever the Go pointer is non-nil). ---- */
+typedef struct {            /* one row of the interface namer table (registerer.IfaceNameForIndexAndMAC) */
+    uint32_t if_index;
+    uint8_t  mac[6];
+    uint8_t  has_mac;       /* 0: matches any MAC */
+    uint8_t  name_len;
+    char     name[16];
+    uint8_t  udn_len;       /* the value NewIntfDirUdn (record.go:167-183) resolves for this name */
+    char     udn[63];
+} orc_intf_name;            /* 92 bytes */
+typedef struct {
+    int64_t  now_unix_ns;   /* currentTime */
+    uint64_t mono_now_ns;   /* monotonicCurrentTime */
+    uint8_t  agent_ip[16];  /* net.IP in 16-byte form */
+    const orc_intf_name* names;
+    uint32_t n_names;
+    char     unknown_name[16];  /* what the namer returns for an unknown interface ("unknown", interfaces_listener.go:77) */
+    uint8_t  unknown_len;
+} orc_pb_options;
+/* Serialise pbflow.Record for one evicted flow into out (>= 1024 bytes); returns the length. */
+size_t orc_pb_encode_record(const orc_flow_record* r, const orc_pb_options* o, uint8_t* out);
+/* pkg/exporter/kafka_proto.go:37-47 getFlowKey: the two IPs, smaller first */
+void orc_kafka_key(const orc_flow_record* r, uint8_t out[32]);
+
 #ifdef __cplusplus
 }
 #endif

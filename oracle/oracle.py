@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "libnfagg_oracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("nfagg_oracle.c", "nfagg_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("nfagg_oracle.c", "nfagg_oracle_pb.c", "nfagg_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -53,6 +53,7 @@ def lib():
             "orc_splitmix64": (_u64, [_u64]),
             "orc_stream_key_index": (_u64, [_u64, _u64, _u64, _vp, C.c_uint32]),
             "orc_gen_stream": (None, [_u64, _u64, _sz, _u64, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
+            "orc_pb_encode_record": (_sz, [_vp, _vp, _vp]), "orc_kafka_key": (None, [_vp, _vp]),
         }
         for name, (res, args) in sig.items():
             f = getattr(l, name)
@@ -190,3 +191,60 @@ def rollup(kind, partials, n_cpu, base):
     folded = np.zeros(n_flows, dtype=dt)
     lib().orc_rollup(k, _p(parts), n_flows, n_cpu, _p(b), _p(folded))
     return b, folded
+
+
+# ---- record -> protobuf (nfagg_oracle_pb.c)
+INTF_NAME = np.dtype({"names": ["if_index", "mac", "has_mac", "name_len", "name", "udn_len", "udn"],
+                      "formats": ["<u4", ("u1", 6), "u1", "u1", ("S16"), "u1", ("S63")],
+                      "offsets": [0, 4, 10, 11, 12, 28, 29], "itemsize": 92})
+
+
+class PbOptions(C.Structure):
+    _fields_ = [("now_unix_ns", C.c_int64), ("mono_now_ns", C.c_uint64), ("agent_ip", C.c_uint8 * 16),
+                ("names", C.c_void_p), ("n_names", C.c_uint32), ("unknown_name", C.c_char * 16), ("unknown_len", C.c_uint8)]
+
+
+def intf_table(rows):
+    """rows: iterable of (if_index, mac bytes or None, name, udn)."""
+    t = np.zeros(len(rows), dtype=INTF_NAME)
+    for k, (ifx, mac, name, udn) in enumerate(rows):
+        t[k]["if_index"] = ifx
+        if mac is not None:
+            t[k]["mac"] = np.frombuffer(bytes(mac), dtype=np.uint8)
+            t[k]["has_mac"] = 1
+        nb, ub = name.encode(), udn.encode()
+        assert len(nb) <= 16 and len(ub) <= 63
+        t[k]["name"], t[k]["name_len"] = nb, len(nb)
+        t[k]["udn"], t[k]["udn_len"] = ub, len(ub)
+    return t
+
+
+def pb_options(now_unix_ns, mono_now_ns, agent_ip16, names, unknown=b"unknown"):
+    o = PbOptions()
+    o.now_unix_ns, o.mono_now_ns = now_unix_ns, mono_now_ns
+    o.agent_ip[:] = list(agent_ip16)
+    o._names = np.ascontiguousarray(names)          # keep alive
+    o.names, o.n_names = o._names.ctypes.data, len(o._names)
+    o.unknown_name, o.unknown_len = unknown, len(unknown)
+    return o
+
+
+def pb_encode(records, opts):
+    """Serialized pbflow.Record (bytes) of every record."""
+    r = np.ascontiguousarray(records)
+    raw = r.view(np.uint8).reshape(-1, 144)
+    buf = (C.c_uint8 * 1024)()
+    out = []
+    for k in range(len(raw)):
+        n = lib().orc_pb_encode_record(raw[k].ctypes.data_as(C.c_void_p), C.byref(opts), buf)
+        out.append(bytes(buf[:n]))
+    return out
+
+
+def kafka_keys(records):
+    r = np.ascontiguousarray(records)
+    raw = r.view(np.uint8).reshape(-1, 144)
+    out = np.zeros((len(raw), 32), dtype=np.uint8)
+    for k in range(len(raw)):
+        lib().orc_kafka_key(raw[k].ctypes.data_as(C.c_void_p), out[k].ctypes.data_as(C.c_void_p))
+    return out

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/pb_golden.json: evicted flow_record_t inputs and the serialized
+pbflow.Record bytes the reference's exporters would put on the wire for them.
+
+The bytes come from the Python protobuf runtime (google.protobuf, upb) over a descriptor that
+mirrors /root/reference/proto/flow.proto field for field, with the message populated by a Python
+restatement of model.NewRecord (pkg/model/record.go:82-125) and pbflow.FlowToPB
+(pkg/pbflow/proto.go:40-149). Serialization is deterministic (field-number order, proto3 zero-value
+omission) and identical to google.golang.org/protobuf's for these messages (no maps on this path).
+This script needs only numpy + protobuf; it is committed with its output because nothing outside
+this repository travels to the GPU box.
+
+    python tests/golden/gen_pb_golden.py      # rewrites tests/golden/pb_golden.json
+"""
+import json
+import os
+import sys
+
+import numpy as np
+from google.protobuf import descriptor_pb2, descriptor_pool, message_factory, duration_pb2, timestamp_pb2
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+T = descriptor_pb2.FieldDescriptorProto
+
+
+def _field(msg, name, number, ftype, type_name=None, repeated=False, oneof=None):
+    f = msg.field.add()
+    f.name, f.number, f.type = name, number, ftype
+    f.label = T.LABEL_REPEATED if repeated else T.LABEL_OPTIONAL
+    if type_name:
+        f.type_name = type_name
+    if oneof is not None:
+        f.oneof_index = oneof
+
+
+def build_classes():
+    """proto/flow.proto:16-138 as a FileDescriptorProto."""
+    fd = descriptor_pb2.FileDescriptorProto()
+    fd.name, fd.package, fd.syntax = "flow_mirror.proto", "pbflow", "proto3"
+    fd.dependency.extend(["google/protobuf/timestamp.proto", "google/protobuf/duration.proto"])
+    e = fd.enum_type.add(); e.name = "Direction"
+    for n, v in (("INGRESS", 0), ("EGRESS", 1)):
+        x = e.value.add(); x.name, x.number = n, v
+    m = fd.message_type.add(); m.name = "Records"
+    _field(m, "entries", 1, T.TYPE_MESSAGE, ".pbflow.Record", repeated=True)
+    m = fd.message_type.add(); m.name = "DupMapEntry"
+    _field(m, "interface", 1, T.TYPE_STRING); _field(m, "direction", 2, T.TYPE_ENUM, ".pbflow.Direction"); _field(m, "udn", 3, T.TYPE_STRING)
+    m = fd.message_type.add(); m.name = "IP"
+    m.oneof_decl.add().name = "ip_family"
+    _field(m, "ipv4", 1, T.TYPE_FIXED32, oneof=0); _field(m, "ipv6", 2, T.TYPE_BYTES, oneof=0)
+    m = fd.message_type.add(); m.name = "DataLink"
+    _field(m, "src_mac", 1, T.TYPE_UINT64); _field(m, "dst_mac", 2, T.TYPE_UINT64)
+    m = fd.message_type.add(); m.name = "Network"
+    _field(m, "src_addr", 1, T.TYPE_MESSAGE, ".pbflow.IP"); _field(m, "dst_addr", 2, T.TYPE_MESSAGE, ".pbflow.IP"); _field(m, "dscp", 3, T.TYPE_UINT32)
+    m = fd.message_type.add(); m.name = "Transport"
+    _field(m, "src_port", 1, T.TYPE_UINT32); _field(m, "dst_port", 2, T.TYPE_UINT32); _field(m, "protocol", 3, T.TYPE_UINT32)
+    m = fd.message_type.add(); m.name = "Xlat"
+    _field(m, "src_addr", 1, T.TYPE_MESSAGE, ".pbflow.IP"); _field(m, "dst_addr", 2, T.TYPE_MESSAGE, ".pbflow.IP")
+    _field(m, "src_port", 3, T.TYPE_UINT32); _field(m, "dst_port", 4, T.TYPE_UINT32); _field(m, "zone_id", 5, T.TYPE_UINT32)
+    m = fd.message_type.add(); m.name = "Quic"
+    _field(m, "version", 1, T.TYPE_UINT32); _field(m, "seen_long_hdr", 2, T.TYPE_UINT32); _field(m, "seen_short_hdr", 3, T.TYPE_UINT32)
+    m = fd.message_type.add(); m.name = "Record"
+    TS, DU = ".google.protobuf.Timestamp", ".google.protobuf.Duration"
+    for name, num, ft, tn, rep in [
+        ("eth_protocol", 1, T.TYPE_UINT32, None, False), ("direction", 2, T.TYPE_ENUM, ".pbflow.Direction", False),
+        ("time_flow_start", 3, T.TYPE_MESSAGE, TS, False), ("time_flow_end", 4, T.TYPE_MESSAGE, TS, False),
+        ("data_link", 5, T.TYPE_MESSAGE, ".pbflow.DataLink", False), ("network", 6, T.TYPE_MESSAGE, ".pbflow.Network", False),
+        ("transport", 7, T.TYPE_MESSAGE, ".pbflow.Transport", False), ("bytes", 8, T.TYPE_UINT64, None, False),
+        ("packets", 9, T.TYPE_UINT64, None, False), ("interface", 10, T.TYPE_STRING, None, False),
+        ("duplicate", 11, T.TYPE_BOOL, None, False), ("agent_ip", 12, T.TYPE_MESSAGE, ".pbflow.IP", False),
+        ("flags", 13, T.TYPE_UINT32, None, False), ("icmp_type", 14, T.TYPE_UINT32, None, False),
+        ("icmp_code", 15, T.TYPE_UINT32, None, False), ("pkt_drop_bytes", 16, T.TYPE_UINT64, None, False),
+        ("pkt_drop_packets", 17, T.TYPE_UINT64, None, False), ("pkt_drop_latest_flags", 18, T.TYPE_UINT32, None, False),
+        ("pkt_drop_latest_state", 19, T.TYPE_UINT32, None, False), ("pkt_drop_latest_drop_cause", 20, T.TYPE_UINT32, None, False),
+        ("dns_id", 21, T.TYPE_UINT32, None, False), ("dns_flags", 22, T.TYPE_UINT32, None, False),
+        ("dns_latency", 23, T.TYPE_MESSAGE, DU, False), ("time_flow_rtt", 24, T.TYPE_MESSAGE, DU, False),
+        ("dns_errno", 25, T.TYPE_UINT32, None, False), ("dup_list", 26, T.TYPE_MESSAGE, ".pbflow.DupMapEntry", True),
+        ("xlat", 28, T.TYPE_MESSAGE, ".pbflow.Xlat", False), ("sampling", 29, T.TYPE_UINT32, None, False),
+        ("ipsec_encrypted", 30, T.TYPE_UINT32, None, False), ("ipsec_encrypted_ret", 31, T.TYPE_INT32, None, False),
+        ("dns_name", 32, T.TYPE_STRING, None, False), ("ssl_version", 33, T.TYPE_UINT32, None, False),
+        ("ssl_mismatch", 34, T.TYPE_BOOL, None, False), ("tls_types", 35, T.TYPE_UINT32, None, False),
+        ("tls_cipher_suite", 36, T.TYPE_UINT32, None, False), ("tls_key_share", 37, T.TYPE_UINT32, None, False),
+        ("quic", 38, T.TYPE_MESSAGE, ".pbflow.Quic", False),
+    ]:   # field 27 (repeated NetworkEvent with a map) is never populated on this path and is left out
+        _field(m, name, num, ft, tn, rep)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(descriptor_pb2.FileDescriptorProto.FromString(timestamp_pb2.DESCRIPTOR.serialized_pb))
+    pool.Add(descriptor_pb2.FileDescriptorProto.FromString(duration_pb2.DESCRIPTOR.serialized_pb))
+    pool.Add(fd)
+    get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName("pbflow." + n))
+    return get("Record"), get("Records")
+
+
+def go_time_add(now_unix_ns, delta):
+    """time.Unix(0, now).Add(-delta) -> (Unix(), Nanosecond())"""
+    sec, nsec = divmod(now_unix_ns, 10**9)
+    d = -delta
+    if d < -(1 << 63) or d >= (1 << 63):
+        d = ((d + (1 << 63)) % (1 << 64)) - (1 << 63)
+    dsec = abs(d) // 10**9 * (1 if d >= 0 else -1)           # Go integer division truncates toward zero
+    nsec += d - dsec * 10**9
+    if nsec >= 10**9:
+        dsec, nsec = dsec + 1, nsec - 10**9
+    elif nsec < 0:
+        dsec, nsec = dsec - 1, nsec + 10**9
+    return sec + dsec, nsec
+
+
+def i64(u):
+    u &= (1 << 64) - 1
+    return u - (1 << 64) if u >= (1 << 63) else u
+
+
+def flow_to_pb(Record, rec, now_unix_ns, mono_now, agent_ip16, namer):
+    """NewRecord + FlowToPB for one evicted flow_record_t (numpy void of oracle.FLOW_RECORD)."""
+    k, m = rec["id"], rec["metrics"]
+    pb = Record()
+    pb.eth_protocol = int(m["eth_protocol"])
+    pb.direction = int(m["direction_first_seen"])
+    for fld, ts in ((pb.time_flow_start, int(m["start"])), (pb.time_flow_end, int(m["end"]))):
+        fld.SetInParent()
+        s, ns = go_time_add(now_unix_ns, i64(mono_now - ts))
+        fld.seconds, fld.nanos = s, ns
+    pb.data_link.SetInParent()
+    pb.data_link.src_mac = int.from_bytes(bytes(m["src_mac"]), "big")
+    pb.data_link.dst_mac = int.from_bytes(bytes(m["dst_mac"]), "big")
+    pb.network.SetInParent()
+    pb.network.dscp = int(m["dscp"])
+    pb.transport.SetInParent()
+    pb.transport.protocol, pb.transport.src_port, pb.transport.dst_port = int(k["proto"]), int(k["src_port"]), int(k["dst_port"])
+    pb.icmp_type, pb.icmp_code = int(k["icmp_type"]), int(k["icmp_code"])
+    pb.bytes, pb.packets = int(m["bytes"]), int(m["packets"])
+    ip = bytes(agent_ip16)
+    if ip[:12] == b"\0" * 10 + b"\xff\xff":
+        pb.agent_ip.ipv4 = int.from_bytes(ip[12:], "big")
+    else:
+        pb.agent_ip.ipv6 = ip
+    pb.flags = int(m["flags"])
+    pb.time_flow_rtt.SetInParent()                           # durationpb.New(0)
+    pb.sampling = int(m["sampling"])
+    pb.ssl_version, pb.tls_types = int(m["ssl_version"]), int(m["tls_types"])
+    pb.tls_cipher_suite, pb.tls_key_share = int(m["tls_cipher_suite"]), int(m["tls_key_share"])
+    pb.ssl_mismatch = bool(int(m["misc_flags"]) & 1)
+    lmac = bytes(m["dst_mac"]) if int(m["direction_first_seen"]) == 0 else bytes(m["src_mac"])
+    intfs = [(int(m["if_index_first_seen"]), int(m["direction_first_seen"]))]
+    for i in range(min(int(m["nb_observed_intf"]), 6)):
+        intfs.append((int(m["observed_intf"][i]), int(m["observed_direction"][i])))
+    for ifx, d in intfs:
+        name, udn = namer(ifx, lmac)
+        e = pb.dup_list.add()
+        e.interface, e.direction, e.udn = name, d, udn
+    src, dst = bytes(k["src_ip"]), bytes(k["dst_ip"])
+    if int(m["eth_protocol"]) == 0x86DD:
+        pb.network.src_addr.ipv6, pb.network.dst_addr.ipv6 = src, dst
+    else:
+        pb.network.src_addr.ipv4 = int.from_bytes(src[12:], "big")
+        pb.network.dst_addr.ipv4 = int.from_bytes(dst[12:], "big")
+    return pb
+
+
+NAMES = [  # (if_index, mac or None, name, udn)
+    (1, None, "lo", ""), (2, None, "eth0", "default"), (3, bytes.fromhex("020000000001"), "veth3a", "udn-blue"),
+    (3, None, "veth3", ""), (4, None, "ovn-k8s-mp0", "tenant/with/slashes-0123456789"), (5, bytes.fromhex("aabbccddeeff"), "br-ex", ""),
+    (7, None, "", "nameless"), (4321, None, "x" * 16, "u" * 63),
+]
+
+
+def namer_from(rows, unknown="unknown"):
+    def f(ifx, mac):
+        anyrow = None
+        for (i, mc, name, udn) in rows:
+            if i != ifx:
+                continue
+            if mc is not None:
+                if mc == mac:
+                    return name, udn
+            elif anyrow is None:
+                anyrow = (name, udn)
+        return anyrow if anyrow else (unknown, "")
+    return f
+
+
+def main():
+    from oracle import oracle as O
+    Record, Records = build_classes()
+    rng = np.random.default_rng(2024)
+    recs = O.gen_stream(96, seed=77, n_keys=40, variant=1)
+    m = recs["metrics"]
+    # reach every branch: IPv6 flows, zero fields, large/odd times, interfaces known/unknown/mac-specific
+    m["if_index_first_seen"] = rng.choice(np.array([0, 1, 2, 3, 4, 5, 7, 9, 4321], dtype=np.uint32), len(recs))
+    m["observed_intf"] = rng.choice(np.array([0, 1, 2, 3, 4, 5, 7, 9, 4321], dtype=np.uint32), (len(recs), 6))
+    m["direction_first_seen"] = rng.integers(0, 2, len(recs))
+    m["src_mac"][::3] = np.frombuffer(bytes.fromhex("020000000001"), dtype=np.uint8)
+    m["dst_mac"][1::3] = np.frombuffer(bytes.fromhex("aabbccddeeff"), dtype=np.uint8)
+    v6 = np.arange(len(recs)) % 4 == 1
+    m["eth_protocol"][v6] = 0x86DD
+    recs["id"]["src_ip"][v6] = rng.integers(0, 256, (int(v6.sum()), 16))
+    m["start"][5], m["end"][5] = 0, 0
+    m["start"][6], m["end"][6] = (1 << 64) - 1, 1 << 63
+    m["bytes"][7], m["packets"][7] = (1 << 64) - 1, (1 << 32) - 1
+    recs[8] = np.zeros((), dtype=recs.dtype)                  # the all-zero record
+    cases = []
+    for now, mono, agent in [
+        (1_661_272_402_123_456_789, 5_000_000_000_000, bytes(10) + b"\xff\xff" + bytes([10, 1, 2, 3])),
+        (1_700_000_000_000_000_000, 3_000_000, bytes.fromhex("20010db8000000000000000000000001")),
+        (999_999_999, 10**15, bytes(16)),                     # times before 1970
+    ]:
+        namer = namer_from(NAMES)
+        enc = [flow_to_pb(Record, r, now, mono, agent, namer).SerializeToString(deterministic=True) for r in recs]
+        # one Records message = what GRPCProto.ExportFlows sends (pkg/pbflow/proto.go:18-36)
+        batch = Records()
+        for r in recs[:10]:
+            batch.entries.append(flow_to_pb(Record, r, now, mono, agent, namer))
+        cases.append({"now_unix_ns": now, "mono_now_ns": mono, "agent_ip": agent.hex(),
+                      "records_pb": [e.hex() for e in enc], "records10_message": batch.SerializeToString(deterministic=True).hex()})
+    out = {"comment": "generated by tests/golden/gen_pb_golden.py (python protobuf %s); do not edit" % __import__("google.protobuf").protobuf.__version__,
+           "names": [[i, mc.hex() if mc is not None else None, n, u] for (i, mc, n, u) in NAMES],
+           "unknown_name": "unknown",
+           "records_hex": recs.tobytes().hex(), "cases": cases}
+    # the record of pkg/exporter/kafka_proto_test.go:26-86 TestProtoConversion, decoded field checks live in the test
+    json.dump(out, open(os.path.join(HERE, "pb_golden.json"), "w"))
+    print("wrote", os.path.join(HERE, "pb_golden.json"), len(recs), "records x", len(cases), "cases")
+
+
+if __name__ == "__main__":
+    main()

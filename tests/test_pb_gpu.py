@@ -1,0 +1,116 @@
+"""Record -> protobuf on the GPU (csrc/nfagg_pb.hip) through the C ABI: bit-exact against the
+golden wire bytes of the Python protobuf runtime (tests/golden/pb_golden.json) and against the
+C oracle on seeded streams; framing, offsets, Kafka keys, truncation, device-resident path."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+NAMES = [(1, None, "lo", ""), (2, None, "eth0", "default"), (3, bytes.fromhex("020000000001"), "veth3a", "udn-blue"),
+         (3, None, "veth3", ""), (4, None, "ovn-k8s-mp0", "t"), (6, None, "", "nameless"), (8, None, "x" * 16, "u" * 63)]
+AGENT4 = bytes(10) + b"\xff\xff" + bytes([10, 1, 2, 3])
+
+
+def frames(buf, off, blen):
+    raw = buf.tobytes()
+    out = []
+    for i in range(len(blen)):
+        fr = raw[int(off[i]):int(off[i + 1])]
+        body = fr[len(fr) - int(blen[i]):]
+        assert fr[0] == 0x0A and _varint(len(body)) == fr[1:len(fr) - len(body)]
+        out.append(body)
+    return out
+
+
+def _varint(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def test_golden_vectors(nf, O):
+    g = json.load(open(os.path.join(HERE, "golden", "pb_golden.json")))
+    recs = np.frombuffer(bytes.fromhex(g["records_hex"]), dtype=O.FLOW_RECORD)
+    names = nf.intf_table([(i, bytes.fromhex(m) if m is not None else None, n, u) for (i, m, n, u) in g["names"]])
+    with nf.FlowTable(max_entries=64) as tab:
+        for case in g["cases"]:
+            buf, off, blen = tab.encode_pb(recs.view(nf.FLOW_RECORD), case["now_unix_ns"], case["mono_now_ns"],
+                                           bytes.fromhex(case["agent_ip"]), names, g["unknown_name"].encode())
+            got = frames(buf, off, blen)
+            want = [bytes.fromhex(h) for h in case["records_pb"]]
+            assert len(got) == len(want)
+            for k, (a, b) in enumerate(zip(got, want)):
+                assert a == b, f"record {k}: {a.hex()} != {b.hex()}"
+            # the first ten frames are exactly the pbflow.Records message of those ten entries
+            assert buf[: int(off[10])].tobytes() == bytes.fromhex(case["records10_message"])
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1023, 1025, 50_000])
+def test_stream_parity_with_oracle(nf, O, n):
+    recs = O.gen_stream(n, seed=n, n_keys=997, variant=1)     # scrambled: interfaces 1..8, observed lists, tls fields, zero times
+    recs["metrics"]["eth_protocol"][::5] = 0x86DD
+    names_rows = NAMES
+    now, mono = 1_700_000_000_123_456_789, 2_500_000
+    want = O.pb_encode(recs, O.pb_options(now, mono, AGENT4, O.intf_table(names_rows)))
+    with nf.FlowTable(max_entries=64) as tab:
+        buf, off, blen, keys = tab.encode_pb(recs.view(nf.FLOW_RECORD), now, mono, AGENT4, nf.intf_table(names_rows), kafka_keys=True)
+    got = frames(buf, off, blen)
+    assert got == want
+    assert int(off[0]) == 0 and int(off[-1]) == len(buf) and (np.diff(off.astype(np.int64)) > 0).all()
+    assert np.array_equal(keys, O.kafka_keys(recs))
+
+
+def test_empty_truncated_and_unknown_names(nf, O):
+    import ctypes as C
+    recs = O.gen_stream(300, seed=4, n_keys=50, variant=1)
+    with nf.FlowTable(max_entries=64) as tab:
+        buf, off, blen = tab.encode_pb(recs[:0].view(nf.FLOW_RECORD), 1, 1, AGENT4, nf.intf_table([]))
+        assert len(buf) == 0 and list(off) == [0] and len(blen) == 0
+        # no table at all: every interface is "unknown" (interfaces_listener.go:77)
+        buf, off, blen = tab.encode_pb(recs.view(nf.FLOW_RECORD), 10**18, 10**9, bytes(range(16)), nf.intf_table([]), unknown=b"unknown")
+        want = O.pb_encode(recs, O.pb_options(10**18, 10**9, bytes(range(16)), O.intf_table([])))
+        assert frames(buf, off, blen) == want
+        # too small an output buffer: nothing written, size reported
+        o, keep = tab._pb_options(10**18, 10**9, bytes(range(16)), nf.intf_table([]), b"unknown")
+        need = C.c_size_t(0)
+        small = np.zeros(100, dtype=np.uint8)
+        off2 = np.zeros(301, dtype=np.uint64); bl2 = np.zeros(300, dtype=np.uint32)
+        rc = nf._lib.lib.nfagg_encode_pb(tab._h, recs.ctypes.data_as(C.c_void_p), 300, C.byref(o), small.ctypes.data_as(C.c_void_p), 100,
+                                         off2.ctypes.data_as(C.c_void_p), bl2.ctypes.data_as(C.c_void_p), None, C.byref(need))
+        assert rc == nf.TRUNCATED and need.value == len(buf) and not small.any()
+
+
+def test_device_resident_evict_then_encode(nf, O):
+    """nfagg_evict_device -> nfagg_encode_pb_device without leaving HBM: what the exporter hand-off would be."""
+    import torch
+    th = O.zipf_thresholds(3000, 1.1)
+    recs = O.gen_stream(100_000, seed=12, n_keys=3000, thresholds=th, variant=1)
+    want_flows = O.run_accounter(recs, 1 << 16)[0][1]
+    now, mono = 1_700_000_000_000_000_000, 10**12
+    names = NAMES
+    with nf.FlowTable(max_entries=1 << 16) as tab:
+        assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
+        d_ev = torch.empty(len(want_flows) * 144 + 16, dtype=torch.uint8, device="cuda")
+        n = tab.evict_device(d_ev.data_ptr(), len(want_flows))
+        assert n == len(want_flows)
+        d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        d_len = torch.empty(n, dtype=torch.int32, device="cuda")
+        d_keys = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+        rc, need = tab.encode_pb_device(d_ev.data_ptr(), n, now, mono, AGENT4, nf.intf_table(names), 0, 0, d_off.data_ptr(), d_len.data_ptr())
+        assert rc == nf.TRUNCATED and need > 0                   # size query
+        d_out = torch.empty(need + 16, dtype=torch.uint8, device="cuda")
+        rc, wrote = tab.encode_pb_device(d_ev.data_ptr(), n, now, mono, AGENT4, nf.intf_table(names), d_out.data_ptr(), need,
+                                         d_off.data_ptr(), d_len.data_ptr(), d_keys.data_ptr())
+        assert rc == nf.OK and wrote == need
+        ev = d_ev[: n * 144].cpu().numpy().view(nf.FLOW_RECORD)
+        got = frames(d_out[:need].cpu().numpy(), d_off.cpu().numpy().astype(np.uint64), d_len.cpu().numpy().astype(np.uint32))
+    # eviction order is unspecified: encode the evicted records (as evicted) with the oracle
+    assert got == O.pb_encode(ev.view(O.FLOW_RECORD), O.pb_options(now, mono, AGENT4, O.intf_table(names)))
+    assert np.array_equal(d_keys.cpu().numpy().reshape(-1, 32), O.kafka_keys(ev.view(O.FLOW_RECORD)))
