@@ -385,6 +385,38 @@ int nfagg_cm_query(nfagg_handle* h, int which, const uint8_t ip[16], uint64_t* e
 double nfagg_hll_estimate_from_histogram(const uint32_t* hist, uint32_t p);
 
 /* ------------------------------------------------------------------ */
+/* Ring-buffer drain — replaces the per-sample loop of                   */
+/* RingBufTracer.listenAndForwardRingBuffer (pkg/flow/tracer_ringbuf.go:  */
+/* 112-134) over ringbuf.Reader / ringReader.readRecord                   */
+/* (vendor/github.com/cilium/ebpf/ringbuf/ring.go:44-101): one bulk copy  */
+/* of every committed sample into a staging buffer instead of one         */
+/* reflection decode + channel send per record. Host-only, no device.     */
+/* ------------------------------------------------------------------ */
+
+/* A BPF_MAP_TYPE_RINGBUF as user space maps it (kernel/bpf/ringbuf.c):
+ * data = the data pages (size mask+1; the second mapping cilium relies on is
+ * not required), producer_pos / consumer_pos = the two position pages. */
+typedef struct nfagg_ringbuf {
+    const uint8_t* data;
+    uint64_t mask;                        /* data size - 1, size a power of two */
+    const volatile uint64_t* producer_pos;/* written by the kernel */
+    volatile uint64_t* consumer_pos;      /* written by this call   */
+} nfagg_ringbuf;
+
+/* Copies committed 144-byte samples, in ring order, into dst (room for
+ * cap_records; e.g. the buffer of nfagg_staging_acquire) until the ring is
+ * empty, the next sample is still busy (ring.go:67-72), or dst is full; then
+ * publishes the consumer position once. Discarded samples (ring.go:84-90) and
+ * samples whose length is not 144 (model.ReadFrom would fail,
+ * tracer_ringbuf.go:119-122) are skipped and counted in *n_skipped.
+ * errno_counts (optional, 256 entries, ADDED to): records per metrics.errno,
+ * for EvictedPacketsCounter("ringbuffer", errno) (tracer_ringbuf.go:128-130).
+ * Returns NFAGG_OK, or NFAGG_EINVAL when the ring content is truncated
+ * (io.ErrUnexpectedEOF in the reference); nothing is consumed past that point. */
+int nfagg_ringbuf_drain(const nfagg_ringbuf* rb, void* dst, size_t cap_records,
+                        size_t* n_records, size_t* n_skipped, uint64_t* errno_counts);
+
+/* ------------------------------------------------------------------ */
 /* Export encode — replaces, for evicted records, model.NewRecord's time */
 /* and interface derivation (pkg/model/record.go:82-125), pbflow.FlowToPB */
 /* / FlowsToPB (pkg/pbflow/proto.go:18-149), proto.Marshal of each        */

@@ -42,6 +42,11 @@ class Config(C.Structure):
     ]
 
 
+class RingBuf(C.Structure):
+    """nfagg_ringbuf (include/nfagg.h)."""
+    _fields_ = [("data", C.c_void_p), ("mask", C.c_uint64), ("producer_pos", C.c_void_p), ("consumer_pos", C.c_void_p)]
+
+
 class PbOptions(C.Structure):
     """nfagg_pb_options (include/nfagg.h)."""
     _fields_ = [
@@ -91,6 +96,7 @@ SIGNATURES = {
     "nfagg_hll_estimate": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     "nfagg_cm_query": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(C.c_uint64)]),
     "nfagg_hll_estimate_from_histogram": (C.c_double, [_vp, C.c_uint32]),
+    "nfagg_ringbuf_drain": (C.c_int, [C.POINTER(RingBuf), _vp, _sz, _psz, _psz, _vp]),
     "nfagg_encode_pb": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
     "nfagg_encode_pb_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
     "nfagg_shard_of": (C.c_uint32, [_vp, C.c_uint32]),
