@@ -235,7 +235,10 @@ hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records,
     if (n == 0) return hipSuccess;
     if (!t.aux) return hipErrorInvalidValue;
     const size_t lds1 = sizeof(dcache::ClaimCache<dcache::kClaimEntries>), lds2 = sizeof(dcache::FoldCache<dcache::kFoldEntries>);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcache::k_dedup_claim_cached), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e == hipSuccess)

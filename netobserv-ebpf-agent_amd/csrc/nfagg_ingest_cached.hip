@@ -217,7 +217,10 @@ template <int BLOCK, int K, bool SKETCH, bool TIMING = false>
 static hipError_t run_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                              int blocks_per_cu, hipStream_t s) {
     const size_t lds = sizeof(FlowCache<K>);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ingest_cached<BLOCK, K, SKETCH, TIMING>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

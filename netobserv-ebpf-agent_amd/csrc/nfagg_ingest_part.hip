@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
 #undef NF_TICK
     if (skipped) aadd(&t.ctr->n_skipped, skipped);
     if (spilled) aadd(&t.ctr->n_bypassed, spilled);
-    if (direct) aadd(&t.ctr->pad[0], direct);
+    if (direct) aadd(&t.ctr->n_direct, direct);
 }
 
 // pass 3: the (normally empty) overflow list, one record per lane, merged directly.
@@ -373,14 +373,17 @@ __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView 
         if (SKETCH) sketch_add(sk, w, r.bytes());
         direct++;
     }
-    if (direct) aadd(&t.ctr->pad[0], direct);
+    if (direct) aadd(&t.ctr->n_direct, direct);
 }
 
 template <bool SKETCH, bool T1 = false, bool T2 = false>
 static hipError_t run(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                       uint64_t seq_base, hipStream_t s) {
     const size_t lds1 = sizeof(Cache) + sizeof(Stage), lds2 = sizeof(Cache);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold<SKETCH, false, T1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);

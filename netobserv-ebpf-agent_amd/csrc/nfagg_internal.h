@@ -87,7 +87,8 @@ struct DevCounters {
     unsigned long long n_bypassed; // records merged one by one (no LDS cache entry for their flow)
     unsigned int error;            // non-zero: a kernel bailed out (probe overflow)
     unsigned int max_probe;
-    unsigned long long pad[2];
+    unsigned long long n_direct;   // two-pass ingest: records merged one by one in pass 2 / pass 3 (no LDS entry, queue overflow)
+    unsigned long long pad1;
     unsigned long long phase[8];   // ingest_variant 6 only: per-phase wave-cycle sums (diagnostics)
 };
 

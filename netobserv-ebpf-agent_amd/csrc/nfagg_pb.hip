@@ -276,7 +276,10 @@ hipError_t launch_pb_size(const void* d_recs, uint64_t n, const PbParams& P, uin
 hipError_t launch_pb_write(const void* d_recs, uint64_t n, const PbParams& P, const uint32_t* d_body_len, const uint32_t* d_local_off,
                            const uint64_t* d_block_base, void* d_out, uint64_t* d_frame_offsets, void* d_kafka_keys, hipStream_t s) {
     const size_t lds = 16 + 64 * (size_t)kPbMaxFrame;
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pb_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
