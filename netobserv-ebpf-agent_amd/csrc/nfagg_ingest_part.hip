@@ -133,7 +133,7 @@ NF_DEV uint4 rec_chunk(const void* recs, uint64_t i, int k) {
 // the entry's earliest record (and its earliest non-zero MACs) are gathered from the batch.
 template <bool SKETCH>
 NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L, int e, const void* recs, uint32_t seq_base32) {
-    if (L.h64[e] == 0) return;
+    if (L.h64[e] == 0 || L.first_seq[e] == 0xffffffffu) return;   // free, or claimed but never folded into
     uint64_t w[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
