@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="records per nfagg_ingest_device call (0 = whole stream)")
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="records of the stream the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--max-entries", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1: nccl (= RCCL, the product path) or gloo "
+                    "(rehearsal of the N>1 code path on a 1-GPU box together with --same-device)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
     if os.environ.get("NFAGG_BENCH_WATCHDOG"):
         import faulthandler
@@ -62,10 +65,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     import netobserv_ebpf_agent_amd as nf
     from netobserv_ebpf_agent_amd import synth
@@ -164,7 +172,8 @@ def main():
                                 "+CM(d=4,w=2^20)+HLL(p=14)" if args.sketches else " only",
                                 ", kernel-dedup merge on" if args.dedup else "")),
                 "records_per_gpu_per_step": n, "unique_flows_per_gpu": keys, "hot_permille": args.hot_permille,
-                "parallelism": "key-hash shards x%d" % world, "ingest_variant": args.variant,
+                "parallelism": "key-hash shards x%d" % world + ("" if args.backend == "nccl" and not args.same_device
+                                                                        else " (REHEARSAL: backend %s, same_device %s)" % (args.backend, args.same_device)), "ingest_variant": args.variant,
                 "evictions_per_step": 1, "evicted_flows_per_step": flows_total,
                 "evictions_per_s": round(steps / dt, 3), "evicted_flows_per_s": round(flows_total * steps / dt, 1),
             },
@@ -199,7 +208,7 @@ def main():
                 out["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
                 break
         # ---- CPU baseline: the oracle (C restatement of pkg/flow.Accounter), 1 core, bounded sample
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:     # rank 0 at N=1 only
             from oracle import oracle as O
             O.build()
             m = min(args.cpu_sample, n)
