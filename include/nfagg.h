@@ -469,6 +469,54 @@ int nfagg_encode_pb_device(nfagg_handle* h, const void* d_records, size_t n, con
                            void* d_out, size_t out_cap, uint64_t* d_frame_offsets, uint32_t* d_body_len,
                            void* d_kafka_keys, size_t* out_bytes);
 
+/* The MapTracer branch (pkg/flow/tracer_map.go:103-146): every flow is a full
+ * model.BpfFlowContent (pkg/model/flow_content.go:9-17) — base metrics plus the
+ * optional per-feature parts that LookupAndDeleteMap merged
+ * (pkg/tracer/tracer.go:1057-1110; here: the `folded` outputs of nfagg_rollup_*).
+ * Struct of arrays indexed like the records; part k is present for flow i (the Go
+ * pointer is non-nil) when its array is non-NULL and present[i] has
+ * NFAGG_FEAT_* set. Encoded per NewRecord (record.go:116-125: DNSLatency,
+ * TimeFlowRtt) and FlowToPB (proto.go:79-118,129-138: dns_id/flags/errno/name
+ * via utils.DNSRawNameToDotted, dns_latency only when non-zero, pkt_drop_*, xlat
+ * with the address family of the FLOW's eth_protocol, ipsec_encrypted[_ret],
+ * quic). Network events (NFAGG_FEAT_NETWORK_EVENTS) need the OVN sample decoder:
+ * they are encoded as NewRecord does with a nil decoder (record.go:126) — field 27
+ * empty, no drop injected; a caller with a decoder routes those flows through Go.
+ * dns.name bytes are copied as they are (Go's Marshal rejects a non-UTF-8 string). */
+enum {   /* the per-CPU feature maps, in the order of the nfagg_rollup_* entries */
+    NFAGG_ROLLUP_ADDITIONAL = 0, NFAGG_ROLLUP_DNS = 1, NFAGG_ROLLUP_DROPS = 2,
+    NFAGG_ROLLUP_NETWORK_EVENTS = 3, NFAGG_ROLLUP_XLAT = 4, NFAGG_ROLLUP_QUIC = 5
+};
+enum {
+    NFAGG_FEAT_ADDITIONAL     = 1 << NFAGG_ROLLUP_ADDITIONAL,
+    NFAGG_FEAT_DNS            = 1 << NFAGG_ROLLUP_DNS,
+    NFAGG_FEAT_DROPS          = 1 << NFAGG_ROLLUP_DROPS,
+    NFAGG_FEAT_NETWORK_EVENTS = 1 << NFAGG_ROLLUP_NETWORK_EVENTS,
+    NFAGG_FEAT_XLAT           = 1 << NFAGG_ROLLUP_XLAT,
+    NFAGG_FEAT_QUIC           = 1 << NFAGG_ROLLUP_QUIC
+};
+typedef struct nfagg_pb_features {
+    uint32_t struct_size;        /* sizeof(nfagg_pb_features) */
+    uint32_t reserved_;
+    const uint8_t* present;                      /* n bytes of NFAGG_FEAT_* bits (NULL: none) */
+    const nfagg_additional_metrics* additional;  /* n entries or NULL */
+    const nfagg_dns_metrics*        dns;
+    const nfagg_pkt_drop_metrics*   drops;
+    const nfagg_xlat_metrics*       xlat;
+    const nfagg_quic_metrics*       quic;
+} nfagg_pb_features;
+
+/* nfagg_encode_pb over (records[i].id, BpfFlowContent{records[i].metrics, features[i]}).
+ * Same outputs and return codes. All pointers HOST memory: */
+int nfagg_encode_pb_content(nfagg_handle* h, const void* records, size_t n, const nfagg_pb_features* features,
+                            const nfagg_pb_options* opt, void* out, size_t out_cap, uint64_t* frame_offsets,
+                            uint32_t* body_len, void* kafka_keys, size_t* out_bytes);
+/* Same with every data pointer (also those inside d_features) in DEVICE memory;
+ * the nfagg_pb_features struct itself is in host memory. */
+int nfagg_encode_pb_content_device(nfagg_handle* h, const void* d_records, size_t n, const nfagg_pb_features* d_features,
+                                   const nfagg_pb_options* opt, void* d_out, size_t out_cap, uint64_t* d_frame_offsets,
+                                   uint32_t* d_body_len, void* d_kafka_keys, size_t* out_bytes);
+
 /* ------------------------------------------------------------------ */
 /* Sharding, stats, sync                                                */
 /* ------------------------------------------------------------------ */

@@ -8,7 +8,8 @@ library has not been built — there is no CPU or pure-Python fallback.
 """
 from . import _lib
 from ._lib import (OK, FULL, TRUNCATED, REASON_TIMEOUT, REASON_FULL, REASON_CLOSING, SKETCH_CM, SKETCH_HLL,
-                   CM_SRC, CM_DST, HLL_SRC, HLL_DST, MODE_ACCOUNTER, MODE_KERNEL_DEDUP)
+                   CM_SRC, CM_DST, HLL_SRC, HLL_DST, MODE_ACCOUNTER, MODE_KERNEL_DEDUP,
+                   FEAT_ADDITIONAL, FEAT_DNS, FEAT_DROPS, FEAT_NETWORK_EVENTS, FEAT_XLAT, FEAT_QUIC)
 from .records import (FLOW_ID, FLOW_METRICS, FLOW_RECORD, ADDITIONAL, DNS, PKT_DROP, NETWORK_EVENTS, XLAT, QUIC,
                       ROLLUP_KINDS, sort_by_key, INTF_NAME, intf_table)
 from .table import (FlowTable, NfaggError, key_hash, shard_of, ip_hash, hll_estimate_from_histogram, record_times)

@@ -56,6 +56,15 @@ class PbOptions(C.Structure):
     ]
 
 
+class PbFeatures(C.Structure):
+    """nfagg_pb_features (include/nfagg.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("reserved_", C.c_uint32), ("present", C.c_void_p), ("additional", C.c_void_p),
+                ("dns", C.c_void_p), ("drops", C.c_void_p), ("xlat", C.c_void_p), ("quic", C.c_void_p)]
+
+
+FEAT_ADDITIONAL, FEAT_DNS, FEAT_DROPS, FEAT_NETWORK_EVENTS, FEAT_XLAT, FEAT_QUIC = 1, 2, 4, 8, 16, 32
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("records_ingested", C.c_uint64), ("records_skipped", C.c_uint64), ("entries", C.c_uint64),
@@ -99,6 +108,8 @@ SIGNATURES = {
     "nfagg_ringbuf_drain": (C.c_int, [C.POINTER(RingBuf), _vp, _sz, _psz, _psz, _vp]),
     "nfagg_encode_pb": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
     "nfagg_encode_pb_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
+    "nfagg_encode_pb_content": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbFeatures), C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
+    "nfagg_encode_pb_content_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbFeatures), C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
     "nfagg_shard_of": (C.c_uint32, [_vp, C.c_uint32]),
     "nfagg_shard_ids": (None, [_vp, _sz, C.c_uint32, _vp]),
     "nfagg_key_hash": (C.c_uint64, [_vp]),

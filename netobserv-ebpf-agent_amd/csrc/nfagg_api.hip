@@ -63,8 +63,8 @@ struct nfagg_handle {
     size_t d_roll_cap[3] = {0, 0, 0};
     uint32_t* d_hist = nullptr;
     // protobuf encode scratch: local offsets, block sums, block bases, namer table, (host variant) records/out/offsets/lens/keys
-    void* d_pb[9] = {};
-    size_t d_pb_cap[9] = {};
+    void* d_pb[15] = {};
+    size_t d_pb_cap[15] = {};
     // spill queues of the two-pass ingest
     void* d_spill = nullptr;
     size_t d_spill_cap = 0;
@@ -386,7 +386,7 @@ void nfagg_destroy(nfagg_handle* h) {
     for (int k = 0; k < 3; k++) if (h->d_roll[k]) hipFree(h->d_roll[k]);
     if (h->d_hist) hipFree(h->d_hist);
     if (h->d_spill) hipFree(h->d_spill);
-    for (int k = 0; k < 9; k++) if (h->d_pb[k]) hipFree(h->d_pb[k]);
+    for (int k = 0; k < 15; k++) if (h->d_pb[k]) hipFree(h->d_pb[k]);
     if (h->tv.spill.qtail) hipFree(h->tv.spill.qtail);
     if (h->d_evict) hipFree(h->d_evict);
     if (h->d_slot_idx) hipFree(h->d_slot_idx);
@@ -731,15 +731,25 @@ int nfagg_stats_get(nfagg_handle* h, nfagg_stats* out) {
 }
 
 // ---- record -> protobuf (nfagg_pb.hip)
-int nfagg_encode_pb_device(nfagg_handle* h, const void* d_records, size_t n, const nfagg_pb_options* opt,
-                           void* d_out, size_t out_cap, uint64_t* d_frame_offsets, uint32_t* d_body_len,
-                           void* d_kafka_keys, size_t* out_bytes) {
+// feat (optional): DEVICE pointers
+static int encode_pb_device_core(nfagg_handle* h, const void* d_records, size_t n, const nfagg_pb_features* feat, const nfagg_pb_options* opt,
+                                 void* d_out, size_t out_cap, uint64_t* d_frame_offsets, uint32_t* d_body_len,
+                                 void* d_kafka_keys, size_t* out_bytes) {
     if (!h || !opt || !out_bytes || !d_frame_offsets || (n && (!d_records || !d_body_len))) return fail(h, NFAGG_EINVAL, "null argument");
     if (opt->struct_size != sizeof(nfagg_pb_options)) return fail(h, NFAGG_EINVAL, "nfagg_pb_options.struct_size mismatch");
     if (opt->unknown_len > 16 || (opt->n_names && !opt->names)) return fail(h, NFAGG_EINVAL, "bad namer table");
     if ((((uintptr_t)d_records | (uintptr_t)d_out | (uintptr_t)d_kafka_keys) & 15u) != 0) return fail(h, NFAGG_EINVAL, "device buffers must be 16-byte aligned");
     for (uint32_t k = 0; k < opt->n_names; k++)
         if (opt->names[k].name_len > 16 || opt->names[k].udn_len > 63) return fail(h, NFAGG_EINVAL, "namer row %u: name/udn too long", k);
+    PbFeat F{};
+    if (feat) {
+        if (feat->struct_size != sizeof(nfagg_pb_features)) return fail(h, NFAGG_EINVAL, "nfagg_pb_features.struct_size mismatch");
+        if ((((uintptr_t)feat->additional | (uintptr_t)feat->dns | (uintptr_t)feat->drops | (uintptr_t)feat->xlat | (uintptr_t)feat->quic) & 7u) != 0)
+            return fail(h, NFAGG_EINVAL, "feature arrays must be 8-byte aligned");
+        F.present = feat->present;
+        F.additional = (const uint8_t*)feat->additional; F.dns = (const uint8_t*)feat->dns; F.drops = (const uint8_t*)feat->drops;
+        F.xlat = (const uint8_t*)feat->xlat; F.quic = (const uint8_t*)feat->quic;
+    }
     HIP_TRY(h, hipSetDevice(h->device));
     *out_bytes = 0;
     if (n == 0) { HIP_TRY(h, hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), h->stream)); HIP_TRY(h, hipStreamSynchronize(h->stream)); return NFAGG_OK; }
@@ -759,23 +769,25 @@ int nfagg_encode_pb_device(nfagg_handle* h, const void* d_records, size_t n, con
     P.agent_is_v4 = memcmp(opt->agent_ip, v4pre, 12) == 0;     // net.IP.To4() != nil (proto.go:255-261)
     P.names = (const nfagg_intf_name*)h->d_pb[3]; P.n_names = opt->n_names;
     P.unknown_len = opt->unknown_len; memcpy(P.unknown, opt->unknown_name, 16);
-    hipError_t e = launch_pb_size(d_records, n, P, d_body_len, (uint32_t*)h->d_pb[0], (uint32_t*)h->d_pb[1], (uint64_t*)h->d_pb[2], h->stream);
+    hipError_t e = launch_pb_size(d_records, n, P, F, d_body_len, (uint32_t*)h->d_pb[0], (uint32_t*)h->d_pb[1], (uint64_t*)h->d_pb[2], h->stream);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "protobuf size launch failed: %s", hipGetErrorString(e));
     uint64_t total = 0;
     HIP_TRY(h, hipMemcpyAsync(&total, (uint64_t*)h->d_pb[2] + blocks, sizeof total, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     *out_bytes = (size_t)total;
     if (total > out_cap || !d_out) return NFAGG_TRUNCATED;
-    e = launch_pb_write(d_records, n, P, d_body_len, (const uint32_t*)h->d_pb[0], (const uint64_t*)h->d_pb[2], d_out, d_frame_offsets, d_kafka_keys, h->stream);
+    e = launch_pb_write(d_records, n, P, F, d_body_len, (const uint32_t*)h->d_pb[0], (const uint64_t*)h->d_pb[2], d_out, d_frame_offsets, d_kafka_keys, h->stream);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "protobuf encode launch failed: %s", hipGetErrorString(e));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NFAGG_OK;
 }
 
-int nfagg_encode_pb(nfagg_handle* h, const void* records, size_t n, const nfagg_pb_options* opt,
-                    void* out, size_t out_cap, uint64_t* frame_offsets, uint32_t* body_len,
-                    void* kafka_keys, size_t* out_bytes) {
+// feat (optional): HOST pointers
+static int encode_pb_host_core(nfagg_handle* h, const void* records, size_t n, const nfagg_pb_features* feat, const nfagg_pb_options* opt,
+                               void* out, size_t out_cap, uint64_t* frame_offsets, uint32_t* body_len,
+                               void* kafka_keys, size_t* out_bytes) {
     if (!h || !opt || !out_bytes || !frame_offsets || (n && (!records || !body_len))) return fail(h, NFAGG_EINVAL, "null argument");
+    if (feat && feat->struct_size != sizeof(nfagg_pb_features)) return fail(h, NFAGG_EINVAL, "nfagg_pb_features.struct_size mismatch");
     HIP_TRY(h, hipSetDevice(h->device));
     int rc;
     if ((rc = ensure_bytes(h, &h->d_pb[4], &h->d_pb_cap[4], n * kRecordBytes + 16)) != NFAGG_OK) return rc;
@@ -784,8 +796,25 @@ int nfagg_encode_pb(nfagg_handle* h, const void* records, size_t n, const nfagg_
     if ((rc = ensure_bytes(h, &h->d_pb[7], &h->d_pb_cap[7], (n + 1) * sizeof(uint32_t))) != NFAGG_OK) return rc;
     if (kafka_keys && (rc = ensure_bytes(h, &h->d_pb[8], &h->d_pb_cap[8], n * 32 + 32)) != NFAGG_OK) return rc;
     if (n) HIP_TRY(h, hipMemcpyAsync(h->d_pb[4], records, n * kRecordBytes, hipMemcpyHostToDevice, h->stream));
-    rc = nfagg_encode_pb_device(h, h->d_pb[4], n, opt, out ? h->d_pb[5] : nullptr, out_cap, (uint64_t*)h->d_pb[6], (uint32_t*)h->d_pb[7],
-                                kafka_keys ? h->d_pb[8] : nullptr, out_bytes);
+    nfagg_pb_features dfeat{};
+    if (feat && n) {
+        dfeat.struct_size = sizeof dfeat;
+        const void* src[6] = {feat->present, feat->additional, feat->dns, feat->drops, feat->xlat, feat->quic};
+        const size_t elem[6] = {1, sizeof(nfagg_additional_metrics), sizeof(nfagg_dns_metrics), sizeof(nfagg_pkt_drop_metrics),
+                                sizeof(nfagg_xlat_metrics), sizeof(nfagg_quic_metrics)};
+        void* dst[6] = {};
+        for (int k = 0; k < 6; k++) {
+            if (!src[k]) continue;
+            if ((rc = ensure_bytes(h, &h->d_pb[9 + k], &h->d_pb_cap[9 + k], n * elem[k] + 16)) != NFAGG_OK) return rc;
+            HIP_TRY(h, hipMemcpyAsync(h->d_pb[9 + k], src[k], n * elem[k], hipMemcpyHostToDevice, h->stream));
+            dst[k] = h->d_pb[9 + k];
+        }
+        dfeat.present = (const uint8_t*)dst[0]; dfeat.additional = (const nfagg_additional_metrics*)dst[1];
+        dfeat.dns = (const nfagg_dns_metrics*)dst[2]; dfeat.drops = (const nfagg_pkt_drop_metrics*)dst[3];
+        dfeat.xlat = (const nfagg_xlat_metrics*)dst[4]; dfeat.quic = (const nfagg_quic_metrics*)dst[5];
+    }
+    rc = encode_pb_device_core(h, h->d_pb[4], n, (feat && n) ? &dfeat : nullptr, opt, out ? h->d_pb[5] : nullptr, out_cap,
+                               (uint64_t*)h->d_pb[6], (uint32_t*)h->d_pb[7], kafka_keys ? h->d_pb[8] : nullptr, out_bytes);
     if (rc != NFAGG_OK) return rc;
     if (*out_bytes) HIP_TRY(h, hipMemcpyAsync(out, h->d_pb[5], *out_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(frame_offsets, h->d_pb[6], (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
@@ -793,6 +822,32 @@ int nfagg_encode_pb(nfagg_handle* h, const void* records, size_t n, const nfagg_
     if (n && kafka_keys) HIP_TRY(h, hipMemcpyAsync(kafka_keys, h->d_pb[8], n * 32, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NFAGG_OK;
+}
+
+int nfagg_encode_pb_device(nfagg_handle* h, const void* d_records, size_t n, const nfagg_pb_options* opt,
+                           void* d_out, size_t out_cap, uint64_t* d_frame_offsets, uint32_t* d_body_len,
+                           void* d_kafka_keys, size_t* out_bytes) {
+    return encode_pb_device_core(h, d_records, n, nullptr, opt, d_out, out_cap, d_frame_offsets, d_body_len, d_kafka_keys, out_bytes);
+}
+
+int nfagg_encode_pb(nfagg_handle* h, const void* records, size_t n, const nfagg_pb_options* opt,
+                    void* out, size_t out_cap, uint64_t* frame_offsets, uint32_t* body_len,
+                    void* kafka_keys, size_t* out_bytes) {
+    return encode_pb_host_core(h, records, n, nullptr, opt, out, out_cap, frame_offsets, body_len, kafka_keys, out_bytes);
+}
+
+int nfagg_encode_pb_content_device(nfagg_handle* h, const void* d_records, size_t n, const nfagg_pb_features* d_features,
+                                   const nfagg_pb_options* opt, void* d_out, size_t out_cap, uint64_t* d_frame_offsets,
+                                   uint32_t* d_body_len, void* d_kafka_keys, size_t* out_bytes) {
+    if (!d_features) return fail(h, NFAGG_EINVAL, "null features (use nfagg_encode_pb_device)");
+    return encode_pb_device_core(h, d_records, n, d_features, opt, d_out, out_cap, d_frame_offsets, d_body_len, d_kafka_keys, out_bytes);
+}
+
+int nfagg_encode_pb_content(nfagg_handle* h, const void* records, size_t n, const nfagg_pb_features* features,
+                            const nfagg_pb_options* opt, void* out, size_t out_cap, uint64_t* frame_offsets,
+                            uint32_t* body_len, void* kafka_keys, size_t* out_bytes) {
+    if (!features) return fail(h, NFAGG_EINVAL, "null features (use nfagg_encode_pb)");
+    return encode_pb_host_core(h, records, n, features, opt, out, out_cap, frame_offsets, body_len, kafka_keys, out_bytes);
 }
 
 // Diagnostics (not part of the drop-in ABI): per-phase wave-cycle sums of ingest_variant 6.

@@ -12,10 +12,15 @@
 // Network, Transport, both Timestamps, agent_ip, time_flow_rtt = durationpb.New(0) -> empty message),
 // oneof members emitted even at their zero value (IP.ipv4 = 0).
 //
-// Byte-granular, HBM-bound streaming work: 144 B read + ~150 B written per record. Three
-// kernels: sizes + block-local scan, scan of the block sums, encode. A wave encodes its 64
-// records into LDS at their final relative byte positions (consecutive records are contiguous
-// in the output) and then copies the packed range out with aligned 16-byte stores.
+// With a PbFeat the same kernels encode the MapTracer branch (pkg/flow/tracer_map.go:103-146): the
+// full model.BpfFlowContent — DNS, packet drops, xlat, RTT/IPsec, QUIC (proto.go:79-118,129-138;
+// record.go:116-125) — with a nil SampleDecoder (record.go:126): network events are not decoded.
+//
+// Byte-granular, HBM-bound streaming work: 144 B read + ~110 B written per record (more with
+// features). Three kernels: sizes + block-local scan, scan of the block sums, encode. A wave
+// encodes its 64 records into LDS at their final relative byte positions (consecutive records are
+// contiguous in the output), one 16 KiB window of the output at a time, and copies each window out
+// with aligned 16-byte stores.
 #include "nfagg_device.h"
 #include "nfagg_pb.h"
 
@@ -26,9 +31,13 @@ struct CountSink {
     uint32_t n = 0;
     NF_DEV void put(uint8_t) { n++; }
 };
-struct ByteSink {
-    uint8_t* p;
-    NF_DEV void put(uint8_t b) { *p++ = b; }
+// Writes only the bytes whose position (relative to the wave's LDS image) falls into [lo, lo + len):
+// a frame that straddles two windows is encoded once per window.
+struct WindowSink {
+    uint8_t* lds;      // window base
+    uint32_t pos;      // position of the next byte in the wave image
+    uint32_t lo, len;
+    NF_DEV void put(uint8_t b) { const uint32_t k = pos - lo; if (k < len) lds[k] = b; pos++; }
 };
 
 NF_DEV uint32_t varint_len(uint64_t v) {
@@ -108,8 +117,48 @@ NF_DEV uint64_t mac_be(uint64_t mac_le48) {   // Rec::smac() holds byte 0 in the
     return v;
 }
 
-// The body of pbflow.Record for one evicted record. Same code sizes (CountSink) and writes (ByteSink).
-template <typename S> NF_DEV void encode_record(S& s, const Rec& r, const PbParams& P) {
+// google.protobuf.Duration = durationpb.New(time.Duration(d)): secs = d / 1e9 truncating, nanos = d - secs*1e9,
+// both carry the sign; Nanos is an int32 (a negative one is sign-extended to a ten-byte varint).
+template <typename S> NF_DEV void put_duration(S& s, uint32_t field, uint64_t d_u) {
+    const int64_t d = (int64_t)d_u, secs = d / 1000000000ll;
+    const uint64_t nanos = (uint64_t)(int64_t)(int32_t)(d - secs * 1000000000ll);
+    put_tag(s, field, 2);
+    s.put((uint8_t)(uint_len(1, (uint64_t)secs) + uint_len(2, nanos)));
+    put_uint(s, 1, (uint64_t)secs);
+    put_uint(s, 2, nanos);
+}
+
+// utils.DNSRawNameToDotted (pkg/utils/utils.go:18-58) over the 32-byte kernel copy at `raw` (global memory):
+// bytes up to the first NUL, label by label; stops at a zero length, a compression pointer, or a label that
+// runs past the end. EMIT = false only measures.
+template <bool EMIT, typename S> NF_DEV uint32_t dns_dotted(S& s, const uint8_t* __restrict__ raw) {
+    uint32_t nb = 0;
+    while (nb < 32 && raw[nb] != 0) nb++;
+    uint32_t i = 0, out = 0;
+    while (i < nb) {
+        const uint32_t l = raw[i];
+        if (l == 0 || (l & 0xC0u) == 0xC0u) break;
+        i++;
+        if (i + l > nb) break;
+        if (out) { if (EMIT) s.put('.'); out++; }
+        if (EMIT) for (uint32_t k = 0; k < l; k++) s.put(raw[i + k]);
+        out += l; i += l;
+    }
+    return out;
+}
+
+NF_DEV uint32_t ld32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+NF_DEV uint64_t ld64(const uint8_t* p) { return *reinterpret_cast<const uint64_t*>(p); }
+
+// The body of pbflow.Record for one flow: evicted record `r`, plus the feature parts of flow `i` when
+// F carries them. Same code sizes (CountSink) and writes (WindowSink).
+template <typename S> NF_DEV void encode_record(S& s, const Rec& r, const PbParams& P, const PbFeat& F, uint64_t i) {
+    const uint32_t have = F.present ? F.present[i] : 0u;
+    const uint8_t* add = (F.additional && (have & 1u)) ? F.additional + i * 32 : nullptr;
+    const uint8_t* dns = (F.dns && (have & 2u)) ? F.dns + i * 64 : nullptr;
+    const uint8_t* drp = (F.drops && (have & 4u)) ? F.drops + i * 32 : nullptr;
+    const uint8_t* xlt = (F.xlat && (have & 16u)) ? F.xlat + i * 56 : nullptr;
+    const uint8_t* quc = (F.quic && (have & 32u)) ? F.quic + i * 24 : nullptr;
     const uint32_t eth = r.eth();
     const uint32_t dirn = r.d[24] & 0xffu;
     put_uint(s, 1, eth);
@@ -140,7 +189,20 @@ template <typename S> NF_DEV void encode_record(S& s, const Rec& r, const PbPara
     put_uint(s, 13, r.flags());
     put_uint(s, 14, (r.d[9] >> 8) & 0xffu);      // icmp_type
     put_uint(s, 15, (r.d[9] >> 16) & 0xffu);     // icmp_code
-    put_tag(s, 24, 2); s.put(0);                 // time_flow_rtt = durationpb.New(0)
+    if (drp) {                                   // proto.go:92-98
+        const uint32_t bp = ld32(drp + 16), fe = ld32(drp + 24);
+        put_uint(s, 16, bp & 0xffffu); put_uint(s, 17, bp >> 16);
+        put_uint(s, 18, fe & 0xffffu); put_uint(s, 19, drp[28]);
+        put_uint(s, 20, ld32(drp + 20));
+    }
+    if (dns) {                                   // proto.go:79-91, record.go:116-120
+        const uint32_t idf = ld32(dns + 24);
+        put_uint(s, 21, idf & 0xffffu); put_uint(s, 22, idf >> 16);
+        const uint64_t lat = ld64(dns + 16);
+        if (lat) put_duration(s, 23, lat);
+    }
+    put_duration(s, 24, add ? ld64(add + 16) : 0ull);   // time_flow_rtt = durationpb.New(fr.TimeFlowRtt): always present
+    if (dns) put_uint(s, 25, dns[30]);
     {   // dup_list = record.Interfaces (record.go:100-114)
         const uint64_t lmac = mac_be(dirn == 0 ? r.dmac() : r.smac());
         put_dup(s, P, r.d[21], lmac, dirn);
@@ -153,18 +215,42 @@ template <typename S> NF_DEV void encode_record(S& s, const Rec& r, const PbPara
             put_dup(s, P, oi, lmac, od);
         }
     }
+    if (xlt) {                                   // proto.go:99-105,129-138: address family by the FLOW's eth_protocol
+        const bool v6 = eth == 0x86DDu;
+        const uint32_t sd = ld32(xlt + 48), ze = ld32(xlt + 52);
+        const uint32_t ipl = v6 ? 20 : 7;
+        put_tag(s, 28, 2);
+        s.put((uint8_t)(2 * ipl + uint_len(3, sd & 0xffffu) + uint_len(4, sd >> 16) + uint_len(5, ze & 0xffffu)));
+        put_ip(s, 1, xlt + 16, v6); put_ip(s, 2, xlt + 32, v6);
+        put_uint(s, 3, sd & 0xffffu); put_uint(s, 4, sd >> 16); put_uint(s, 5, ze & 0xffffu);
+    }
     put_uint(s, 29, r.sampling());
+    if (add) {                                   // proto.go:106-111
+        put_uint(s, 30, add[30] ? 1u : 0u);
+        put_uint(s, 31, (uint64_t)(int64_t)(int32_t)ld32(add + 24));
+    }
+    if (dns) {                                   // dns_name = 32
+        CountSink c;
+        const uint32_t nl = dns_dotted<false>(c, dns + 31);
+        if (nl) { put_tag(s, 32, 2); s.put((uint8_t)nl); dns_dotted<true>(s, dns + 31); }
+    }
     put_uint(s, 33, r.d[33] & 0xffffu);          // ssl_version
     put_uint(s, 34, (r.d[34] >> 24) & 1u);       // HasSSLMismatch (record.go:255-257)
     put_uint(s, 35, (r.d[34] >> 16) & 0xffu);    // tls_types
     put_uint(s, 36, r.d[33] >> 16);              // tls_cipher_suite
     put_uint(s, 37, r.d[34] & 0xffffu);          // tls_key_share
+    if (quc) {                                   // proto.go:112-118
+        const uint32_t ver = ld32(quc + 16);
+        put_tag(s, 38, 2);
+        s.put((uint8_t)(uint_len(1, ver) + uint_len(2, quc[22]) + uint_len(3, quc[23])));
+        put_uint(s, 1, ver); put_uint(s, 2, quc[22]); put_uint(s, 3, quc[23]);
+    }
 }
 
 constexpr int kScanBlock = 1024;
 
 // ---- kernel 1: body length per record, frame length, block-local exclusive scan of the frame lengths
-__global__ __launch_bounds__(kScanBlock) void k_pb_size(const void* __restrict__ recs, uint64_t n, PbParams P,
+__global__ __launch_bounds__(kScanBlock) void k_pb_size(const void* __restrict__ recs, uint64_t n, PbParams P, PbFeat F,
                                                         uint32_t* __restrict__ body_len, uint32_t* __restrict__ local_off,
                                                         uint32_t* __restrict__ block_sum) {
     __shared__ uint32_t wave_tot[kScanBlock / 64];
@@ -175,7 +261,7 @@ __global__ __launch_bounds__(kScanBlock) void k_pb_size(const void* __restrict__
         load_record(recs, i, r);
         r.canonicalize();
         CountSink c;
-        encode_record(c, r, P);
+        encode_record(c, r, P, F, i);
         body_len[i] = c.n;
         frame = 1 + varint_len(c.n) + c.n;
     }
@@ -208,30 +294,27 @@ __global__ __launch_bounds__(1024) void k_pb_scan_blocks(const uint32_t* __restr
     for (uint32_t k = lo; k < hi; k++) { block_base[k] = acc; acc += block_sum[k]; }
 }
 
-// ---- kernel 3: encode. One wave per 64 consecutive records.
-constexpr int kPbMaxFrame = 832;   // upper bound of one frame, multiple of 16
+// ---- kernel 3: encode. One wave per 64 consecutive records, one kPbWindow-byte window of its output at a time.
+constexpr uint32_t kPbWindow = 16384;   // LDS per wave: ten waves per CU; 64 typical frames (~110 B) fit one window
+constexpr uint32_t kPbMaxFrame = 1040;  // upper bound of one frame: 64 of them span at most five windows
 
-__global__ __launch_bounds__(64) void k_pb_write(const void* __restrict__ recs, uint64_t n, PbParams P,
+__global__ __launch_bounds__(64) void k_pb_write(const void* __restrict__ recs, uint64_t n, PbParams P, PbFeat F,
                                                  const uint32_t* __restrict__ body_len, const uint32_t* __restrict__ local_off,
                                                  const uint64_t* __restrict__ block_base, uint8_t* __restrict__ out,
                                                  uint64_t* __restrict__ frame_offsets, uint8_t* __restrict__ kafka_keys) {
-    extern __shared__ __align__(16) unsigned char lds[];
+    __shared__ __align__(16) unsigned char lds[kPbWindow];
     const uint64_t i0 = (uint64_t)blockIdx.x * 64, i = i0 + threadIdx.x;
     const uint64_t wave_base = block_base[i0 / kScanBlock] + local_off[i0];
-    const uint32_t shift = (uint32_t)(wave_base & 15);       // LDS image has the alignment of the destination
-    uint64_t my_off = 0; uint32_t my_len = 0;
+    const uint32_t shift = (uint32_t)(wave_base & 15);       // the LDS image has the alignment of the destination
+    uint64_t my_off = 0; uint32_t my_len = 0, bl = 0;
+    Rec r;
     if (i < n) {
-        Rec r;
         load_record(recs, i, r);
         r.canonicalize();
         my_off = block_base[i / kScanBlock] + local_off[i];
-        const uint32_t bl = body_len[i];
+        bl = body_len[i];
         my_len = 1 + varint_len(bl) + bl;
         frame_offsets[i] = my_off;
-        ByteSink s{lds + shift + (uint32_t)(my_off - wave_base)};
-        s.put(0x0A);                                          // Records.entries = 1, length-delimited
-        put_varint(s, bl);
-        encode_record(s, r, P);
         if (kafka_keys) {
             // getFlowKey (kafka_proto.go:37-47): the two 16-byte addresses, the smaller one first
             int c = 0;
@@ -249,44 +332,45 @@ __global__ __launch_bounds__(64) void k_pb_write(const void* __restrict__ recs, 
     uint64_t end = my_off + my_len;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const uint64_t o = __shfl_xor(end, d, 64); end = o > end ? o : end; }
-    __syncthreads();
-    const uint32_t total = (uint32_t)(end - wave_base);
-    uint8_t* dst = out + (wave_base - shift);                 // 16-byte aligned
-    const uint32_t span = shift + total;                      // image bytes [shift, span)
-    for (uint32_t c = threadIdx.x * 16; c < span; c += 64 * 16) {
-        if (c >= shift && c + 16 <= span) {
-            *reinterpret_cast<uint4*>(dst + c) = *reinterpret_cast<const uint4*>(lds + c);
-        } else {
-            for (uint32_t b = c < shift ? shift : c; b < c + 16 && b < span; b++) dst[b] = lds[b];
+    const uint32_t span = shift + (uint32_t)(end - wave_base);   // image bytes [shift, span)
+    const uint32_t p0 = shift + (uint32_t)(my_off - wave_base);  // my frame = image bytes [p0, p0 + my_len)
+    uint8_t* dst = out + (wave_base - shift);                     // 16-byte aligned
+    for (uint32_t lo = 0; lo < span; lo += kPbWindow) {
+        const uint32_t hi = lo + kPbWindow < span ? lo + kPbWindow : span;
+        if (my_len && p0 < hi && p0 + my_len > lo) {
+            WindowSink s{lds, p0, lo, hi - lo};
+            s.put(0x0A);                                          // Records.entries = 1, length-delimited
+            put_varint(s, bl);
+            encode_record(s, r, P, F, i);
         }
+        __syncthreads();
+        for (uint32_t c = lo + threadIdx.x * 16; c < hi; c += 64 * 16) {
+            if (c >= shift && c + 16 <= hi) {
+                *reinterpret_cast<uint4*>(dst + c) = *reinterpret_cast<const uint4*>(lds + (c - lo));
+            } else {
+                for (uint32_t b = c < shift ? shift : c; b < c + 16 && b < hi; b++) dst[b] = lds[b - lo];
+            }
+        }
+        __syncthreads();
     }
 }
 
-hipError_t launch_pb_size(const void* d_recs, uint64_t n, const PbParams& P, uint32_t* d_body_len, uint32_t* d_local_off,
+hipError_t launch_pb_size(const void* d_recs, uint64_t n, const PbParams& P, const PbFeat& F, uint32_t* d_body_len, uint32_t* d_local_off,
                           uint32_t* d_block_sum, uint64_t* d_block_base, hipStream_t s) {
     const uint32_t blocks = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_pb_size, dim3(blocks), dim3(kScanBlock), 0, s, d_recs, n, P, d_body_len, d_local_off, d_block_sum);
+    hipLaunchKernelGGL(k_pb_size, dim3(blocks), dim3(kScanBlock), 0, s, d_recs, n, P, F, d_body_len, d_local_off, d_block_sum);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pb_scan_blocks, dim3(1), dim3(1024), 0, s, d_block_sum, blocks, d_block_base);
     return hipGetLastError();
 }
 
-hipError_t launch_pb_write(const void* d_recs, uint64_t n, const PbParams& P, const uint32_t* d_body_len, const uint32_t* d_local_off,
+hipError_t launch_pb_write(const void* d_recs, uint64_t n, const PbParams& P, const PbFeat& F, const uint32_t* d_body_len, const uint32_t* d_local_off,
                            const uint64_t* d_block_base, void* d_out, uint64_t* d_frame_offsets, void* d_kafka_keys, hipStream_t s) {
-    const size_t lds = 16 + 64 * (size_t)kPbMaxFrame;
-    static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    bool& attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pb_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static_assert(64 * kPbMaxFrame + 16 <= 5 * kPbWindow, "window count bound");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_pb_write, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, s, d_recs, n, P, d_body_len, d_local_off, d_block_base,
+    hipLaunchKernelGGL(k_pb_write, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_recs, n, P, F, d_body_len, d_local_off, d_block_base,
                        (uint8_t*)d_out, d_frame_offsets, (uint8_t*)d_kafka_keys);
     return hipGetLastError();
 }

@@ -181,14 +181,41 @@ class FlowTable:
         o.unknown_name, o.unknown_len = unknown, len(unknown)
         return o, names
 
+    @staticmethod
+    def _pb_features(n, present, parts, device=False):
+        """nfagg_pb_features from `present` (n bytes of FEAT_* bits) and parts = {"additional"|"dns"|"drops"|"xlat"|"quic":
+        array of n structs}; with device=True the values are raw device pointers."""
+        f = L.PbFeatures()
+        f.struct_size = C.sizeof(L.PbFeatures)
+        keep = []
+        if device:
+            f.present = present or None
+            for k, v in parts.items():
+                setattr(f, k, v or None)
+            return f, keep
+        p = np.ascontiguousarray(present, dtype=np.uint8)
+        assert p.size == n
+        keep.append(p)
+        f.present = p.ctypes.data
+        for k, v in parts.items():
+            a = np.ascontiguousarray(v)
+            assert a.dtype == ROLLUP_KINDS[k] and len(a) == n, k
+            keep.append(a)
+            setattr(f, k, a.ctypes.data)
+        return f, keep
+
     def encode_pb(self, records: np.ndarray, now_unix_ns: int, mono_now_ns: int, agent_ip16: bytes, names: np.ndarray,
-                  unknown: bytes = b"unknown", kafka_keys=False):
+                  unknown: bytes = b"unknown", kafka_keys=False, present=None, parts=None):
         """FlowsToPB + proto.Marshal of evicted records on the GPU. Returns (buf, frame_offsets, body_len[, keys]):
         buf[frame_offsets[a]:frame_offsets[b]] is a serialized pbflow.Records of entries a..b-1; the last body_len[i]
-        bytes of frame i are the serialized pbflow.Record."""
+        bytes of frame i are the serialized pbflow.Record. With present/parts (see _pb_features) the flows are full
+        BpfFlowContents of the MapTracer branch (nfagg_encode_pb_content)."""
         r = np.ascontiguousarray(records)
         n = r.nbytes // 144
         o, keep = self._pb_options(now_unix_ns, mono_now_ns, agent_ip16, names, unknown)
+        feat = None
+        if present is not None:
+            feat, keep_f = self._pb_features(n, present, parts or {})
         off = np.zeros(n + 1, dtype=np.uint64)
         blen = np.zeros(max(n, 1), dtype=np.uint32)
         keys = np.zeros((max(n, 1), 32), dtype=np.uint8) if kafka_keys else None
@@ -196,9 +223,12 @@ class FlowTable:
         cap = max(256 * n, 64)
         while True:
             buf = np.zeros(cap, dtype=np.uint8)
-            rc = L.lib.nfagg_encode_pb(self._h, r.ctypes.data_as(C.c_void_p), n, C.byref(o), buf.ctypes.data_as(C.c_void_p), cap,
-                                       off.ctypes.data_as(C.c_void_p), blen.ctypes.data_as(C.c_void_p),
-                                       keys.ctypes.data_as(C.c_void_p) if kafka_keys else None, C.byref(need))
+            tail = (C.byref(o), buf.ctypes.data_as(C.c_void_p), cap, off.ctypes.data_as(C.c_void_p), blen.ctypes.data_as(C.c_void_p),
+                    keys.ctypes.data_as(C.c_void_p) if kafka_keys else None, C.byref(need))
+            if feat is None:
+                rc = L.lib.nfagg_encode_pb(self._h, r.ctypes.data_as(C.c_void_p), n, *tail)
+            else:
+                rc = L.lib.nfagg_encode_pb_content(self._h, r.ctypes.data_as(C.c_void_p), n, C.byref(feat), *tail)
             if rc == L.TRUNCATED:
                 cap = need.value
                 continue
@@ -209,13 +239,17 @@ class FlowTable:
 
     def encode_pb_device(self, d_records: int, n: int, now_unix_ns: int, mono_now_ns: int, agent_ip16: bytes, names: np.ndarray,
                          d_out: int, out_cap: int, d_frame_offsets: int, d_body_len: int, d_kafka_keys: int = 0,
-                         unknown: bytes = b"unknown"):
+                         unknown: bytes = b"unknown", d_present: int = 0, d_parts=None):
         """Device-resident variant (raw device pointers). Returns (rc, bytes needed/written)."""
         o, keep = self._pb_options(now_unix_ns, mono_now_ns, agent_ip16, names, unknown)
         need = C.c_size_t(0)
-        rc = L.lib.nfagg_encode_pb_device(self._h, C.c_void_p(d_records), n, C.byref(o), C.c_void_p(d_out or None), out_cap,
-                                          C.c_void_p(d_frame_offsets), C.c_void_p(d_body_len), C.c_void_p(d_kafka_keys or None),
-                                          C.byref(need))
+        tail = (C.byref(o), C.c_void_p(d_out or None), out_cap, C.c_void_p(d_frame_offsets), C.c_void_p(d_body_len),
+                C.c_void_p(d_kafka_keys or None), C.byref(need))
+        if d_present:
+            feat, _ = self._pb_features(n, d_present, d_parts or {}, device=True)
+            rc = L.lib.nfagg_encode_pb_content_device(self._h, C.c_void_p(d_records), n, C.byref(feat), *tail)
+        else:
+            rc = L.lib.nfagg_encode_pb_device(self._h, C.c_void_p(d_records), n, *tail)
         self._check(rc, ok=(L.OK, L.TRUNCATED))
         return rc, need.value
 

@@ -171,6 +171,11 @@ typedef struct {
 } orc_pb_options;
 /* Serialise pbflow.Record for one evicted flow into out (>= 1024 bytes); returns the length. */
 size_t orc_pb_encode_record(const orc_flow_record* r, const orc_pb_options* o, uint8_t* out);
+/* Same for the MapTracer branch: the full BpfFlowContent (DNS, drops, xlat, RTT/IPsec, QUIC;
+ * network events need the OVN sample decoder and are encoded as with a nil decoder, record.go:126). */
+size_t orc_pb_encode_content(const orc_flow_id* id, const orc_content* c, const orc_pb_options* o, uint8_t* out);
+/* pkg/utils/utils.go:18-58 DNSRawNameToDotted over the 32-byte kernel copy; out >= 32 bytes; returns the length */
+size_t orc_dns_name_dotted(const char raw[32], char* out);
 /* pkg/exporter/kafka_proto.go:37-47 getFlowKey: the two IPs, smaller first */
 void orc_kafka_key(const orc_flow_record* r, uint8_t out[32]);
 

@@ -74,8 +74,48 @@ static size_t enc_dup(uint8_t* buf, const orc_pb_options* o, uint32_t if_index, 
     return (size_t)(w.p - buf);
 }
 
+/* utils.DNSRawNameToDotted (pkg/utils/utils.go:18-58): bytes up to the first NUL, then label
+ * by label; stops at a zero length, a compression pointer, or a label that runs past the end. */
+size_t orc_dns_name_dotted(const char raw[32], char* out) {
+    uint8_t b[32]; size_t nb = 0, no = 0, i = 0; int first = 1;
+    while (nb < 32 && raw[nb] != 0) { b[nb] = (uint8_t)raw[nb]; nb++; }
+    while (i < nb) {
+        size_t l = b[i];
+        if (l == 0) break;
+        if ((l & 0xC0) == 0xC0) break;
+        i++;
+        if (i + l > nb) break;
+        if (!first) out[no++] = '.';
+        first = 0;
+        memcpy(out + no, b + i, l); no += l; i += l;
+    }
+    return no;
+}
+
+/* durationpb.New(d) (types/known/durationpb): secs = d / 1e9 (truncating), nanos = d - secs*1e9;
+ * Seconds int64 = 1, Nanos int32 = 2 (a negative int32 is sign-extended to a 10-byte varint). */
+static size_t enc_duration(uint8_t* buf, int64_t d) {
+    int64_t secs = d / 1000000000, nanos = d - secs * 1000000000;
+    wr w = { buf };
+    put_uint(&w, 1, (uint64_t)secs);
+    put_uint(&w, 2, (uint64_t)(int64_t)(int32_t)nanos);
+    return (size_t)(w.p - buf);
+}
+
+static size_t pb_encode(const orc_flow_id* id, const orc_flow_metrics* m, const orc_content* c, const orc_pb_options* o, uint8_t* out);
+
 size_t orc_pb_encode_record(const orc_flow_record* r, const orc_pb_options* o, uint8_t* out) {
-    const orc_flow_metrics* m = &r->metrics;
+    return pb_encode(&r->id, &r->metrics, 0, o, out);
+}
+
+/* The MapTracer branch (pkg/flow/tracer_map.go:103-146): NewRecord + FlowToPB over a full
+ * BpfFlowContent. The SampleDecoder is nil here (record.go:126 `s != nil &&`): network events are
+ * not decoded, field 27 stays empty and no drop is injected from them. */
+size_t orc_pb_encode_content(const orc_flow_id* id, const orc_content* c, const orc_pb_options* o, uint8_t* out) {
+    return pb_encode(id, &c->base, c, o, out);
+}
+
+static size_t pb_encode(const orc_flow_id* id, const orc_flow_metrics* m, const orc_content* c, const orc_pb_options* o, uint8_t* out) {
     wr w = { out };
     uint8_t t[128], u[64];
     size_t n;
@@ -92,13 +132,13 @@ size_t orc_pb_encode_record(const orc_flow_record* r, const orc_pb_options* o, u
     {   /* Network: addresses by eth_protocol (proto.go:125-139), dscp */
         const int v6 = m->eth_protocol == 0x86DD;   /* model.IPv6Type */
         wr x = { t };
-        n = enc_ip(u, r->id.src_ip, v6); put_msg(&x, 1, u, n);
-        n = enc_ip(u, r->id.dst_ip, v6); put_msg(&x, 2, u, n);
+        n = enc_ip(u, id->src_ip, v6); put_msg(&x, 1, u, n);
+        n = enc_ip(u, id->dst_ip, v6); put_msg(&x, 2, u, n);
         put_uint(&x, 3, m->dscp);
         put_msg(&w, 6, t, (size_t)(x.p - t));
     }
     {   /* Transport */
-        wr x = { t }; put_uint(&x, 1, r->id.src_port); put_uint(&x, 2, r->id.dst_port); put_uint(&x, 3, r->id.proto);
+        wr x = { t }; put_uint(&x, 1, id->src_port); put_uint(&x, 2, id->dst_port); put_uint(&x, 3, id->proto);
         put_msg(&w, 7, t, (size_t)(x.p - t));
     }
     put_uint(&w, 8, m->bytes);
@@ -109,10 +149,22 @@ size_t orc_pb_encode_record(const orc_flow_record* r, const orc_pb_options* o, u
         n = enc_ip(t, o->agent_ip, !is4); put_msg(&w, 12, t, n);
     }
     put_uint(&w, 13, m->flags);
-    put_uint(&w, 14, r->id.icmp_type);
-    put_uint(&w, 15, r->id.icmp_code);
-    /* 16-23: no feature metrics on the Accounter path (pointers nil) */
-    put_msg(&w, 24, t, 0);                          /* time_flow_rtt = durationpb.New(0): present, empty */
+    put_uint(&w, 14, id->icmp_type);
+    put_uint(&w, 15, id->icmp_code);
+    if (c && c->has_drops) {                        /* proto.go:92-98 */
+        put_uint(&w, 16, c->drops.bytes); put_uint(&w, 17, c->drops.packets);
+        put_uint(&w, 18, c->drops.latest_flags); put_uint(&w, 19, c->drops.latest_state);
+        put_uint(&w, 20, c->drops.latest_drop_cause);
+    }
+    if (c && c->has_dns) {                          /* proto.go:79-91 */
+        put_uint(&w, 21, c->dns.id); put_uint(&w, 22, c->dns.flags);
+        if (c->dns.latency != 0) { n = enc_duration(t, (int64_t)c->dns.latency); put_msg(&w, 23, t, n); }   /* record.go:116-120 */
+    }
+    {   /* time_flow_rtt = durationpb.New(fr.TimeFlowRtt): always present; record.go:121-125 */
+        int64_t rtt = (c && c->has_additional) ? (int64_t)c->additional.flow_rtt : 0;
+        n = enc_duration(t, rtt); put_msg(&w, 24, t, n);
+    }
+    if (c && c->has_dns) put_uint(&w, 25, c->dns.err_no);
     {   /* dup_list from record.Interfaces (record.go:100-114) */
         const uint8_t* lmac = m->direction_first_seen == 0 ? m->dst_mac : m->src_mac;
         n = enc_dup(t, o, m->if_index_first_seen, lmac, m->direction_first_seen); put_msg(&w, 26, t, n);
@@ -121,12 +173,34 @@ size_t orc_pb_encode_record(const orc_flow_record* r, const orc_pb_options* o, u
             n = enc_dup(t, o, m->observed_intf[k], lmac, m->observed_direction[k]); put_msg(&w, 26, t, n);
         }
     }
+    if (c && c->has_xlat) {                         /* proto.go:99-105,129-138: addresses by the FLOW's eth_protocol */
+        const int v6 = m->eth_protocol == 0x86DD;
+        wr x = { t };
+        n = enc_ip(u, c->xlat.saddr, v6); put_msg(&x, 1, u, n);
+        n = enc_ip(u, c->xlat.daddr, v6); put_msg(&x, 2, u, n);
+        put_uint(&x, 3, c->xlat.sport); put_uint(&x, 4, c->xlat.dport); put_uint(&x, 5, c->xlat.zone_id);
+        put_msg(&w, 28, t, (size_t)(x.p - t));
+    }
     put_uint(&w, 29, m->sampling);
+    if (c && c->has_additional) {                   /* proto.go:106-111 */
+        put_uint(&w, 30, c->additional.ipsec_encrypted ? 1 : 0);
+        put_uint(&w, 31, (uint64_t)(int64_t)c->additional.ipsec_ret);   /* int32: negative -> 10 bytes */
+    }
+    if (c && c->has_dns) {
+        char name[64];
+        size_t nl = orc_dns_name_dotted(c->dns.name, name);
+        if (nl) put_bytes(&w, 32, name, nl);
+    }
     put_uint(&w, 33, m->ssl_version);
     put_uint(&w, 34, (m->misc_flags & 1) ? 1 : 0);  /* HasSSLMismatch (record.go:255-257) */
     put_uint(&w, 35, m->tls_types);
     put_uint(&w, 36, m->tls_cipher_suite);
     put_uint(&w, 37, m->tls_key_share);
+    if (c && c->has_quic) {                         /* proto.go:112-118 */
+        wr x = { t };
+        put_uint(&x, 1, c->quic.version); put_uint(&x, 2, c->quic.seen_long_hdr); put_uint(&x, 3, c->quic.seen_short_hdr);
+        put_msg(&w, 38, t, (size_t)(x.p - t));
+    }
     return (size_t)(w.p - out);
 }
 

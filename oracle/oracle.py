@@ -54,6 +54,7 @@ def lib():
             "orc_stream_key_index": (_u64, [_u64, _u64, _u64, _vp, C.c_uint32]),
             "orc_gen_stream": (None, [_u64, _u64, _sz, _u64, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
             "orc_pb_encode_record": (_sz, [_vp, _vp, _vp]), "orc_kafka_key": (None, [_vp, _vp]),
+            "orc_pb_encode_content": (_sz, [_vp, _vp, _vp, _vp]), "orc_dns_name_dotted": (_sz, [_vp, _vp]),
         }
         for name, (res, args) in sig.items():
             f = getattr(l, name)
@@ -239,6 +240,26 @@ def pb_encode(records, opts):
         n = lib().orc_pb_encode_record(raw[k].ctypes.data_as(C.c_void_p), C.byref(opts), buf)
         out.append(bytes(buf[:n]))
     return out
+
+
+def pb_encode_contents(ids, contents, opts):
+    """Serialized pbflow.Record of every (flow id, BpfFlowContent) pair — the MapTracer branch."""
+    i = np.ascontiguousarray(ids).view(np.uint8).reshape(-1, 40)
+    c = np.ascontiguousarray(contents).view(np.uint8).reshape(len(i), -1)
+    assert c.shape[1] == CONTENT.itemsize
+    buf = (C.c_uint8 * 2048)()
+    out = []
+    for k in range(len(i)):
+        n = lib().orc_pb_encode_content(i[k].ctypes.data_as(C.c_void_p), c[k].ctypes.data_as(C.c_void_p), C.byref(opts), buf)
+        out.append(bytes(buf[:n]))
+    return out
+
+
+def dns_name_dotted(raw32: bytes) -> bytes:
+    raw = (bytes(raw32) + bytes(32))[:32]
+    out = C.create_string_buffer(64)
+    n = lib().orc_dns_name_dotted(raw, out)
+    return out.raw[:n]
 
 
 def kafka_keys(records):

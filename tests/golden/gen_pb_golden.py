@@ -113,9 +113,39 @@ def i64(u):
     return u - (1 << 64) if u >= (1 << 63) else u
 
 
-def flow_to_pb(Record, rec, now_unix_ns, mono_now, agent_ip16, namer):
-    """NewRecord + FlowToPB for one evicted flow_record_t (numpy void of oracle.FLOW_RECORD)."""
+def dns_raw_name_to_dotted(raw):
+    """utils.DNSRawNameToDotted (pkg/utils/utils.go:18-58), written from the Go text."""
+    b = bytes(raw)
+    b = b[:b.index(0)] if 0 in b else b
+    out, i, first = b"", 0, True
+    while i < len(b):
+        l = b[i]
+        if l == 0 or (l & 0xC0) == 0xC0:
+            break
+        i += 1
+        if i + l > len(b):
+            break
+        out += (b"" if first else b".") + b[i:i + l]
+        first = False
+        i += l
+    return out
+
+
+def duration_new(pbdur, d):
+    """durationpb.New(time.Duration(d)): truncating division, both parts carry the sign."""
+    d = i64(d)
+    secs = abs(d) // 10**9 * (1 if d >= 0 else -1)
+    pbdur.SetInParent()
+    pbdur.seconds, pbdur.nanos = secs, d - secs * 10**9
+
+
+def flow_to_pb(Record, rec, now_unix_ns, mono_now, agent_ip16, namer, content=None):
+    """NewRecord + FlowToPB for one evicted flow_record_t (numpy void of oracle.FLOW_RECORD); with
+    `content` (numpy void of oracle.CONTENT) the MapTracer branch: rec["id"] + the full BpfFlowContent,
+    SampleDecoder nil (network events not decoded, record.go:126)."""
     k, m = rec["id"], rec["metrics"]
+    if content is not None:
+        m = content["base"]
     pb = Record()
     pb.eth_protocol = int(m["eth_protocol"])
     pb.direction = int(m["direction_first_seen"])
@@ -139,6 +169,39 @@ def flow_to_pb(Record, rec, now_unix_ns, mono_now, agent_ip16, namer):
         pb.agent_ip.ipv6 = ip
     pb.flags = int(m["flags"])
     pb.time_flow_rtt.SetInParent()                           # durationpb.New(0)
+    c = content
+    if c is not None:
+        if c["has_additional"]:
+            duration_new(pb.time_flow_rtt, int(c["additional"]["flow_rtt"]))       # record.go:121-125: != 0 -> copy; New(0) is the same message
+            pb.ipsec_encrypted_ret = int(c["additional"]["ipsec_ret"])
+            if c["additional"]["ipsec_encrypted"]:
+                pb.ipsec_encrypted = 1
+        if c["has_dns"]:
+            d = c["dns"]
+            pb.dns_id, pb.dns_flags, pb.dns_errno = int(d["id"]), int(d["flags"]), int(d["err_no"])
+            name = dns_raw_name_to_dotted(d["name"])
+            if name:
+                pb.dns_name = name.decode("utf-8")
+            if int(d["latency"]) != 0:
+                duration_new(pb.dns_latency, int(d["latency"]))
+        if c["has_drops"]:
+            d = c["drops"]
+            pb.pkt_drop_bytes, pb.pkt_drop_packets = int(d["bytes"]), int(d["packets"])
+            pb.pkt_drop_latest_flags, pb.pkt_drop_latest_state = int(d["latest_flags"]), int(d["latest_state"])
+            pb.pkt_drop_latest_drop_cause = int(d["latest_drop_cause"])
+        if c["has_xlat"]:
+            x = c["xlat"]
+            pb.xlat.SetInParent()
+            pb.xlat.src_port, pb.xlat.dst_port, pb.xlat.zone_id = int(x["sport"]), int(x["dport"]), int(x["zone_id"])
+            if int(m["eth_protocol"]) == 0x86DD:
+                pb.xlat.src_addr.ipv6, pb.xlat.dst_addr.ipv6 = bytes(x["saddr"]), bytes(x["daddr"])
+            else:
+                pb.xlat.src_addr.ipv4 = int.from_bytes(bytes(x["saddr"])[12:], "big")
+                pb.xlat.dst_addr.ipv4 = int.from_bytes(bytes(x["daddr"])[12:], "big")
+        if c["has_quic"]:
+            q = c["quic"]
+            pb.quic.SetInParent()
+            pb.quic.version, pb.quic.seen_long_hdr, pb.quic.seen_short_hdr = int(q["version"]), int(q["seen_long_hdr"]), int(q["seen_short_hdr"])
     pb.sampling = int(m["sampling"])
     pb.ssl_version, pb.tls_types = int(m["ssl_version"]), int(m["tls_types"])
     pb.tls_cipher_suite, pb.tls_key_share = int(m["tls_cipher_suite"]), int(m["tls_key_share"])
@@ -182,6 +245,49 @@ def namer_from(rows, unknown="unknown"):
     return f
 
 
+DNS_NAMES = [  # label-encoded kernel copies, incl. the inputs of pkg/decode/decode_protobuf_test.go (DNSRawNameToDotted cases)
+    b"\x03www\x07example\x03com\x00", b"\x00\x03abc\x00", b"\x03ab\x00\x03def\x00", b"\x01a\x01b\x01c\x00",
+    b"\x0aabcdefghij\x00", b"\x03AbC\x03DeF\x00", b"\x05test1\x03abc\x00", b"\x03abc\x05de", b"\x03abc\xc0\x12\xc0\x34\x00",
+    b"", b"\x1eabcdefghijklmnopqrstuvwxyz0123", b"\x07k8s-api\x03svc\x07cluster\x05local", b"\x02\xc3\xa9\x00", b"\xc0\x0c",
+]
+
+
+def gen_contents(O, rng, recs):
+    """BpfFlowContent per record: every feature present/absent, zero-valued-but-present parts,
+    durations beyond int64, negative IPsec return codes, the DNS names above."""
+    n = len(recs)
+    c = np.zeros(n, dtype=O.CONTENT)
+    c["base"] = recs["metrics"]
+    for name in ("has_dns", "has_drops", "has_netev", "has_xlat", "has_additional", "has_quic"):
+        c[name] = rng.integers(0, 2, n)
+    c[["has_dns", "has_drops", "has_netev", "has_xlat", "has_additional", "has_quic"]][0] = 1
+    for k in range(n):
+        c[k]["has_dns"] = 1 if k < len(DNS_NAMES) else c[k]["has_dns"]
+        d = c[k]["dns"]
+        d["latency"] = [0, 1, 999_999_999, 10**9, 123_456_789_012, (1 << 63) + 5, (1 << 64) - 1][k % 7]
+        d["id"], d["flags"], d["err_no"] = rng.integers(0, 1 << 16), rng.integers(0, 1 << 16), [0, 2, 255][k % 3]
+        nm = DNS_NAMES[k % len(DNS_NAMES)]
+        d["name"][:len(nm)] = np.frombuffer(nm, dtype=np.uint8)
+        p = c[k]["drops"]
+        p["bytes"], p["packets"] = rng.integers(0, 1 << 16), rng.integers(0, 1 << 16)
+        p["latest_drop_cause"] = [0, 2, 0x30001, (1 << 32) - 1][k % 4]
+        p["latest_flags"], p["latest_state"] = rng.integers(0, 1 << 16), rng.integers(0, 13)
+        x = c[k]["xlat"]
+        x["saddr"], x["daddr"] = rng.integers(0, 256, 16), rng.integers(0, 256, 16)
+        x["sport"], x["dport"], x["zone_id"] = rng.integers(0, 1 << 16), [0, 443][k % 2], rng.integers(0, 3)
+        a = c[k]["additional"]
+        a["flow_rtt"] = [0, 1, 10**9 - 1, 10**9, 7_123_456_789, (1 << 63), (1 << 64) - 1][(k // 2) % 7]
+        a["ipsec_ret"] = [0, 1, -1, -(1 << 31), (1 << 31) - 1][k % 5]
+        a["ipsec_encrypted"] = [0, 1, 2][k % 3]           # Go decodes any non-zero byte as true
+        q = c[k]["quic"]
+        q["version"], q["seen_long_hdr"], q["seen_short_hdr"] = [0, 1, 0x6b3343cf, (1 << 32) - 1][k % 4], k % 2, (k // 2) % 2
+        c[k]["netev"]["packets"] = 1                       # present network events: ignored with a nil decoder
+    c[9] = np.zeros((), dtype=O.CONTENT)
+    for name in ("has_dns", "has_drops", "has_xlat", "has_additional", "has_quic"):
+        c[9][name] = 1                                     # every part present and all-zero
+    return c
+
+
 def main():
     from oracle import oracle as O
     Record, Records = build_classes()
@@ -201,6 +307,7 @@ def main():
     m["start"][6], m["end"][6] = (1 << 64) - 1, 1 << 63
     m["bytes"][7], m["packets"][7] = (1 << 64) - 1, (1 << 32) - 1
     recs[8] = np.zeros((), dtype=recs.dtype)                  # the all-zero record
+    contents = gen_contents(O, np.random.default_rng(4048), recs)
     cases = []
     for now, mono, agent in [
         (1_661_272_402_123_456_789, 5_000_000_000_000, bytes(10) + b"\xff\xff" + bytes([10, 1, 2, 3])),
@@ -213,12 +320,15 @@ def main():
         batch = Records()
         for r in recs[:10]:
             batch.entries.append(flow_to_pb(Record, r, now, mono, agent, namer))
+        enc_c = [flow_to_pb(Record, r, now, mono, agent, namer, content=c).SerializeToString(deterministic=True)
+                 for r, c in zip(recs, contents)]
         cases.append({"now_unix_ns": now, "mono_now_ns": mono, "agent_ip": agent.hex(),
-                      "records_pb": [e.hex() for e in enc], "records10_message": batch.SerializeToString(deterministic=True).hex()})
+                      "records_pb": [e.hex() for e in enc], "records10_message": batch.SerializeToString(deterministic=True).hex(),
+                      "contents_pb": [e.hex() for e in enc_c]})
     out = {"comment": "generated by tests/golden/gen_pb_golden.py (python protobuf %s); do not edit" % __import__("google.protobuf").protobuf.__version__,
            "names": [[i, mc.hex() if mc is not None else None, n, u] for (i, mc, n, u) in NAMES],
            "unknown_name": "unknown",
-           "records_hex": recs.tobytes().hex(), "cases": cases}
+           "records_hex": recs.tobytes().hex(), "contents_hex": contents.tobytes().hex(), "cases": cases}
     # the record of pkg/exporter/kafka_proto_test.go:26-86 TestProtoConversion, decoded field checks live in the test
     json.dump(out, open(os.path.join(HERE, "pb_golden.json"), "w"))
     print("wrote", os.path.join(HERE, "pb_golden.json"), len(recs), "records x", len(cases), "cases")

@@ -114,3 +114,132 @@ def test_device_resident_evict_then_encode(nf, O):
     # eviction order is unspecified: encode the evicted records (as evicted) with the oracle
     assert got == O.pb_encode(ev.view(O.FLOW_RECORD), O.pb_options(now, mono, AGENT4, O.intf_table(names)))
     assert np.array_equal(d_keys.cpu().numpy().reshape(-1, 32), O.kafka_keys(ev.view(O.FLOW_RECORD)))
+
+
+# ---- the MapTracer branch: full BpfFlowContent (nfagg_encode_pb_content)
+def _split_contents(nf, O, contents):
+    """oracle CONTENT array -> (present bits, parts dict) of the product ABI."""
+    n = len(contents)
+    present = np.zeros(n, dtype=np.uint8)
+    for name, bit in (("has_additional", nf.FEAT_ADDITIONAL), ("has_dns", nf.FEAT_DNS), ("has_drops", nf.FEAT_DROPS),
+                      ("has_netev", nf.FEAT_NETWORK_EVENTS), ("has_xlat", nf.FEAT_XLAT), ("has_quic", nf.FEAT_QUIC)):
+        present |= (contents[name] != 0).astype(np.uint8) * np.uint8(bit)
+    parts = {k: np.ascontiguousarray(contents[src]).view(np.uint8).reshape(n, -1).copy().view(nf.ROLLUP_KINDS[k]).reshape(n)
+             for k, src in (("additional", "additional"), ("dns", "dns"), ("drops", "drops"), ("xlat", "xlat"), ("quic", "quic"))}
+    return present, parts
+
+
+def _records_of(nf, O, ids, contents):
+    recs = np.zeros(len(ids), dtype=O.FLOW_RECORD)
+    recs["id"], recs["metrics"] = ids, contents["base"]
+    return recs.view(nf.FLOW_RECORD)
+
+
+def test_content_golden_vectors(nf, O):
+    g = json.load(open(os.path.join(HERE, "golden", "pb_golden.json")))
+    recs = np.frombuffer(bytes.fromhex(g["records_hex"]), dtype=O.FLOW_RECORD)
+    contents = np.frombuffer(bytes.fromhex(g["contents_hex"]), dtype=O.CONTENT)
+    names = nf.intf_table([(i, bytes.fromhex(m) if m is not None else None, n, u) for (i, m, n, u) in g["names"]])
+    present, parts = _split_contents(nf, O, contents)
+    with nf.FlowTable(max_entries=64) as tab:
+        for case in g["cases"]:
+            buf, off, blen = tab.encode_pb(_records_of(nf, O, recs["id"], contents), case["now_unix_ns"], case["mono_now_ns"],
+                                           bytes.fromhex(case["agent_ip"]), names, g["unknown_name"].encode(),
+                                           present=present, parts=parts)
+            got = frames(buf, off, blen)
+            want = [bytes.fromhex(h) for h in case["contents_pb"]]
+            for k, (a, b) in enumerate(zip(got, want)):
+                assert a == b, f"content {k}: {a.hex()} != {b.hex()}"
+
+
+def _random_contents(O, n, seed):
+    rng = np.random.default_rng(seed)
+    recs = O.gen_stream(n, seed=seed, n_keys=max(n // 3, 1), variant=1)
+    recs["metrics"]["eth_protocol"][::3] = 0x86DD
+    c = np.zeros(n, dtype=O.CONTENT)
+    raw = c.view(np.uint8).reshape(n, -1)
+    raw[:] = rng.integers(0, 256, raw.shape, dtype=np.uint8)            # every byte of every part random (padding too)
+    c["base"] = recs["metrics"]
+    for name in ("has_dns", "has_drops", "has_netev", "has_xlat", "has_additional", "has_quic"):
+        c[name] = rng.integers(0, 2, n)
+    # a third of the DNS names well-formed label sequences, a third NUL-terminated early, the rest raw noise
+    for k in range(0, n, 3):
+        labels = b"".join(bytes([l]) + bytes(rng.integers(97, 123, l, dtype=np.uint8)) for l in rng.integers(1, 9, 4))[:31]
+        nm = np.zeros(32, dtype=np.uint8); nm[:len(labels)] = np.frombuffer(labels, dtype=np.uint8)
+        c["dns"]["name"][k] = nm
+    c["dns"]["name"][1::3, rng.integers(0, 32)] = 0
+    zero = rng.integers(0, 4, n) == 0                                     # zero latencies / rtt: omitted or empty messages
+    c["dns"]["latency"][zero] = 0
+    c["additional"]["flow_rtt"][rng.integers(0, 4, n) == 0] = 0
+    return recs, c
+
+
+@pytest.mark.parametrize("n", [1, 64, 65, 1000, 1025, 40_000])
+def test_content_stream_parity_with_oracle(nf, O, n):
+    recs, contents = _random_contents(O, n, seed=100 + n)
+    now, mono = 1_700_000_000_123_456_789, 2_500_000
+    want = O.pb_encode_contents(recs["id"], contents, O.pb_options(now, mono, AGENT4, O.intf_table(NAMES)))
+    present, parts = _split_contents(nf, O, contents)
+    with nf.FlowTable(max_entries=64) as tab:
+        buf, off, blen, keys = tab.encode_pb(_records_of(nf, O, recs["id"], contents), now, mono, AGENT4, nf.intf_table(NAMES),
+                                             kafka_keys=True, present=present, parts=parts)
+        got = frames(buf, off, blen)
+        assert got == want
+        assert np.array_equal(keys, O.kafka_keys(recs))
+        assert max(len(b) for b in want) > (250 if n >= 64 else 0)
+        # a part whose array is NULL is absent whatever `present` says; no parts at all = the Accounter encoding
+        buf2, off2, blen2 = tab.encode_pb(_records_of(nf, O, recs["id"], contents), now, mono, AGENT4, nf.intf_table(NAMES),
+                                          present=present, parts={"dns": parts["dns"]})
+        only_dns = contents.copy()
+        for name in ("has_drops", "has_netev", "has_xlat", "has_additional", "has_quic"):
+            only_dns[name] = 0
+        assert frames(buf2, off2, blen2) == O.pb_encode_contents(recs["id"], only_dns, O.pb_options(now, mono, AGENT4, O.intf_table(NAMES)))
+        buf3, off3, blen3 = tab.encode_pb(_records_of(nf, O, recs["id"], contents), now, mono, AGENT4, nf.intf_table(NAMES),
+                                          present=np.zeros(n, dtype=np.uint8), parts=parts)
+        base = np.zeros(n, dtype=O.FLOW_RECORD); base["id"], base["metrics"] = recs["id"], contents["base"]
+        assert frames(buf3, off3, blen3) == O.pb_encode(base, O.pb_options(now, mono, AGENT4, O.intf_table(NAMES)))
+
+
+def test_content_rollup_then_encode_device(nf, O):
+    """Per-CPU partials -> nfagg_rollup_* -> nfagg_encode_pb_content_device: the MapTracer hand-off with the folded
+    parts resident in HBM."""
+    import torch
+    rng = np.random.default_rng(77)
+    n, n_cpu = 5000, 8
+    recs = O.gen_stream(n, seed=9, n_keys=n, variant=1)
+    base = recs["metrics"].copy()
+    parts_o, parts_p = {}, {}
+    with nf.FlowTable(max_entries=64) as tab:
+        b_o = base.copy(); b_p = base.copy().view(nf.FLOW_METRICS)
+        for kind in ("dns", "drops", "xlat", "additional", "quic"):       # tracer.go:1057-1110 order (network events left out)
+            dt = O.KIND_DTYPES[O.KIND_INDEX[kind]]
+            partials = np.zeros((n, n_cpu), dtype=dt)
+            partials.view(np.uint8).reshape(n, -1)[:] = rng.integers(0, 256, (n, n_cpu * dt.itemsize), dtype=np.uint8)
+            b_o, parts_o[kind] = O.rollup(kind, partials, n_cpu, b_o)
+            b_p, parts_p[kind] = tab.rollup(kind, partials.view(np.uint8).reshape(n, -1).copy().view(nf.ROLLUP_KINDS[kind]).reshape(n, n_cpu), n_cpu, b_p)
+            assert parts_p[kind].tobytes() == parts_o[kind].tobytes()
+        assert b_p.tobytes() == b_o.tobytes()
+        present = rng.integers(0, 64, n).astype(np.uint8)
+        contents = np.zeros(n, dtype=O.CONTENT)
+        contents["base"] = b_o
+        for kind, has in (("dns", "has_dns"), ("drops", "has_drops"), ("xlat", "has_xlat"), ("additional", "has_additional"), ("quic", "has_quic")):
+            contents[kind] = parts_o[kind]
+            contents[has] = (present >> O.KIND_INDEX[kind]) & 1
+        now, mono = 1_712_345_678_000_000_001, 77_000_000_000
+        want = O.pb_encode_contents(recs["id"], contents, O.pb_options(now, mono, AGENT4, O.intf_table(NAMES)))
+        flows = np.zeros(n, dtype=O.FLOW_RECORD); flows["id"], flows["metrics"] = recs["id"], b_o
+        d_recs = torch.from_numpy(flows.view(np.uint8).reshape(-1).copy()).cuda()
+        d_present = torch.from_numpy(present).cuda()
+        d_parts = {k: torch.from_numpy(np.ascontiguousarray(v).view(np.uint8).reshape(-1).copy()).cuda() for k, v in parts_p.items()}
+        d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        d_len = torch.empty(n, dtype=torch.int32, device="cuda")
+        ptrs = {k: v.data_ptr() for k, v in d_parts.items()}
+        rc, need = tab.encode_pb_device(d_recs.data_ptr(), n, now, mono, AGENT4, nf.intf_table(NAMES), 0, 0, d_off.data_ptr(), d_len.data_ptr(),
+                                        d_present=d_present.data_ptr(), d_parts=ptrs)
+        assert rc == nf.TRUNCATED and need == sum(len(b) + 1 + len(_varint(len(b))) for b in want)
+        d_out = torch.empty(need + 16, dtype=torch.uint8, device="cuda")
+        rc, wrote = tab.encode_pb_device(d_recs.data_ptr(), n, now, mono, AGENT4, nf.intf_table(NAMES), d_out.data_ptr(), need,
+                                         d_off.data_ptr(), d_len.data_ptr(), d_present=d_present.data_ptr(), d_parts=ptrs)
+        assert rc == nf.OK and wrote == need
+        got = frames(d_out[:need].cpu().numpy(), d_off.cpu().numpy().astype(np.uint64), d_len.cpu().numpy().astype(np.uint32))
+    assert got == want

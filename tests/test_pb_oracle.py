@@ -38,6 +38,41 @@ def test_oracle_matches_protobuf_runtime_bytes(O, golden):
         assert framed == bytes.fromhex(case["records10_message"])
 
 
+def test_oracle_contents_match_protobuf_runtime_bytes(O, golden):
+    """The MapTracer branch: full BpfFlowContent (DNS, drops, xlat, RTT/IPsec, QUIC) per flow."""
+    recs, names = golden_inputs(O, golden)
+    contents = np.frombuffer(bytes.fromhex(golden["contents_hex"]), dtype=O.CONTENT)
+    assert len(contents) == len(recs)
+    seen = set()
+    for case in golden["cases"]:
+        opts = O.pb_options(case["now_unix_ns"], case["mono_now_ns"], bytes.fromhex(case["agent_ip"]), names,
+                            golden["unknown_name"].encode())
+        got = O.pb_encode_contents(recs["id"], contents, opts)
+        want = [bytes.fromhex(h) for h in case["contents_pb"]]
+        for k, (g, w) in enumerate(zip(got, want)):
+            assert g == w, f"content {k}: {g.hex()} != {w.hex()}"
+        seen.update(len(w) for w in want)
+    assert max(seen) > 300          # the fixtures reach the long frames (all features + 7 interfaces)
+
+
+# pkg/decode/decode_protobuf_test.go:288-395 TestDnsRawNameToDotted, every case (input -> expected); the
+# 1000-byte case is cut to the 32 bytes the kernel struct holds
+DNS_KATS = [
+    (b"", b""), (b"\x00", b""), (b"\x03abc\x00", b"abc"), (b"\x03abc\x03def\x00", b"abc.def"),
+    (b"\x03www\x07example\x03com\x00", b"www.example.com"), (b"\x03abc\xc0\x12\x00", b"abc"), (b"\xc0\x12", b""),
+    (b"\x0aabc", b""), (b"\x00\x03abc\x00", b""), (b"\x03ab\x00\x03def\x00", b""), (b"\x01a\x01b\x01c\x00", b"a.b.c"),
+    (b"\x0aabcdefghij\x00", b"abcdefghij"), (b"\x03AbC\x03DeF\x00", b"AbC.DeF"), (b"\x05test1\x03abc\x00", b"test1.abc"),
+    (b"\x03abc\x05de", b"abc"), (b"\x03abc\xc0\x12\xc0\x34\x00", b"abc"), (b"\x03abc\x00" + bytes(27), b"abc"),
+]
+
+
+@pytest.mark.parametrize("raw,want", DNS_KATS)
+def test_dns_raw_name_to_dotted_kats(O, raw, want):
+    import gen_pb_golden as G
+    assert O.dns_name_dotted(raw) == want
+    assert G.dns_raw_name_to_dotted((raw + bytes(32))[:32]) == want
+
+
 def _varint(v):
     out = bytearray()
     while v >= 0x80:
