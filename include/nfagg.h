@@ -327,6 +327,20 @@ void nfagg_record_times(int64_t now_unix_ns, uint64_t mono_now_ns,
                         int64_t* time_flow_start_unix_ns,
                         int64_t* time_flow_end_unix_ns);
 
+enum {   /* the per-CPU feature maps, in the order of the nfagg_rollup_* entries */
+    NFAGG_ROLLUP_ADDITIONAL = 0, NFAGG_ROLLUP_DNS = 1, NFAGG_ROLLUP_DROPS = 2,
+    NFAGG_ROLLUP_NETWORK_EVENTS = 3, NFAGG_ROLLUP_XLAT = 4, NFAGG_ROLLUP_QUIC = 5
+};
+/* bits of a "present" byte: which parts of model.BpfFlowContent are non-nil */
+enum {
+    NFAGG_FEAT_ADDITIONAL     = 1 << NFAGG_ROLLUP_ADDITIONAL,
+    NFAGG_FEAT_DNS            = 1 << NFAGG_ROLLUP_DNS,
+    NFAGG_FEAT_DROPS          = 1 << NFAGG_ROLLUP_DROPS,
+    NFAGG_FEAT_NETWORK_EVENTS = 1 << NFAGG_ROLLUP_NETWORK_EVENTS,
+    NFAGG_FEAT_XLAT           = 1 << NFAGG_ROLLUP_XLAT,
+    NFAGG_FEAT_QUIC           = 1 << NFAGG_ROLLUP_QUIC
+};
+
 /* ------------------------------------------------------------------ */
 /* Per-CPU map rollup — replaces lookupAndDeletePerCPUMap's accumulator */
 /* closures (pkg/tracer/tracer.go:1057-1110,1118-1146).                 */
@@ -359,6 +373,55 @@ int nfagg_rollup_xlat(nfagg_handle* h, const nfagg_xlat_metrics* partials,
 int nfagg_rollup_quic(nfagg_handle* h, const nfagg_quic_metrics* partials,
                       size_t n_flows, size_t n_cpu,
                       nfagg_flow_metrics* base, nfagg_quic_metrics* folded);
+
+/* ------------------------------------------------------------------ */
+/* Map merge — replaces FlowFetcher.LookupAndDeleteMap's join            */
+/* (pkg/tracer/tracer.go:1022-1116) including lookupAndDeletePerCPUMap    */
+/* (:1118-1146): the caller drains the eBPF maps (syscalls stay in Go)    */
+/* and hands the raw arrays over; the join by flow id, the per-CPU folds  */
+/* and buildBaseFromAdditional happen on the device in one call.          */
+/* ------------------------------------------------------------------ */
+
+/* One drained map: n keys and their values. Main map (aggregated_flows):
+ * values = nfagg_flow_metrics[n]. Feature map k (NFAGG_ROLLUP_*): values =
+ * that map's struct[n * n_cpu], flow-major (what cilium's per-CPU Lookup
+ * returns per key). A key listed twice in one map keeps its first row (the
+ * reference's second LookupAndDelete fails and is skipped, :1048-1052,
+ * :1130-1134); such rows are counted in *n_duplicate_keys. */
+typedef struct nfagg_map_view {
+    const nfagg_flow_id* ids;
+    const void*          values;
+    size_t               n;
+} nfagg_map_view;
+
+/* Caller-allocated outputs, `cap` entries each. records[i] = {id, base metrics
+ * after every buildBaseFromAdditional}; present[i] = NFAGG_FEAT_* bits (the
+ * non-nil parts of model.BpfFlowContent); part arrays hold the folded part
+ * (zeroes when absent) and may be NULL when not wanted. The layout is what
+ * nfagg_encode_pb_content consumes. Flows come out in order of first
+ * appearance: main map first, then the feature maps in the order the reference
+ * walks them (dns, drops, network events, xlat, additional, quic) — Go's map
+ * order is random, so any order is valid. id byte 39 (a blank field in Go) is
+ * not part of the key and is written as zero. */
+typedef struct nfagg_merged_flows {
+    nfagg_flow_record*            records;
+    uint8_t*                      present;
+    nfagg_additional_metrics*     additional;
+    nfagg_dns_metrics*            dns;
+    nfagg_pkt_drop_metrics*       drops;
+    nfagg_network_events_metrics* network_events;
+    nfagg_xlat_metrics*           xlat;
+    nfagg_quic_metrics*           quic;
+} nfagg_merged_flows;
+
+/* feature_maps[k], k = NFAGG_ROLLUP_*; n = 0 for a map that is not enabled.
+ * NFAGG_TRUNCATED (nothing written, *n_out = flows) when cap is too small.
+ * All pointers HOST memory: */
+int nfagg_map_merge(nfagg_handle* h, const nfagg_map_view* main_map, const nfagg_map_view feature_maps[6],
+                    size_t n_cpu, const nfagg_merged_flows* out, size_t cap, size_t* n_out, size_t* n_duplicate_keys);
+/* Same with every data pointer in DEVICE memory (8-byte aligned). */
+int nfagg_map_merge_device(nfagg_handle* h, const nfagg_map_view* d_main_map, const nfagg_map_view d_feature_maps[6],
+                           size_t n_cpu, const nfagg_merged_flows* d_out, size_t cap, size_t* n_out, size_t* n_duplicate_keys);
 
 /* ------------------------------------------------------------------ */
 /* Sketches — new functionality (no reference counterpart; spec in      */
@@ -483,18 +546,6 @@ int nfagg_encode_pb_device(nfagg_handle* h, const void* d_records, size_t n, con
  * they are encoded as NewRecord does with a nil decoder (record.go:126) — field 27
  * empty, no drop injected; a caller with a decoder routes those flows through Go.
  * dns.name bytes are copied as they are (Go's Marshal rejects a non-UTF-8 string). */
-enum {   /* the per-CPU feature maps, in the order of the nfagg_rollup_* entries */
-    NFAGG_ROLLUP_ADDITIONAL = 0, NFAGG_ROLLUP_DNS = 1, NFAGG_ROLLUP_DROPS = 2,
-    NFAGG_ROLLUP_NETWORK_EVENTS = 3, NFAGG_ROLLUP_XLAT = 4, NFAGG_ROLLUP_QUIC = 5
-};
-enum {
-    NFAGG_FEAT_ADDITIONAL     = 1 << NFAGG_ROLLUP_ADDITIONAL,
-    NFAGG_FEAT_DNS            = 1 << NFAGG_ROLLUP_DNS,
-    NFAGG_FEAT_DROPS          = 1 << NFAGG_ROLLUP_DROPS,
-    NFAGG_FEAT_NETWORK_EVENTS = 1 << NFAGG_ROLLUP_NETWORK_EVENTS,
-    NFAGG_FEAT_XLAT           = 1 << NFAGG_ROLLUP_XLAT,
-    NFAGG_FEAT_QUIC           = 1 << NFAGG_ROLLUP_QUIC
-};
 typedef struct nfagg_pb_features {
     uint32_t struct_size;        /* sizeof(nfagg_pb_features) */
     uint32_t reserved_;

@@ -56,6 +56,17 @@ class PbOptions(C.Structure):
     ]
 
 
+class MapView(C.Structure):
+    """nfagg_map_view (include/nfagg.h)."""
+    _fields_ = [("ids", C.c_void_p), ("values", C.c_void_p), ("n", C.c_size_t)]
+
+
+class MergedFlows(C.Structure):
+    """nfagg_merged_flows (include/nfagg.h)."""
+    _fields_ = [("records", C.c_void_p), ("present", C.c_void_p), ("additional", C.c_void_p), ("dns", C.c_void_p),
+                ("drops", C.c_void_p), ("network_events", C.c_void_p), ("xlat", C.c_void_p), ("quic", C.c_void_p)]
+
+
 class PbFeatures(C.Structure):
     """nfagg_pb_features (include/nfagg.h)."""
     _fields_ = [("struct_size", C.c_uint32), ("reserved_", C.c_uint32), ("present", C.c_void_p), ("additional", C.c_void_p),
@@ -108,6 +119,8 @@ SIGNATURES = {
     "nfagg_ringbuf_drain": (C.c_int, [C.POINTER(RingBuf), _vp, _sz, _psz, _psz, _vp]),
     "nfagg_encode_pb": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
     "nfagg_encode_pb_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
+    "nfagg_map_merge": (C.c_int, [_vp, C.POINTER(MapView), C.POINTER(MapView), _sz, C.POINTER(MergedFlows), _sz, _psz, _psz]),
+    "nfagg_map_merge_device": (C.c_int, [_vp, C.POINTER(MapView), C.POINTER(MapView), _sz, C.POINTER(MergedFlows), _sz, _psz, _psz]),
     "nfagg_encode_pb_content": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbFeatures), C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
     "nfagg_encode_pb_content_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbFeatures), C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
     "nfagg_shard_of": (C.c_uint32, [_vp, C.c_uint32]),

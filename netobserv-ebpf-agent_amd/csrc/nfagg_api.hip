@@ -63,6 +63,10 @@ struct nfagg_handle {
     size_t d_roll_cap[3] = {0, 0, 0};
     uint32_t* d_hist = nullptr;
     // protobuf encode scratch: local offsets, block sums, block bases, namer table, (host variant) records/out/offsets/lens/keys
+    // map merge scratch: [0] slots [1] slot_of [2] local_off [3] block_sum [4] block_base [5] dup counter,
+    // (host variant) [6..12] ids, [13..19] values, [20..27] outputs
+    void* d_mm[28] = {};
+    size_t d_mm_cap[28] = {};
     void* d_pb[15] = {};
     size_t d_pb_cap[15] = {};
     // spill queues of the two-pass ingest
@@ -387,6 +391,7 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->d_hist) hipFree(h->d_hist);
     if (h->d_spill) hipFree(h->d_spill);
     for (int k = 0; k < 15; k++) if (h->d_pb[k]) hipFree(h->d_pb[k]);
+    for (int k = 0; k < 28; k++) if (h->d_mm[k]) hipFree(h->d_mm[k]);
     if (h->tv.spill.qtail) hipFree(h->tv.spill.qtail);
     if (h->d_evict) hipFree(h->d_evict);
     if (h->d_slot_idx) hipFree(h->d_slot_idx);
@@ -574,6 +579,112 @@ int nfagg_rollup_xlat(nfagg_handle* h, const nfagg_xlat_metrics* p, size_t nf, s
                       nfagg_flow_metrics* base, nfagg_xlat_metrics* folded) { return rollup_core(h, 4, p, nf, nc, base, folded); }
 int nfagg_rollup_quic(nfagg_handle* h, const nfagg_quic_metrics* p, size_t nf, size_t nc,
                       nfagg_flow_metrics* base, nfagg_quic_metrics* folded) { return rollup_core(h, 5, p, nf, nc, base, folded); }
+
+// ---------------------------------------------------------------- map merge (LookupAndDeleteMap's join)
+static const int kWalk[7] = {-1, NFAGG_ROLLUP_DNS, NFAGG_ROLLUP_DROPS, NFAGG_ROLLUP_NETWORK_EVENTS, NFAGG_ROLLUP_XLAT,
+                             NFAGG_ROLLUP_ADDITIONAL, NFAGG_ROLLUP_QUIC};   // tracer.go:1057-1110; position 0 = main map
+
+static int map_merge_device_core(nfagg_handle* h, const nfagg_map_view* mm, const nfagg_map_view fm[6], size_t n_cpu,
+                                 const nfagg_merged_flows* out, size_t cap, size_t* n_out, size_t* n_dup) {
+    if (!h || !mm || !fm || !out || !n_out) return fail(h, NFAGG_EINVAL, "null argument");
+    if (n_cpu == 0 || n_cpu > 0xFFFFu) return fail(h, NFAGG_EINVAL, "n_cpu must be in [1, 65535]");
+    MergeIn in{};
+    in.n_cpu = (uint32_t)n_cpu;
+    uint64_t total = 0;
+    uintptr_t align = 0;
+    for (int q = 0; q < 7; q++) {
+        const nfagg_map_view& v = q == 0 ? *mm : fm[kWalk[q]];
+        if (v.n && (!v.ids || !v.values)) return fail(h, NFAGG_EINVAL, "map %d: null ids/values", q);
+        in.ids[q] = (const uint8_t*)v.ids; in.vals[q] = (const uint8_t*)v.values;
+        in.off[q] = (uint32_t)total;
+        total += v.n;
+        if (v.n) align |= (uintptr_t)v.ids | (uintptr_t)v.values;
+    }
+    if (total >= 0x7FFFFFFFull) return fail(h, NFAGG_ERANGE, "map merge: more than 2^31 rows");
+    in.off[7] = (uint32_t)total;
+    *n_out = 0;
+    if (n_dup) *n_dup = 0;
+    if (total == 0) return NFAGG_OK;
+    if (cap && (!out->records || !out->present)) return fail(h, NFAGG_EINVAL, "null records/present output");
+    align |= (uintptr_t)out->records | (uintptr_t)out->additional | (uintptr_t)out->dns | (uintptr_t)out->drops |
+             (uintptr_t)out->network_events | (uintptr_t)out->xlat | (uintptr_t)out->quic;
+    if (align & 7u) return fail(h, NFAGG_EINVAL, "map merge: device arrays must be 8-byte aligned");
+    HIP_TRY(h, hipSetDevice(h->device));
+    uint32_t n_slots = 1024;
+    while ((uint64_t)n_slots < 2 * total) n_slots <<= 1;
+    const size_t blocks = (total + 1023) / 1024;
+    int rc;
+    if ((rc = ensure_bytes(h, &h->d_mm[0], &h->d_mm_cap[0], (size_t)n_slots * merge_slot_bytes())) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_mm[1], &h->d_mm_cap[1], total * sizeof(uint32_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_mm[2], &h->d_mm_cap[2], total * sizeof(uint32_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_mm[3], &h->d_mm_cap[3], blocks * sizeof(uint32_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_mm[4], &h->d_mm_cap[4], (blocks + 1) * sizeof(uint64_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_mm[5], &h->d_mm_cap[5], 16)) != NFAGG_OK) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->d_mm[0], 0xFF, (size_t)n_slots * merge_slot_bytes(), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_mm[5], 0, 16, h->stream));
+    hipError_t e = launch_merge_build(in, h->d_mm[0], n_slots, (uint32_t*)h->d_mm[1], (unsigned int*)h->d_mm[5],
+                                      (uint32_t*)h->d_mm[2], (uint32_t*)h->d_mm[3], h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "map merge build launch failed: %s", hipGetErrorString(e));
+    e = launch_scan_block_sums((const uint32_t*)h->d_mm[3], (uint32_t)blocks, (uint64_t*)h->d_mm[4], h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "map merge scan launch failed: %s", hipGetErrorString(e));
+    uint64_t flows = 0; unsigned int dups = 0;
+    HIP_TRY(h, hipMemcpyAsync(&flows, (uint64_t*)h->d_mm[4] + blocks, sizeof flows, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&dups, h->d_mm[5], sizeof dups, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *n_out = (size_t)flows;
+    if (n_dup) *n_dup = dups;
+    if (flows > cap) return NFAGG_TRUNCATED;
+    MergeOut o{out->records, out->present, out->additional, out->dns, out->drops, out->network_events, out->xlat, out->quic};
+    e = launch_merge_fold(in, o, h->d_mm[0], (const uint32_t*)h->d_mm[1], (const uint32_t*)h->d_mm[2], (const uint64_t*)h->d_mm[4], h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "map merge fold launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NFAGG_OK;
+}
+
+int nfagg_map_merge_device(nfagg_handle* h, const nfagg_map_view* d_main_map, const nfagg_map_view d_feature_maps[6],
+                           size_t n_cpu, const nfagg_merged_flows* d_out, size_t cap, size_t* n_out, size_t* n_duplicate_keys) {
+    return map_merge_device_core(h, d_main_map, d_feature_maps, n_cpu, d_out, cap, n_out, n_duplicate_keys);
+}
+
+int nfagg_map_merge(nfagg_handle* h, const nfagg_map_view* main_map, const nfagg_map_view feature_maps[6],
+                    size_t n_cpu, const nfagg_merged_flows* out, size_t cap, size_t* n_out, size_t* n_duplicate_keys) {
+    if (!h || !main_map || !feature_maps || !out || !n_out) return fail(h, NFAGG_EINVAL, "null argument");
+    if (n_cpu == 0) return fail(h, NFAGG_EINVAL, "n_cpu must be >= 1");
+    HIP_TRY(h, hipSetDevice(h->device));
+    nfagg_map_view dm{}, df[6] = {};
+    int rc;
+    for (int q = 0; q < 7; q++) {
+        const nfagg_map_view& v = q == 0 ? *main_map : feature_maps[q - 1];
+        nfagg_map_view& d = q == 0 ? dm : df[q - 1];
+        d.n = v.n;
+        if (!v.n) continue;
+        if (!v.ids || !v.values) return fail(h, NFAGG_EINVAL, "map %d: null ids/values", q);
+        const size_t vb = q == 0 ? v.n * sizeof(nfagg_flow_metrics) : v.n * n_cpu * rollup_struct_size(q - 1);
+        if ((rc = ensure_bytes(h, &h->d_mm[6 + q], &h->d_mm_cap[6 + q], v.n * sizeof(nfagg_flow_id))) != NFAGG_OK) return rc;
+        if ((rc = ensure_bytes(h, &h->d_mm[13 + q], &h->d_mm_cap[13 + q], vb)) != NFAGG_OK) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->d_mm[6 + q], v.ids, v.n * sizeof(nfagg_flow_id), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_mm[13 + q], v.values, vb, hipMemcpyHostToDevice, h->stream));
+        d.ids = (const nfagg_flow_id*)h->d_mm[6 + q]; d.values = h->d_mm[13 + q];
+    }
+    void* host_out[8] = {out->records, out->present, out->additional, out->dns, out->drops, out->network_events, out->xlat, out->quic};
+    const size_t elem[8] = {sizeof(nfagg_flow_record), 1, sizeof(nfagg_additional_metrics), sizeof(nfagg_dns_metrics), sizeof(nfagg_pkt_drop_metrics),
+                            sizeof(nfagg_network_events_metrics), sizeof(nfagg_xlat_metrics), sizeof(nfagg_quic_metrics)};
+    void* dev_out[8] = {};
+    for (int k = 0; k < 8; k++) {
+        if (!host_out[k] || !cap) continue;
+        if ((rc = ensure_bytes(h, &h->d_mm[20 + k], &h->d_mm_cap[20 + k], cap * elem[k] + 16)) != NFAGG_OK) return rc;
+        dev_out[k] = h->d_mm[20 + k];
+    }
+    nfagg_merged_flows dout{(nfagg_flow_record*)dev_out[0], (uint8_t*)dev_out[1], (nfagg_additional_metrics*)dev_out[2], (nfagg_dns_metrics*)dev_out[3],
+                            (nfagg_pkt_drop_metrics*)dev_out[4], (nfagg_network_events_metrics*)dev_out[5], (nfagg_xlat_metrics*)dev_out[6],
+                            (nfagg_quic_metrics*)dev_out[7]};
+    rc = map_merge_device_core(h, &dm, df, n_cpu, &dout, cap, n_out, n_duplicate_keys);
+    if (rc != NFAGG_OK) return rc;
+    for (int k = 0; k < 8; k++)
+        if (dev_out[k] && *n_out) HIP_TRY(h, hipMemcpyAsync(host_out[k], dev_out[k], *n_out * elem[k], hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NFAGG_OK;
+}
 
 // ---------------------------------------------------------------- sketches
 static int sketch_info(nfagg_handle* h, int which, void** p, size_t* bytes) {

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "nfagg_hash.h"
+#include "../../include/nfagg.h"
 
 namespace nfagg {
 
@@ -156,5 +157,32 @@ hipError_t launch_hll_pack(const uint32_t* d_regs, uint32_t p, uint8_t* d_out, h
 hipError_t launch_rollup(int kind, const void* d_partials, uint64_t n_flows, uint64_t n_cpu,
                          void* d_base, void* d_folded, hipStream_t s);
 size_t rollup_struct_size(int kind);
+
+// Merge of the drained maps (nfagg_rollup.hip). Index = position in Go's walk order:
+// 0 main (aggregated_flows), 1 dns, 2 drops, 3 network events, 4 xlat, 5 additional, 6 quic.
+struct MergeIn {
+    const uint8_t* ids[7];        // 40-byte flow ids (DEVICE), 8-byte aligned
+    const uint8_t* vals[7];       // [0]: nfagg_flow_metrics[n]; others: struct[n * n_cpu], flow-major
+    uint32_t off[8];              // off[q] = global position of row 0 of map q; off[7] = total rows
+    uint32_t n_cpu;
+};
+struct MergeOut {                 // dense, one entry per merged flow (DEVICE); part arrays may be null
+    nfagg_flow_record* records;
+    uint8_t* present;
+    nfagg_additional_metrics* additional;
+    nfagg_dns_metrics* dns;
+    nfagg_pkt_drop_metrics* drops;
+    nfagg_network_events_metrics* network_events;
+    nfagg_xlat_metrics* xlat;
+    nfagg_quic_metrics* quic;
+};
+size_t merge_slot_bytes();
+// build the join (slots pre-set to 0xFF, n_slots a power of two >= 2 * rows), flag first occurrences, block-local scan
+hipError_t launch_merge_build(const MergeIn& in, void* d_slots, uint32_t n_slots, uint32_t* d_slot_of, unsigned int* d_n_dup,
+                              uint32_t* d_local_off, uint32_t* d_block_sum, hipStream_t s);
+hipError_t launch_merge_fold(const MergeIn& in, const MergeOut& out, const void* d_slots, const uint32_t* d_slot_of,
+                             const uint32_t* d_local_off, const uint64_t* d_block_base, hipStream_t s);
+// exclusive scan of n_blocks block sums into d_block_base[0..n_blocks], total at [n_blocks] (nfagg_pb.hip)
+hipError_t launch_scan_block_sums(const uint32_t* d_block_sum, uint32_t n_blocks, uint64_t* d_block_base, hipStream_t s);
 
 }  // namespace nfagg

@@ -366,6 +366,12 @@ hipError_t launch_pb_size(const void* d_recs, uint64_t n, const PbParams& P, con
     return hipGetLastError();
 }
 
+hipError_t launch_scan_block_sums(const uint32_t* d_block_sum, uint32_t n_blocks, uint64_t* d_block_base, hipStream_t s) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_pb_scan_blocks, dim3(1), dim3(1024), 0, s, d_block_sum, n_blocks, d_block_base);
+    return hipGetLastError();
+}
+
 hipError_t launch_pb_write(const void* d_recs, uint64_t n, const PbParams& P, const PbFeat& F, const uint32_t* d_body_len, const uint32_t* d_local_off,
                            const uint64_t* d_block_base, void* d_out, uint64_t* d_frame_offsets, void* d_kafka_keys, hipStream_t s) {
     static_assert(64 * kPbMaxFrame + 16 <= 5 * kPbWindow, "window count bound");

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/nfagg.h"
 #include "nfagg_internal.h"
+#include "nfagg_hash.h"
 
 namespace nfagg {
 
@@ -105,6 +106,161 @@ __global__ __launch_bounds__(256) void k_rollup(const M* __restrict__ partials, 
     base[f] = b;
     folded[f] = acc;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Merge of the drained eBPF maps — FlowFetcher.LookupAndDeleteMap (pkg/tracer/tracer.go:1022-1116)
+// with lookupAndDeletePerCPUMap (:1118-1146) as ONE device-side join: the main map (aggregated_flows)
+// and up to six per-CPU feature maps, each a list of (40-byte id, value | n_cpu partials), become one
+// dense array of merged flows {id, base metrics, present bits, folded parts}.
+//
+// The join is a hash build over every input row. A slot never stores a key: it stores `rep`, the
+// global position of a row that carries the key (claimed with one CAS); a later row compares its key
+// with the key of row `rep` in the INPUT arrays, which nobody writes — so there is no publish
+// protocol and no spinning. Per slot: `first` = smallest global position of the key (atomic min; it
+// orders the output by first appearance, main map first, then the maps in the order Go walks them)
+// and `row[m]` = the key's row in map m (atomic min: an id listed twice in one map keeps its first
+// row, as the second LookupAndDelete of the Go loop fails and is skipped, :1048-1052,1130-1134).
+// Then: flag rows with first == position, scan, and one lane per merged flow replays the Go order
+// (dns, drops, network events, xlat, additional, quic; CPUs ascending) over its rows.
+struct MergeSlot { uint32_t rep, first, row[7]; uint32_t pad_; };   // 40 bytes, initialised to 0xFF
+
+RD void load_key(const uint8_t* ids, uint32_t row, uint64_t w[5]) {
+    const uint64_t* p = reinterpret_cast<const uint64_t*>(ids + (size_t)row * 40);
+#pragma unroll
+    for (int k = 0; k < 5; k++) w[k] = p[k];
+    w[4] &= 0x00FFFFFFFFFFFFFFull;          // byte 39 is a blank field in Go (bpf_x86_bpfel.go:119): not part of the key
+}
+
+RD void locate(const MergeIn& in, uint32_t g, int& q, uint32_t& row) {
+    q = 0;
+#pragma unroll
+    for (int k = 1; k < 7; k++) q += (g >= in.off[k]) ? 1 : 0;
+    row = g - in.off[q];
+}
+
+__global__ __launch_bounds__(256) void k_merge_build(MergeIn in, MergeSlot* __restrict__ slots, uint32_t mask,
+                                                     uint32_t* __restrict__ slot_of, unsigned int* __restrict__ n_dup) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= in.off[7]) return;
+    int q; uint32_t row;
+    locate(in, g, q, row);
+    uint64_t w[5];
+    load_key(in.ids[q], row, w);
+    uint32_t s = (uint32_t)key_hash(w) & mask;
+    for (;;) {
+        uint32_t rep = __hip_atomic_load(&slots[s].rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (rep == 0xFFFFFFFFu) {
+            uint32_t expected = 0xFFFFFFFFu;
+            if (__hip_atomic_compare_exchange_strong(&slots[s].rep, &expected, g, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) rep = g;
+            else rep = expected;
+        }
+        bool same = rep == g;
+        if (!same) {
+            int rq; uint32_t rrow;
+            locate(in, rep, rq, rrow);
+            uint64_t v[5];
+            load_key(in.ids[rq], rrow, v);
+            same = v[0] == w[0] && v[1] == w[1] && v[2] == w[2] && v[3] == w[3] && v[4] == w[4];
+        }
+        if (same) break;
+        s = (s + 1) & mask;
+    }
+    __hip_atomic_fetch_min(&slots[s].first, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t old = __hip_atomic_fetch_min(&slots[s].row[q], row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old != 0xFFFFFFFFu) atomicAdd(n_dup, 1u);
+    slot_of[g] = s;
+}
+
+// flags + block-local exclusive scan (block = 1024 rows); block sums go through launch_scan_block_sums
+__global__ __launch_bounds__(1024) void k_merge_flags(uint32_t n_rows, const MergeSlot* __restrict__ slots, const uint32_t* __restrict__ slot_of,
+                                                      uint32_t* __restrict__ local_off, uint32_t* __restrict__ block_sum) {
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t g = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t flag = (g < n_rows && slots[slot_of[g]].first == g) ? 1u : 0u;
+    uint32_t v = flag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+    if (lane == 63) wave_tot[wave] = v;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int k = 0; k < wave; k++) base += wave_tot[k];
+    if (g < n_rows) local_off[g] = flag ? base + v - 1 : 0xFFFFFFFFu;
+    if (threadIdx.x == 1023) block_sum[blockIdx.x] = base + v;
+}
+
+template <typename M>
+RD bool merge_part(const MergeIn& in, int q, uint32_t row, nfagg_flow_metrics& b, M* __restrict__ out, uint64_t j) {
+    M acc;
+    const bool have = row != 0xFFFFFFFFu;
+    if (have) {
+        const M* p = reinterpret_cast<const M*>(in.vals[q]) + (size_t)row * in.n_cpu;
+        acc = p[0];                                       // CPU 0 adopted whole
+        base_from(b, acc.start_mono_time_ts, acc.end_mono_time_ts, acc.eth_protocol);
+        for (uint32_t c = 1; c < in.n_cpu; c++) {
+            const M o = p[c];
+            base_from(b, o.start_mono_time_ts, o.end_mono_time_ts, o.eth_protocol);
+            fold(acc, o);
+        }
+    } else {
+        memset(&acc, 0, sizeof acc);
+    }
+    if (out) out[j] = acc;
+    return have;
+}
+
+__global__ __launch_bounds__(256) void k_merge_fold(MergeIn in, MergeOut out, const MergeSlot* __restrict__ slots,
+                                                    const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ local_off,
+                                                    const uint64_t* __restrict__ block_base) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= in.off[7]) return;
+    const uint32_t lo = local_off[g];
+    if (lo == 0xFFFFFFFFu) return;
+    const uint64_t j = block_base[g / 1024] + lo;
+    const MergeSlot sl = slots[slot_of[g]];
+    int q; uint32_t row;
+    locate(in, g, q, row);
+    nfagg_flow_record rec;
+    memset(&rec, 0, sizeof rec);
+    {
+        uint64_t w[5];
+        load_key(in.ids[q], row, w);
+        memcpy(&rec.id, w, 40);
+    }
+    // position 0 of the walk order is the main map: flows[id] = NewBpfFlowContent(baseMetrics), else zero metrics (:1136-1139)
+    if (sl.row[0] != 0xFFFFFFFFu) rec.metrics = reinterpret_cast<const nfagg_flow_metrics*>(in.vals[0])[sl.row[0]];
+    uint32_t present = 0;
+    // walk order positions 1..6 = dns, drops, network events, xlat, additional, quic (tracer.go:1057-1110)
+    if (merge_part<nfagg_dns_metrics>(in, 1, sl.row[1], rec.metrics, out.dns, j)) present |= NFAGG_FEAT_DNS;
+    if (merge_part<nfagg_pkt_drop_metrics>(in, 2, sl.row[2], rec.metrics, out.drops, j)) present |= NFAGG_FEAT_DROPS;
+    if (merge_part<nfagg_network_events_metrics>(in, 3, sl.row[3], rec.metrics, out.network_events, j)) present |= NFAGG_FEAT_NETWORK_EVENTS;
+    if (merge_part<nfagg_xlat_metrics>(in, 4, sl.row[4], rec.metrics, out.xlat, j)) present |= NFAGG_FEAT_XLAT;
+    if (merge_part<nfagg_additional_metrics>(in, 5, sl.row[5], rec.metrics, out.additional, j)) present |= NFAGG_FEAT_ADDITIONAL;
+    if (merge_part<nfagg_quic_metrics>(in, 6, sl.row[6], rec.metrics, out.quic, j)) present |= NFAGG_FEAT_QUIC;
+    out.records[j] = rec;
+    out.present[j] = (uint8_t)present;
+}
+
+hipError_t launch_merge_build(const MergeIn& in, void* d_slots, uint32_t n_slots, uint32_t* d_slot_of, unsigned int* d_n_dup,
+                              uint32_t* d_local_off, uint32_t* d_block_sum, hipStream_t s) {
+    const uint32_t n = in.off[7];
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_merge_build, dim3((n + 255) / 256), dim3(256), 0, s, in, (MergeSlot*)d_slots, n_slots - 1, d_slot_of, d_n_dup);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_merge_flags, dim3((n + 1023) / 1024), dim3(1024), 0, s, n, (const MergeSlot*)d_slots, d_slot_of, d_local_off, d_block_sum);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_fold(const MergeIn& in, const MergeOut& out, const void* d_slots, const uint32_t* d_slot_of,
+                             const uint32_t* d_local_off, const uint64_t* d_block_base, hipStream_t s) {
+    const uint32_t n = in.off[7];
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_merge_fold, dim3((n + 255) / 256), dim3(256), 0, s, in, out, (const MergeSlot*)d_slots, d_slot_of, d_local_off, d_block_base);
+    return hipGetLastError();
+}
+
+size_t merge_slot_bytes() { return sizeof(MergeSlot); }
 
 size_t rollup_struct_size(int kind) {
     switch (kind) {

@@ -139,6 +139,56 @@ class FlowTable:
                                      base.ctypes.data_as(C.c_void_p), folded.ctypes.data_as(C.c_void_p)))
         return base, folded
 
+    # -- map merge (LookupAndDeleteMap's join), nfagg_map_merge
+    _KIND_ORDER = ("additional", "dns", "drops", "network_events", "xlat", "quic")      # NFAGG_ROLLUP_*
+
+    def map_merge(self, main_ids, main_vals, feats: dict, n_cpu: int, cap=None):
+        """feats: {kind: (ids[n], partials[n, n_cpu])}. Returns (records, present, parts dict, n_duplicate_keys):
+        one entry per merged flow, in order of first appearance."""
+        mi = np.ascontiguousarray(main_ids, dtype=FLOW_RECORD["id"])
+        mv = np.ascontiguousarray(main_vals, dtype=FLOW_METRICS)
+        assert len(mi) == len(mv)
+        keep = [mi, mv]
+        main = L.MapView(mi.ctypes.data if len(mi) else None, mv.ctypes.data if len(mv) else None, len(mi))
+        views = (L.MapView * 6)()
+        total = len(mi)
+        for k, name in enumerate(self._KIND_ORDER):
+            if name not in feats:
+                continue
+            fi = np.ascontiguousarray(feats[name][0], dtype=FLOW_RECORD["id"])
+            fv = np.ascontiguousarray(feats[name][1], dtype=ROLLUP_KINDS[name]).reshape(-1)
+            assert fv.size == len(fi) * n_cpu, name
+            keep += [fi, fv]
+            views[k] = L.MapView(fi.ctypes.data if len(fi) else None, fv.ctypes.data if len(fi) else None, len(fi))
+            total += len(fi)
+        cap = total if cap is None else cap
+        recs = np.zeros(max(cap, 1), dtype=FLOW_RECORD)
+        present = np.zeros(max(cap, 1), dtype=np.uint8)
+        parts = {name: np.zeros(max(cap, 1), dtype=ROLLUP_KINDS[name]) for name in self._KIND_ORDER}
+        out = L.MergedFlows(recs.ctypes.data, present.ctypes.data, *[parts[name].ctypes.data for name in self._KIND_ORDER])
+        n_out, n_dup = C.c_size_t(0), C.c_size_t(0)
+        rc = L.lib.nfagg_map_merge(self._h, C.byref(main), views, n_cpu, C.byref(out), cap, C.byref(n_out), C.byref(n_dup))
+        if rc == L.TRUNCATED:
+            return rc, n_out.value
+        self._check(rc)
+        n = n_out.value
+        return recs[:n], present[:n], {k: v[:n] for k, v in parts.items()}, n_dup.value
+
+    def map_merge_device(self, d_main, d_feats: dict, n_cpu: int, d_out: dict, cap: int):
+        """Raw device pointers: d_main = (d_ids, d_vals, n); d_feats = {kind: (d_ids, d_vals, n)};
+        d_out = {"records", "present", kind...: pointer}. Returns (rc, n_out, n_duplicate_keys)."""
+        main = L.MapView(d_main[0] or None, d_main[1] or None, d_main[2])
+        views = (L.MapView * 6)()
+        for k, name in enumerate(self._KIND_ORDER):
+            if name in d_feats:
+                views[k] = L.MapView(d_feats[name][0] or None, d_feats[name][1] or None, d_feats[name][2])
+        out = L.MergedFlows(d_out.get("records") or None, d_out.get("present") or None,
+                            *[d_out.get(name) or None for name in self._KIND_ORDER])
+        n_out, n_dup = C.c_size_t(0), C.c_size_t(0)
+        rc = L.lib.nfagg_map_merge_device(self._h, C.byref(main), views, n_cpu, C.byref(out), cap, C.byref(n_out), C.byref(n_dup))
+        self._check(rc, ok=(L.OK, L.TRUNCATED))
+        return rc, n_out.value, n_dup.value
+
     # -- sketches
     def sketch_snapshot(self, which):
         p, b = C.c_void_p(), C.c_size_t(0)

@@ -93,6 +93,14 @@ uint16_t orc_add_uint16(uint16_t a, uint16_t b);                                
 void orc_rollup(int kind, const void* partials, size_t n_flows, size_t n_cpu,
                 orc_flow_metrics* base, void* folded);
 
+/* ---- pkg/tracer/tracer.go:1022-1146 LookupAndDeleteMap: merge of the drained maps (nfagg_oracle_maps.c).
+ * feat_*[k]: kind k as in orc_rollup (NULL / 0 = map not enabled); feat_vals[k] holds feat_n[k]*n_cpu
+ * partials, flow-major. out_ids/out: room for n_main + sum(feat_n) entries; returns the number of flows,
+ * sorted by key bytes. */
+size_t orc_map_merge(const orc_flow_id* main_ids, const orc_flow_metrics* main_vals, size_t n_main,
+                     const orc_flow_id* const feat_ids[6], const void* const feat_vals[6], const size_t feat_n[6],
+                     size_t n_cpu, orc_flow_id* out_ids, orc_content* out);
+
 /* ---- pkg/flow/account.go ---- */
 typedef struct orc_accounter orc_accounter;
 /* mode 0: Accounter (AccumulateBase). mode 1: kernel dedup merge (bpf/flows.c:76-143). */

@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "libnfagg_oracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("nfagg_oracle.c", "nfagg_oracle_pb.c", "nfagg_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("nfagg_oracle.c", "nfagg_oracle_pb.c", "nfagg_oracle_maps.c", "nfagg_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -54,6 +54,7 @@ def lib():
             "orc_stream_key_index": (_u64, [_u64, _u64, _u64, _vp, C.c_uint32]),
             "orc_gen_stream": (None, [_u64, _u64, _sz, _u64, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
             "orc_pb_encode_record": (_sz, [_vp, _vp, _vp]), "orc_kafka_key": (None, [_vp, _vp]),
+            "orc_map_merge": (_sz, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp]),
             "orc_pb_encode_content": (_sz, [_vp, _vp, _vp, _vp]), "orc_dns_name_dotted": (_sz, [_vp, _vp]),
         }
         for name, (res, args) in sig.items():
@@ -192,6 +193,27 @@ def rollup(kind, partials, n_cpu, base):
     folded = np.zeros(n_flows, dtype=dt)
     lib().orc_rollup(k, _p(parts), n_flows, n_cpu, _p(b), _p(folded))
     return b, folded
+
+
+def map_merge(main_ids, main_vals, feats, n_cpu):
+    """LookupAndDeleteMap (tracer.go:1022-1146). feats: {kind name: (ids[n], partials[n, n_cpu])}.
+    Returns (ids, contents) sorted by key."""
+    mi = np.ascontiguousarray(main_ids, dtype=FLOW_ID)
+    mv = np.ascontiguousarray(main_vals, dtype=FLOW_METRICS)
+    ids_p, vals_p, ns = (C.c_void_p * 6)(), (C.c_void_p * 6)(), (C.c_size_t * 6)()
+    keep, total = [], len(mi)
+    for name, (fi, fv) in feats.items():
+        k = KIND_INDEX[name]
+        fi = np.ascontiguousarray(fi, dtype=FLOW_ID)
+        fv = np.ascontiguousarray(fv, dtype=KIND_DTYPES[k]).reshape(-1)
+        assert fv.size == len(fi) * n_cpu
+        keep += [fi, fv]
+        ids_p[k], vals_p[k], ns[k] = fi.ctypes.data, fv.ctypes.data, len(fi)
+        total += len(fi)
+    out_ids = np.zeros(max(total, 1), dtype=FLOW_ID)
+    out = np.zeros(max(total, 1), dtype=CONTENT)
+    n = lib().orc_map_merge(_p(mi), _p(mv), len(mi), ids_p, vals_p, ns, n_cpu, _p(out_ids), _p(out))
+    return out_ids[:n].copy(), out[:n].copy()
 
 
 # ---- record -> protobuf (nfagg_oracle_pb.c)
