@@ -16,4 +16,6 @@ from .table import (FlowTable, NfaggError, key_hash, shard_of, ip_hash, hll_esti
 from .accounter import (Accounter, NewAccounter, NewRecord, Record, IntfDirUdn, NewIntfDirUdn, Metrics, NoOp, CLOSE,
                         SetInterfaceNamer, SetGlobalIP)
 from . import synth
+from . import pipeline
+from .pipeline import CapacityLimiter, RecordToMap, DirectFLPStdout
 from . import distributed
