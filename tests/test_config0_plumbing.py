@@ -17,6 +17,15 @@ NOW, MONO = 1_700_000_000_000_000_000, 3_000_000
 NAMER = lambda ifx, mac: {2: "eth0", 3: "eth1", 4: "br-ex", 5: "ovn-k8s-mp0"}.get(ifx, "unknown")
 
 
+@pytest.fixture(autouse=True)
+def _restore_globals(nf):
+    """SetInterfaceNamer / SetGlobalIP are process globals, as in the reference (record.go:50-61)."""
+    from netobserv_ebpf_agent_amd import accounter as A
+    namer, ip = A._interface_namer, A._agent_ip
+    yield
+    nf.SetInterfaceNamer(namer); nf.SetGlobalIP(ip)
+
+
 def _mods(nf):
     import importlib
     return importlib.import_module("netobserv_ebpf_agent_amd.pipeline")
