@@ -241,6 +241,9 @@ typedef struct nfagg_config {
      * NULL -> the library allocates. Sizes as listed under NFAGG_CM_* above,
      * HLL buffers hold uint32_t registers. */
     void*    ext_sketch[4];
+    uint32_t copy_threads;       /* host threads that copy a caller buffer into the pinned staging ring in
+                                    nfagg_ingest (one core moves ~28 GB/s, PCIe Gen5 x16 takes ~50); 0 -> 4, 1 -> inline */
+    uint32_t reserved_;
 } nfagg_config;
 
 typedef struct nfagg_stats {

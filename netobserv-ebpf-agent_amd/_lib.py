@@ -39,6 +39,7 @@ class Config(C.Structure):
         ("cm_depth", C.c_uint32), ("cm_log2_width", C.c_uint32), ("hll_p", C.c_uint32),
         ("staging_records", C.c_uint64), ("n_shards", C.c_uint32), ("shard_id", C.c_uint32),
         ("profile", C.c_uint32), ("ingest_variant", C.c_uint32), ("ext_sketch", C.c_void_p * 4),
+        ("copy_threads", C.c_uint32), ("reserved_", C.c_uint32),
     ]
 
 

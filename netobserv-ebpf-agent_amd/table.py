@@ -28,7 +28,7 @@ class FlowTable:
 
     def __init__(self, max_entries=5000, device=0, mode=L.MODE_ACCOUNTER, sketches=0, cm_depth=0, cm_log2_width=0,
                  hll_p=0, table_log2_slots=0, staging_records=0, n_shards=1, shard_id=0, profile=False,
-                 ingest_variant=0, ext_sketch=None):
+                 ingest_variant=0, ext_sketch=None, copy_threads=0):
         cfg = L.Config()
         cfg.struct_size = C.sizeof(L.Config)
         cfg.device = device
@@ -41,6 +41,7 @@ class FlowTable:
         cfg.n_shards, cfg.shard_id = n_shards, shard_id
         cfg.profile = 1 if profile else 0
         cfg.ingest_variant = ingest_variant
+        cfg.copy_threads = copy_threads
         if ext_sketch:
             for k, p in enumerate(ext_sketch):
                 cfg.ext_sketch[k] = p

@@ -10,15 +10,17 @@ from netobserv_ebpf_agent_amd import synth
 n, flows = 20_000_000, 1_000_000
 th = synth.zipf_thresholds(flows, 1.1)
 recs = synth.stream_host(n, seed=2, n_keys=flows, thresholds=th)
-for staging in (1 << 20, 1 << 22):
-    with nf.FlowTable(max_entries=1 << 26, staging_records=staging) as tab:
+for staging, threads in ((1 << 20, 1), (1 << 20, 4), (1 << 22, 1), (1 << 22, 4), (1 << 22, 8)):
+    with nf.FlowTable(max_entries=1 << 26, staging_records=staging, copy_threads=threads) as tab:
         tab.ingest(recs[: 2 * staging]); tab.evict()
         t0 = time.perf_counter()
         rc, c = tab.ingest(recs)
         tab.sync()
         dt = time.perf_counter() - t0
-        print(f"nfagg_ingest (pageable host buffer, staging {staging} records): {n / dt / 1e6:.1f} M records/s = {n * 144 / dt / 1e9:.1f} GB/s")
+        print(f"nfagg_ingest (pageable host buffer, staging {staging} records, {threads} copy thread(s)): {n / dt / 1e6:.1f} M records/s = {n * 144 / dt / 1e9:.1f} GB/s")
         tab.evict()
+        if threads != 1:
+            continue
         # staging acquire/commit: fill cost excluded (the ring reader would write straight into the pinned buffer)
         buf = tab.staging_acquire(); m = len(buf); buf[:] = recs[:m]; tab.staging_commit(m)
         t0 = time.perf_counter(); done = 0
