@@ -293,6 +293,31 @@ size_t orc_acc_ingest(orc_accounter* a, const void* records, size_t n) {
     return n;
 }
 
+static uint32_t shard_mix(const orc_flow_id* id) {      /* cheap word mix, only used to split work between cores */
+    uint64_t w[5]; memcpy(w, id, 40); w[4] &= 0x00FFFFFFFFFFFFFFull;
+    uint64_t h = (w[0] ^ (w[1] * 0x9E3779B97F4A7C15ull)) + (w[2] ^ (w[3] * 0xC2B2AE3D27D4EB4Full)) + w[4] * 0x165667B19E3779F9ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    return (uint32_t)h;
+}
+
+/* Best-effort multi-core CPU baseline (bench.py cpu_baseline.multicore): the records whose
+ * FNV hash of the key falls into `shard` of `n_shards`, folded as orc_acc_ingest does; every worker scans the whole
+ * batch and skips the records of the other shards. Not a reference path: the reference's Accounter is one goroutine. */
+size_t orc_acc_ingest_shard(orc_accounter* a, const void* records, size_t n, uint32_t n_shards, uint32_t shard) {
+    const orc_flow_record* r = (const orc_flow_record*)records;
+    size_t i = 0, mine = 0;
+    while (i < n) {
+        size_t j = i;
+        while (j < n && shard_mix(&r[j].id) % n_shards != shard) j++;
+        if (j == n) break;
+        size_t k = j + 1;   /* fold one record of this shard */
+        if (orc_acc_ingest(a, &r[j], 1) != 1) return mine;
+        mine++;
+        i = k;
+    }
+    return mine;
+}
+
 static int rec_key_cmp(const void* x, const void* y) { return memcmp(x, y, 40); }
 
 size_t orc_acc_evict(orc_accounter* a, void* out, size_t cap) {       /* account.go:102-124 */

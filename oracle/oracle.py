@@ -40,6 +40,7 @@ def lib():
             "orc_acc_new": (_vp, [_u64, C.c_int]), "orc_acc_free": (None, [_vp]),
             "orc_acc_ingest": (_sz, [_vp, _vp, _sz]), "orc_acc_len": (_sz, [_vp]),
             "orc_acc_evict": (_sz, [_vp, _vp, _sz]),
+            "orc_acc_ingest_shard": (_sz, [_vp, _vp, _sz, C.c_uint32, C.c_uint32]),
             "orc_record_times": (None, [C.c_int64, _u64, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
             "orc_key_hash": (_u64, [_vp]), "orc_ip_hash": (_u64, [_vp, C.c_uint32]),
             "orc_shard_of": (C.c_uint32, [_vp, C.c_uint32]),
@@ -117,6 +118,10 @@ class Accounter:
     def ingest(self, records) -> int:
         r = np.ascontiguousarray(records)
         return lib().orc_acc_ingest(self._a, _p(r), r.nbytes // 144)
+
+    def ingest_shard(self, records, n_shards, shard) -> int:
+        r = np.ascontiguousarray(records)
+        return lib().orc_acc_ingest_shard(self._a, _p(r), r.nbytes // 144, n_shards, shard)
 
     def __len__(self):
         return lib().orc_acc_len(self._a)
