@@ -53,6 +53,15 @@ struct Stage {
     uint32_t cnt[kSpillParts];
 };
 
+// Pass-1 admission filter ("doorkeeper"): entries are never evicted, so WHICH flows get the 1024 entries
+// decides the hit rate. First come, first served hands about half of them to one-off flows of the cold tail
+// (40 % of a Zipf(1.1) stream are tail records, each a distinct flow). With the filter a flow is admitted on its
+// SECOND appearance in this workgroup's share: bit (hash) unset -> set it and spill the record. Hot flows come
+// back within a few tiles; a tail flow rarely does before the cache is full. 32 Ki bits = the 4 KiB of LDS
+// the cache and the spill staging leave free.
+constexpr int kDoorBits = 32768;
+struct Door { uint32_t bits[kDoorBits / 32]; };
+
 NF_DEV uint32_t part_of(uint64_t h) { return (uint32_t)(h >> 29) & (kSpillParts - 1); }
 
 NF_DEV void cache_init(Cache& L, int tid) {
@@ -63,14 +72,19 @@ NF_DEV void cache_init(Cache& L, int tid) {
     }
 }
 
-// phase A: find or claim the entry of hash h (the creator writes the key); -1 = window full
-NF_DEV int cache_claim(Cache& L, uint64_t h, const uint64_t w[5]) {
+// phase A: find or claim the entry of hash h (the creator writes the key); -1 = window full (or not admitted yet)
+template <bool DOOR>
+NF_DEV int cache_claim(Cache& L, uint32_t* door, uint64_t h, const uint64_t w[5]) {
     const uint64_t hk = h | 1ull;
     uint32_t e = (uint32_t)(h >> 40) & (kEntries - 1);
 #pragma unroll 1
     for (int p = 0; p < kProbe; p++) {
         uint64_t cur = L.h64[e];
         if (cur == 0) {
+            if (DOOR) {
+                const uint32_t b = (uint32_t)(h >> 14) & (kDoorBits - 1), m = 1u << (b & 31);
+                if (!(door[b >> 5] & m)) { atomicOr(&door[b >> 5], m); return -1; }
+            }
             cur = atomicCAS((unsigned long long*)&L.h64[e], 0ull, (unsigned long long)hk);
             if (cur == 0) {
 #pragma unroll
@@ -183,12 +197,13 @@ NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L
 
 // QUEUE == false: pass 1 over records[0..n). QUEUE == true: pass 2, workgroup b folds
 // the records whose indices pass 1 queued for partition b.
-template <bool SKETCH, bool QUEUE, bool TIMING>
+template <bool SKETCH, bool QUEUE, bool TIMING, bool DOOR = false>
 __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
                                                  uint64_t n, uint64_t seq_base) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     Cache& L = *reinterpret_cast<Cache*>(lds_raw);
     Stage& S = *reinterpret_cast<Stage*>(lds_raw + sizeof(Cache));   // pass 1 only
+    uint32_t* door = reinterpret_cast<Door*>(lds_raw + sizeof(Cache) + sizeof(Stage))->bits;   // pass 1 with DOOR only
     const int tid = threadIdx.x;
     const uint32_t seq_base32 = (uint32_t)seq_base;
     uint64_t count = n;
@@ -201,6 +216,7 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
     }
     cache_init(L, tid);
     if (!QUEUE) for (int p = tid; p < kSpillParts; p += kBlock) S.cnt[p] = 0;
+    if (DOOR) for (int p = tid; p < kDoorBits / 32; p += kBlock) door[p] = 0;
     __syncthreads();
     if (QUEUE && tid == 0) q.qtail[blockIdx.x] = 0;                    // every lane has read it: ready for the next batch
 
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
         }
         const uint32_t seq32 = seq_base32 + (uint32_t)i;
         if (TIMING) { asm volatile("" :: "v"(h)); NF_TICK(0); }
-        int ent = valid ? cache_claim(L, h, w) : -1;
+        int ent = valid ? cache_claim<DOOR && !QUEUE>(L, door, h, w) : -1;
         NF_TICK(1);
         __syncthreads();
         NF_TICK(2);
@@ -376,16 +392,17 @@ __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView 
     if (direct) aadd(&t.ctr->n_direct, direct);
 }
 
-template <bool SKETCH, bool T1 = false, bool T2 = false>
+template <bool SKETCH, bool T1 = false, bool T2 = false, bool DOOR = true>
 static hipError_t run(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                       uint64_t seq_base, hipStream_t s) {
-    const size_t lds1 = sizeof(Cache) + sizeof(Stage), lds2 = sizeof(Cache);
+    const size_t lds1 = sizeof(Cache) + sizeof(Stage) + (DOOR ? sizeof(Door) : 0), lds2 = sizeof(Cache);
+    static_assert(sizeof(Cache) + sizeof(Stage) + sizeof(Door) <= 160 * 1024, "pass 1 needs the whole LDS of a CU");
     static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold<SKETCH, false, T1>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold<SKETCH, false, T1, DOOR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold<SKETCH, true, T2>),
@@ -397,7 +414,7 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     uint64_t grid = 256;
     if (grid > tiles) grid = tiles;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_fold<SKETCH, false, T1>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
+    hipLaunchKernelGGL((k_fold<SKETCH, false, T1, DOOR>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_fold<SKETCH, true, T2>), dim3(kSpillParts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
@@ -416,6 +433,9 @@ hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const Sp
     if (!q.queue || !q.qtail || !q.ovf || !q.ovf_tail || q.qcap < 4 || (q.qcap & 3u)) return hipErrorInvalidValue;
     if (variant == 8) return part::run<false, true, false>(t, sk, q, d_records, n, seq_base, s);   // diagnostics: pass-1 phase timing
     if (variant == 9) return part::run<false, false, true>(t, sk, q, d_records, n, seq_base, s);   // diagnostics: pass-2 phase timing
+    if (variant == 11)   // A/B: pass 1 without the admission filter (first come, first served)
+        return sk.flags ? part::run<true, false, false, false>(t, sk, q, d_records, n, seq_base, s)
+                        : part::run<false, false, false, false>(t, sk, q, d_records, n, seq_base, s);
     return sk.flags ? part::run<true>(t, sk, q, d_records, n, seq_base, s) : part::run<false>(t, sk, q, d_records, n, seq_base, s);
 }
 

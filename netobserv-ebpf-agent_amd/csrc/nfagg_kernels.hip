@@ -143,7 +143,7 @@ hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const 
                                 int variant, hipStream_t s);  // nfagg_ingest_cached.hip
 
 constexpr uint64_t kPartMinBatch = 1u << 16;
-bool ingest_needs_spill(int mode, int variant) { return mode == 0 && (variant == 0 || (variant >= 8 && variant <= 10)); }
+bool ingest_needs_spill(int mode, int variant) { return mode == 0 && (variant == 0 || (variant >= 8 && variant <= 11)); }
 bool ingest_fuses_sketches(int mode, int variant) { return mode == 0 && variant != 1 && variant != 2 && variant != 6 && variant != 8 && variant != 9; }
 
 hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
@@ -156,7 +156,7 @@ hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d
     // 0 (default): two-pass partitioned fold (nfagg_ingest_part.hip; 8/9 = its phase-timing builds) — batches too
     // small to amortise its extra launches take the single-pass cached kernel, which is what variant 7 always runs.
     // 3..5: other geometries of the cached kernel, 6: its phase-timing build; 1: direct; 2: per-tile LDS fold.
-    if ((variant >= 8 && variant <= 10) || (variant == 0 && n >= kPartMinBatch))   // 10: two-pass whatever the size
+    if ((variant >= 8 && variant <= 11) || (variant == 0 && n >= kPartMinBatch))   // 10: two-pass whatever the size; 11: same without the admission filter
         return launch_ingest_part(t, sk, t.spill, d_records, n, seq_base, variant, s);
     if (variant == 2) return launch_ingest_lds(t, d_records, n, seq_base, variant, s);
     if (variant != 1) return launch_ingest_cached(t, sk, d_records, n, seq_base, variant, s);

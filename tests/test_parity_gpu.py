@@ -115,7 +115,7 @@ def test_evict_period(nf):
 
 # ---------------------------------------------------------------- seeded streams vs the oracle
 @pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3, 4, 5, 7, 10])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3, 4, 5, 7, 10, 11])
 @pytest.mark.parametrize("batch", [1 << 30, 1000, 257])
 def test_stream_parity(nf, O, variant, ingest_variant, batch):
     th = O.zipf_thresholds(3000, 1.1)
@@ -136,7 +136,7 @@ def test_config1_10k_records_1k_keys(nf, O):
     assert len(want[0][1]) == len(np.unique(recs["id"]["src_port"]))
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3, 4, 5, 7, 10])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3, 4, 5, 7, 10, 11])
 def test_hot_key_stream(nf, O, ingest_variant):
     """BASELINE configs[4] shape: 90 % of the records are one flow (LDS / atomic contention)."""
     th = O.zipf_thresholds(5000, 1.1)
