@@ -83,7 +83,9 @@ NF_DEV int cache_claim(Cache& L, uint32_t* door, uint64_t h, const uint64_t w[5]
         if (cur == 0) {
             if (DOOR) {
                 const uint32_t b = (uint32_t)(h >> 14) & (kDoorBits - 1), m = 1u << (b & 31);
-                if (!(door[b >> 5] & m)) { atomicOr(&door[b >> 5], m); return -1; }
+                // the atomic's own return value decides: of the lanes that meet a new flow in the same tile exactly one
+                // is turned away (a hot flow would otherwise spill a whole burst into one partition's staging group)
+                if (!(door[b >> 5] & m) && !(atomicOr(&door[b >> 5], m) & m)) return -1;
             }
             cur = atomicCAS((unsigned long long*)&L.h64[e], 0ull, (unsigned long long)hk);
             if (cur == 0) {

@@ -16,16 +16,18 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof"
 os.makedirs("profiles", exist_ok=True)
-ks = glob.glob(f"{src}/trace/**/*_kernel_stats.csv", recursive=True)
+ks = sorted(glob.glob(f"{src}/trace/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
 if ks:
-    shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
+    shutil.copy(ks[-1], f"profiles/{tag}_kernel_stats.csv")
 for j in glob.glob(f"{src}/trace_bench.json"):
     shutil.copy(j, f"profiles/{tag}_bench_under_rocprof.json")
 
 
 def collect(d, want=None):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
+    files = glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)
+    # gpurun merges into an existing gpurun_out/: keep only the newest run of this directory
+    for f in sorted(files, key=os.path.getmtime)[-1:]:
         for row in csv.DictReader(open(f)):
             agg[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return agg
