@@ -68,6 +68,9 @@ struct nfagg_handle {
     // (host variant) [6..12] ids, [13..19] values, [20..27] outputs
     void* d_mm[28] = {};
     size_t d_mm_cap[28] = {};
+    void* d_sort[2] = {};          // eviction: live list in slot order, radix-sort scratch
+    size_t d_sort_cap[2] = {};
+    int sort_bits = 0;
     void* d_pb[15] = {};
     size_t d_pb_cap[15] = {};
     // spill queues of the two-pass ingest
@@ -394,6 +397,7 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->d_hist) hipFree(h->d_hist);
     if (h->d_spill) hipFree(h->d_spill);
     for (int k = 0; k < 15; k++) if (h->d_pb[k]) hipFree(h->d_pb[k]);
+    for (int k = 0; k < 2; k++) if (h->d_sort[k]) hipFree(h->d_sort[k]);
     for (int k = 0; k < 28; k++) if (h->d_mm[k]) hipFree(h->d_mm[k]);
     if (h->tv.spill.qtail) hipFree(h->tv.spill.qtail);
     if (h->d_evict) hipFree(h->d_evict);
@@ -531,9 +535,27 @@ static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device
         d_out = h->d_evict;
     }
     HIP_TRY(h, hipMemsetAsync(&h->tv.ctr->n_out, 0, sizeof(unsigned long long), h->stream));
+    // large table: visit the claimed slots in address order (see launch_sort_slots)
+    TableView tv = h->tv;
+    const bool sort_slots = claimed >= (1u << 16) && h->slots >= (1ull << 24) && claimed < (1ull << 31);
+    size_t temp_bytes = 0;
+    if (sort_slots) {
+        int bits = 0;
+        while ((1ull << bits) < h->slots) bits++;
+        h->sort_bits = bits;
+        hipError_t es = launch_sort_slots(h->tv.live_list, nullptr, claimed, bits, nullptr, &temp_bytes, h->stream);
+        if (es != hipSuccess) return fail(h, NFAGG_EDEVICE, "sort size query failed: %s", hipGetErrorString(es));
+        if ((rc = ensure_bytes(h, &h->d_sort[0], &h->d_sort_cap[0], claimed * sizeof(uint32_t))) != NFAGG_OK) return rc;
+        if ((rc = ensure_bytes(h, &h->d_sort[1], &h->d_sort_cap[1], temp_bytes + 16)) != NFAGG_OK) return rc;
+    }
     EventPair ep{};
     if (h->cfg.profile) prof_begin(h, ep, 1);
-    hipError_t e = launch_evict(h->tv, claimed, h->must_evict ? h->split_seq : ~0ull, d_out, h->stream);
+    if (sort_slots) {
+        hipError_t es = launch_sort_slots(h->tv.live_list, (uint32_t*)h->d_sort[0], claimed, h->sort_bits, h->d_sort[1], &temp_bytes, h->stream);
+        if (es != hipSuccess) return fail(h, NFAGG_EDEVICE, "slot sort failed: %s", hipGetErrorString(es));
+        tv.live_list = (uint32_t*)h->d_sort[0];
+    }
+    hipError_t e = launch_evict(tv, claimed, h->must_evict ? h->split_seq : ~0ull, d_out, h->stream);
     if (h->cfg.profile) prof_end(h, ep);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "evict launch failed: %s", hipGetErrorString(e));
     HIP_TRY(h, hipMemcpyAsync(h->h_ctr, h->tv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));

@@ -147,6 +147,7 @@ hipError_t launch_first_flags(const TableView& t, const uint32_t* d_slot_idx, ui
                               uint8_t* d_flags, uint32_t* d_block_counts, hipStream_t s);
 // Write every live flow whose first record has seq < seq_limit as a 144-byte
 // record (dense, order unspecified), zero every claimed slot, reset n_live.
+hipError_t launch_sort_slots(const uint32_t* d_in, uint32_t* d_out, uint64_t n, int end_bit, void* d_temp, size_t* temp_bytes, hipStream_t s);
 hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);
 // Sketch update over a batch (nfagg_sketch.hip).
 hipError_t launch_sketch_update(const SketchView& sk, const TableView& t, const void* d_records, uint64_t n, hipStream_t s);

@@ -2,6 +2,7 @@
 //
 // Replaces the body of Accounter.Account's record arm and Accounter.evict
 // (pkg/flow/account.go:81-96, 102-124). HBM-bound hash/scatter work: no MFMA.
+#include <hipcub/hipcub.hpp>
 #include "nfagg_device.h"
 
 namespace nfagg {
@@ -177,6 +178,14 @@ hipError_t launch_first_flags(const TableView& t, const uint32_t* d_slot_idx, ui
     const int blocks = (int)((n + kFlagBlock - 1) / kFlagBlock);
     (void)hipGetLastError(); hipLaunchKernelGGL(k_first_flags, dim3(blocks), dim3(kFlagBlock), 0, s, t, d_slot_idx, n, seq_base, d_flags, d_block_counts);
     return hipGetLastError();
+}
+
+// Radix sort of the live list by slot index (rocPRIM through hipCUB). Eviction visits the claimed slots of a table that
+// can span tens of GiB; in claim order every access lands on another page and the kernel is bound by address
+// translation (0.16 ms for 287 k flows of a 64 GiB table against 0.08 ms of a 2 GiB one); in slot order consecutive
+// lanes walk the table front to back. temp == nullptr: size query.
+hipError_t launch_sort_slots(const uint32_t* d_in, uint32_t* d_out, uint64_t n, int end_bit, void* d_temp, size_t* temp_bytes, hipStream_t s) {
+    return hipcub::DeviceRadixSort::SortKeys(d_temp, *temp_bytes, d_in, d_out, (int)n, 0, end_bit, s);
 }
 
 hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s) {

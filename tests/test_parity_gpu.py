@@ -297,3 +297,22 @@ def test_partition_skew_overflows_the_spill_queues(nf, O):
         st = tab.stats()
         assert st.records_bypassed > 2 * (2 * n // 2048 + 1024), "the stream was meant to overflow one partition queue"
         assert_records_equal(nf.sort_by_key(tab.evict()), want)
+
+
+@pytest.mark.parametrize("mode", ["accounter", "dedup"])
+def test_large_table_evicts_in_slot_order(nf, O, mode):
+    """A table of 2^24 slots or more with 65 536+ live flows takes the slot-sorted eviction (launch_sort_slots):
+    same flows, bit-exact, two epochs so that the zeroing is checked too."""
+    th = O.zipf_thresholds(150_000, 0.6)
+    recs = O.gen_stream(400_000, seed=31, n_keys=150_000, thresholds=th, variant=2 if mode == "dedup" else 1)
+    omode = 1 if mode == "dedup" else 0
+    want = O.run_accounter(recs, 1 << 23, omode)[0][1]
+    assert len(want) >= 1 << 16
+    kw = dict(mode=nf.MODE_KERNEL_DEDUP) if mode == "dedup" else {}
+    with nf.FlowTable(max_entries=1 << 23, **kw) as tab:
+        assert tab.stats().table_slots >= 1 << 24
+        for _ in range(2):
+            assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
+            got = nf.sort_by_key(tab.evict(nf.REASON_TIMEOUT))
+            assert_records_equal(got, want, mode)
+            assert len(tab) == 0
