@@ -54,14 +54,20 @@ struct FoldCache {
     uint32_t min_seq[K];
 };
 
-// find or claim the entry of sub-flow hash hs; the creator writes key and interface. -1 = window full
-template <typename Cache, int K>
-NF_DEV int claim(Cache& L, uint64_t hs, const uint64_t w[5], uint32_t ifx) {
+// find or claim the entry of sub-flow hash hs; the creator writes key and interface. -1 = window full, or the
+// sub-flow is seen for the first time: entries are never evicted, so a sub-flow is admitted on its second
+// appearance (admission filter `door`, DOORBITS bits of LDS, as in nfagg_ingest_part.hip) — one-off sub-flows of
+// the cold tail do not take the entries of the hot ones. Exactly one of the lanes that meet a new sub-flow in
+// the same tile is turned away (the atomic's return value decides).
+template <typename Cache, int K, int DOORBITS>
+NF_DEV int claim(Cache& L, uint32_t* door, uint64_t hs, const uint64_t w[5], uint32_t ifx) {
     uint32_t e = (uint32_t)(hs >> 40) & (K - 1);
 #pragma unroll 1
     for (int p = 0; p < kProbe; p++) {
         uint64_t cur = L.h64[e];
         if (cur == 0) {
+            const uint32_t b = (uint32_t)(hs >> 14) & (DOORBITS - 1), m = 1u << (b & 31);
+            if (!(door[b >> 5] & m) && !(atomicOr(&door[b >> 5], m) & m)) return -1;
             cur = atomicCAS((unsigned long long*)&L.h64[e], 0ull, (unsigned long long)hs);
             if (cur == 0) {
 #pragma unroll
@@ -99,12 +105,15 @@ NF_DEV void lds_dir_insert(FoldCache<K>& L, int ent, uint64_t v) {
 
 constexpr int kClaimEntries = 2048;
 constexpr int kFoldEntries = 1024;
+constexpr int kClaimDoorBits = 65536, kFoldDoorBits = 32768;   // 8 KiB / 4 KiB of LDS behind the caches
 
 __global__ __launch_bounds__(kBlock) void k_dedup_claim_cached(TableView t, const void* __restrict__ recs, uint64_t n, uint64_t seq_base) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     ClaimCache<kClaimEntries>& L = *reinterpret_cast<ClaimCache<kClaimEntries>*>(lds_raw);
+    uint32_t* door = reinterpret_cast<uint32_t*>(lds_raw + sizeof(ClaimCache<kClaimEntries>));
     const int tid = threadIdx.x;
     for (int e = tid; e < kClaimEntries; e += kBlock) { L.h64[e] = 0; L.min_seq[e] = 0xffffffffu; }
+    for (int e = tid; e < kClaimDoorBits / 32; e += kBlock) door[e] = 0;
     __syncthreads();
     const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
     unsigned long long skipped = 0;
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void k_dedup_claim_cached(TableView t, cons
         if (valid && !record_prologue(t, recs, i, r, w, h)) { valid = false; skipped++; }
         const uint32_t seq32 = (uint32_t)(seq_base + i);
         const uint32_t ifx = valid ? r.d[21] : 0;
-        const int ent0 = valid ? claim<ClaimCache<kClaimEntries>, kClaimEntries>(L, subflow_hash(h, ifx), w, ifx) : -1;
+        const int ent0 = valid ? claim<ClaimCache<kClaimEntries>, kClaimEntries, kClaimDoorBits>(L, door, subflow_hash(h, ifx), w, ifx) : -1;
         __syncthreads();
         if (valid) {
             if (ent0 >= 0 && same_subflow(L, ent0, w, ifx)) {
@@ -149,7 +158,9 @@ __global__ __launch_bounds__(kBlock) void k_dedup_claim_cached(TableView t, cons
 __global__ __launch_bounds__(kBlock) void k_dedup_fold_cached(TableView t, const void* __restrict__ recs, uint64_t n, uint64_t seq_base) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     FoldCache<kFoldEntries>& L = *reinterpret_cast<FoldCache<kFoldEntries>*>(lds_raw);
+    uint32_t* door = reinterpret_cast<uint32_t*>(lds_raw + sizeof(FoldCache<kFoldEntries>));
     const int tid = threadIdx.x;
+    for (int e = tid; e < kFoldDoorBits / 32; e += kBlock) door[e] = 0;
     for (int e = tid; e < kFoldEntries; e += kBlock) {
         L.h64[e] = 0; L.bytes[e] = 0; L.endl_lo[e] = 0; L.endl_hi[e] = 0; L.dscp_tag[e] = 0; L.samp_tag[e] = 0;
         L.ssl_first[e] = 0; L.cs_tag[e] = 0; L.ks_tag[e] = 0; L.dir[0][e] = 0; L.dir[1][e] = 0;
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_dedup_fold_cached(TableView t, const
         if (valid && !record_prologue(t, recs, i, r, w, h)) valid = false;
         const uint32_t seq32 = (uint32_t)(seq_base + i);
         const uint32_t ifx = valid ? r.d[21] : 0;
-        const int ent0 = valid ? claim<FoldCache<kFoldEntries>, kFoldEntries>(L, subflow_hash(h, ifx), w, ifx) : -1;
+        const int ent0 = valid ? claim<FoldCache<kFoldEntries>, kFoldEntries, kFoldDoorBits>(L, door, subflow_hash(h, ifx), w, ifx) : -1;
         __syncthreads();
         if (valid) {
             if (ent0 >= 0 && same_subflow(L, ent0, w, ifx)) {
@@ -234,7 +245,9 @@ __global__ __launch_bounds__(kBlock) void k_dedup_fold_cached(TableView t, const
 hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (!t.aux) return hipErrorInvalidValue;
-    const size_t lds1 = sizeof(dcache::ClaimCache<dcache::kClaimEntries>), lds2 = sizeof(dcache::FoldCache<dcache::kFoldEntries>);
+    const size_t lds1 = sizeof(dcache::ClaimCache<dcache::kClaimEntries>) + dcache::kClaimDoorBits / 8,
+                 lds2 = sizeof(dcache::FoldCache<dcache::kFoldEntries>) + dcache::kFoldDoorBits / 8;
+    static_assert(sizeof(dcache::FoldCache<dcache::kFoldEntries>) + dcache::kFoldDoorBits / 8 <= 160 * 1024, "LDS of one CU");
     static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
