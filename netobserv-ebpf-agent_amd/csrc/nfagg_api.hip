@@ -139,7 +139,7 @@ int ensure_bytes(nfagg_handle* h, void** p, size_t* cap, size_t need);
 int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t seq_base) {
     EventPair ep{};
     const bool prof = h->cfg.profile != 0;
-    if (ingest_needs_spill((int)h->cfg.mode, (int)h->cfg.ingest_variant)) {
+    if (ingest_needs_spill((int)h->cfg.mode, (int)h->cfg.ingest_variant, n)) {
         // room for twice the even share of a batch in which every record spills; beyond that the kernel merges directly
         uint64_t qcap = (2 * n / kSpillParts + 1024 + 3) & ~3ull;
         // overflow list: every record may overflow, plus one padded group per partition per workgroup
@@ -160,7 +160,7 @@ int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t 
     hipError_t e = launch_ingest(h->tv, h->sk, d, n, seq_base, (int)h->cfg.mode, (int)h->cfg.ingest_variant, h->stream);
     if (prof) prof_end(h, ep);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "ingest launch failed: %s", hipGetErrorString(e));
-    if (h->sk.flags && !ingest_fuses_sketches((int)h->cfg.mode, (int)h->cfg.ingest_variant)) {
+    if (h->sk.flags && !ingest_fuses_sketches((int)h->cfg.mode, (int)h->cfg.ingest_variant, n, h->sk.flags)) {
         if (prof) prof_begin(h, ep, 2);
         e = launch_sketch_update(h->sk, h->tv, d, n, h->stream);
         if (prof) prof_end(h, ep);

@@ -129,8 +129,8 @@ struct SketchView {
 // (pass sk.flags = 0 to disable); otherwise the caller launches launch_sketch_update itself.
 hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                          int mode, int variant, hipStream_t s);
-bool ingest_fuses_sketches(int mode, int variant);
-bool ingest_needs_spill(int mode, int variant);
+bool ingest_fuses_sketches(int mode, int variant, uint64_t n, uint32_t sketch_flags);
+bool ingest_needs_spill(int mode, int variant, uint64_t n);
 hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                               uint64_t seq_base, int variant, hipStream_t s);
 // Kernel-dedup mode (nfagg_dedup.hip): two passes over the batch (claim + earliest interfaces, then fold).

@@ -143,24 +143,38 @@ hipError_t launch_ingest_lds(const TableView& t, const void* d_records, uint64_t
 hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                                 int variant, hipStream_t s);  // nfagg_ingest_cached.hip
 
-constexpr uint64_t kPartMinBatch = 1u << 16;
-bool ingest_needs_spill(int mode, int variant) { return mode == 0 && (variant == 0 || (variant >= 8 && variant <= 11)); }
-bool ingest_fuses_sketches(int mode, int variant) { return mode == 0 && variant != 1 && variant != 2 && variant != 6 && variant != 8 && variant != 9; }
+// Default kernel by batch size, measured on configs[1]'s stream (profiles/r01e_batch_size_crossover.txt):
+//   below 6 144 records the direct kernel (one record per lane, HBM atomics; no LDS cache to set up and flush): 14 / 24 us
+//     per 1 024 / 4 096 records against 34 / 35 us for the cached kernel;
+//   below 3 Mi records the single-pass LDS-cached kernel: 0.046 ms per 65 536 records against 0.098 ms for the three
+//     launches of the two-pass fold, 0.46 against 0.51 ms at 2 Mi;
+//   from there the two-pass partitioned fold: 0.74 against 0.79 ms at 4 Mi, 5.5 against 12.5 ms at 100 M.
+constexpr uint64_t kDirectMaxBatch = 6144;
+constexpr uint64_t kPartMinBatch = 3u << 20;
+constexpr uint64_t kDedupCachedMinBatch = 1u << 16;
+static bool takes_two_pass(int variant, uint64_t n) { return (variant >= 8 && variant <= 11) || (variant == 0 && n >= kPartMinBatch); }
+static bool takes_direct(int variant, uint64_t n, uint32_t sketch_flags) {
+    return variant == 1 || (variant == 0 && n < kDirectMaxBatch && sketch_flags == 0);   // with sketches on, the cached kernel fuses them: one launch
+}
+bool ingest_needs_spill(int mode, int variant, uint64_t n) { return mode == 0 && takes_two_pass(variant, n); }
+bool ingest_fuses_sketches(int mode, int variant, uint64_t n, uint32_t sketch_flags) {
+    return mode == 0 && !takes_direct(variant, n, sketch_flags) && variant != 2 && variant != 6 && variant != 8 && variant != 9;
+}
 
 hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                          int mode, int variant, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (mode == 1) {   // NFAGG_MODE_KERNEL_DEDUP: LDS-cached passes; direct per-record passes for small batches (variant 1: always, 10: never)
-        if (variant == 1 || (variant != 10 && n < kPartMinBatch)) return launch_ingest_dedup(t, d_records, n, seq_base, s);
+        if (variant == 1 || (variant != 10 && n < kDedupCachedMinBatch)) return launch_ingest_dedup(t, d_records, n, seq_base, s);
         return launch_ingest_dedup_cached(t, d_records, n, seq_base, s);
     }
     // 0 (default): two-pass partitioned fold (nfagg_ingest_part.hip; 8/9 = its phase-timing builds) — batches too
     // small to amortise its extra launches take the single-pass cached kernel, which is what variant 7 always runs.
     // 3..5: other geometries of the cached kernel, 6: its phase-timing build; 1: direct; 2: per-tile LDS fold.
-    if ((variant >= 8 && variant <= 11) || (variant == 0 && n >= kPartMinBatch))   // 10: two-pass whatever the size; 11: same without the admission filter
+    if (takes_two_pass(variant, n))   // 10: two-pass whatever the size; 11: same without the admission filter
         return launch_ingest_part(t, sk, t.spill, d_records, n, seq_base, variant, s);
     if (variant == 2) return launch_ingest_lds(t, d_records, n, seq_base, variant, s);
-    if (variant != 1) return launch_ingest_cached(t, sk, d_records, n, seq_base, variant, s);
+    if (!takes_direct(variant, n, sk.flags)) return launch_ingest_cached(t, sk, d_records, n, seq_base, variant, s);
     (void)hipGetLastError(); hipLaunchKernelGGL(k_ingest_direct, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, t, d_records, n, seq_base);
     return hipGetLastError();
 }
