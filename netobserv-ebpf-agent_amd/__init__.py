@@ -17,5 +17,5 @@ from .accounter import (Accounter, NewAccounter, NewRecord, Record, IntfDirUdn, 
                         SetInterfaceNamer, SetGlobalIP)
 from . import synth
 from . import pipeline
-from .pipeline import CapacityLimiter, RecordToMap, DirectFLPStdout
+from .pipeline import (CapacityLimiter, RecordToMap, DirectFLPStdout, BpfFlowContent, GPUMapFetcher, MapTracer, NewMapTracer)
 from . import distributed

@@ -105,3 +105,84 @@ class DirectFLPStdout:
                 return
             for rec in batch:
                 self.stream.write(json.dumps(RecordToMap(rec, self.time_received), sort_keys=True, separators=(",", ":")) + "\n")
+
+
+# ---------------------------------------------------------------------------------------------
+# The kernel-map branch: MapTracer (pkg/flow/tracer_map.go:22-146) over a fetcher whose
+# LookupAndDeleteMap runs on the GPU (nfagg_map_merge). The eBPF syscalls that drain the maps stay
+# with the caller (`drain`); the join, the per-CPU folds and buildBaseFromAdditional are libnfagg's.
+from dataclasses import dataclass  # noqa: E402
+from typing import Callable, Optional  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+from . import _lib as _L  # noqa: E402
+from .accounter import NewRecord  # noqa: E402
+
+
+@dataclass
+class BpfFlowContent:                                     # pkg/model/flow_content.go:9-17 (nil = None)
+    BpfFlowMetrics: np.void
+    DNSMetrics: Optional[np.void] = None
+    PktDropMetrics: Optional[np.void] = None
+    NetworkEventsMetrics: Optional[np.void] = None
+    XlatMetrics: Optional[np.void] = None
+    AdditionalMetrics: Optional[np.void] = None
+    QuicMetrics: Optional[np.void] = None
+
+
+class GPUMapFetcher:
+    """mapFetcher (tracer_map.go:37-40) whose LookupAndDeleteMap (pkg/tracer/tracer.go:1022-1116) is one
+    nfagg_map_merge call. drain() -> (main_ids, main_vals, {kind: (ids, partials[n, n_cpu])}, n_cpu)."""
+
+    _PARTS = (("dns", "DNSMetrics", _L.FEAT_DNS), ("drops", "PktDropMetrics", _L.FEAT_DROPS),
+              ("network_events", "NetworkEventsMetrics", _L.FEAT_NETWORK_EVENTS), ("xlat", "XlatMetrics", _L.FEAT_XLAT),
+              ("additional", "AdditionalMetrics", _L.FEAT_ADDITIONAL), ("quic", "QuicMetrics", _L.FEAT_QUIC))
+
+    def __init__(self, table, drain: Callable):
+        self.table, self.drain = table, drain
+
+    def LookupAndDeleteMap(self, metrics=None):
+        main_ids, main_vals, feats, n_cpu = self.drain()
+        recs, present, parts, _dups = self.table.map_merge(main_ids, main_vals, feats, n_cpu)
+        flows = []
+        for i in range(len(recs)):
+            c = BpfFlowContent(BpfFlowMetrics=recs[i]["metrics"])
+            for kind, attr, bit in self._PARTS:
+                if present[i] & bit:
+                    setattr(c, attr, parts[kind][i])
+            flows.append((recs[i]["id"], c))
+        if metrics is not None:
+            metrics.buffer_size["merged-maps"] = len(flows)            # tracer.go:1112
+        return flows
+
+    def DeleteMapsStaleEntries(self, timeout):                          # kernel-side housekeeping: stays in Go
+        pass
+
+
+class MapTracer:
+    """tracer_map.go:22-60. TraceLoop's ticker / condition variable (:62-101) is goroutine plumbing: callers
+    invoke evictFlows directly (what Flush() ends up doing)."""
+
+    def __init__(self, fetcher, eviction_timeout, stale_entries_evict_timeout, metrics=None, s=None, udn_enabled=False,
+                 clock=None, mono_clock=None):
+        self.mapFetcher, self.evictionTimeout, self.staleEntriesEvictTimeout = fetcher, eviction_timeout, stale_entries_evict_timeout
+        self.metrics, self.s, self.udnEnabled = metrics, s, udn_enabled
+        self.clock = clock or (lambda: time.time_ns())
+        self.monoClock = mono_clock or (lambda: time.monotonic_ns())
+
+    def evictFlows(self, forwardFlows: "queue.Queue"):                  # :103-146
+        monotonic_now, current = self.monoClock(), self.clock()
+        flows = self.mapFetcher.LookupAndDeleteMap(self.metrics)
+        udn_cache = dict(self.s.GetInterfaceUDNs()) if (self.s is not None and self.udnEnabled) else {}
+        forwarding = [NewRecord(k, c.BpfFlowMetrics, current, monotonic_now, udn_cache,
+                                dns_metrics=c.DNSMetrics, additional_metrics=c.AdditionalMetrics) for k, c in flows]
+        self.mapFetcher.DeleteMapsStaleEntries(self.staleEntriesEvictTimeout)
+        forwardFlows.put(forwarding)
+        if self.metrics is not None:
+            self.metrics.eviction("hashmap", "", len(forwarding))       # EvictionCounter / EvictedFlowsCounter WithSource("hashmap")
+        return len(forwarding)
+
+
+def NewMapTracer(fetcher, evictionTimeout, staleEntriesEvictTimeout, m=None, s=None, udnEnabled=False, **kw) -> MapTracer:
+    return MapTracer(fetcher, evictionTimeout, staleEntriesEvictTimeout, m, s, udnEnabled, **kw)

@@ -41,8 +41,9 @@ def test_capacity_limiter_no_drop_and_drop(nf):
         t.start()
         for i in range(sent):
             inp.put([nf.Record(ID=None, Metrics=None, TimeFlowStart=0, TimeFlowEnd=0, Interfaces=[nf.NewIntfDirUdn(str(i), 0, None)])])
+        import time as _t
         while inp.qsize():
-            pass
+            _t.sleep(0.001)
         got = [out.get(timeout=5) for _ in range(expect)]
         assert [g[0].Interfaces[0].Interface for g in got] == [str(i) for i in range(expect)]
         assert out.empty() and lim.droppedFlows == sent - expect
@@ -145,3 +146,66 @@ def _forward_close(q_mid, q_out, limiter):
     from netobserv_ebpf_agent_amd import CLOSE
     inner.put(CLOSE)
     t.join(timeout=30)
+
+
+# ------------------------------------------------------------------ the kernel-map branch
+def _decoration_fixture(nf, now):
+    """pkg/agent/agent_test.go:140-166: key1/key2 and their metrics."""
+    ids = np.zeros(2, dtype=nf.FLOW_ID); m = np.zeros(2, dtype=nf.FLOW_METRICS)
+    ids["src_port"], ids["dst_port"] = [123, 333], [456, 532]
+    m["packets"], m["bytes"] = [3, 7], [44, 33]
+    m["start_mono_time_ts"], m["end_mono_time_ts"] = [now + 1000, now], [now + 1_000_000_000, now + 2_000_000_000]
+    m["if_index_first_seen"], m["direction_first_seen"], m["nb_observed_intf"] = [1, 4], [1, 0], [1, 2]
+    m["observed_intf"][0][:1] = [3]; m["observed_direction"][0][:1] = [0]
+    m["observed_intf"][1][:2] = [1, 99]; m["observed_direction"][1][:2] = [1, 1]
+    return ids, m
+
+
+AGENT_NAMER = lambda ifx, mac: {1: "eth0", 3: "foo", 4: "bar"}.get(ifx, "unknown")   # agent_test.go:200-204 + interfaces_listener.go:77
+
+
+def _check_decoration(nf, exported):
+    """agent_test.go:168-189."""
+    assert len(exported) == 2
+    for f in exported:
+        assert str(f.AgentIP) == "192.168.1.13"
+        names = [i.Interface for i in f.Interfaces]
+        if int(f.ID["src_port"]) == 123:
+            assert names == ["eth0", "foo"]
+        elif int(f.ID["src_port"]) == 333:
+            assert names == ["bar", "eth0", "unknown"]
+        else:
+            raise AssertionError("unexpected key")
+
+
+def test_flows_agent_decoration_new_record(nf):
+    """TestFlowsAgent_Decoration through the NewRecord mirror alone (no GPU)."""
+    nf.SetInterfaceNamer(AGENT_NAMER); nf.SetGlobalIP(ipaddress.ip_address("192.168.1.13"))
+    ids, m = _decoration_fixture(nf, 10**12)
+    _check_decoration(nf, [nf.NewRecord(ids[i], m[i], NOW, 10**12) for i in range(2)])
+
+
+@pytest.mark.gpu
+def test_map_tracer_evict_flows_decoration(nf, O):
+    """The same reference test through MapTracer.evictFlows with LookupAndDeleteMap on the GPU; key2 also carries per-CPU
+    DNS and RTT partials, so DNSLatency / TimeFlowRtt (record.go:116-125) are checked against the oracle's fold."""
+    P = _mods(nf)
+    nf.SetInterfaceNamer(AGENT_NAMER); nf.SetGlobalIP(ipaddress.ip_address("192.168.1.13"))
+    now = 10**12
+    ids, m = _decoration_fixture(nf, now)
+    n_cpu = 4
+    dns = np.zeros((1, n_cpu), dtype=nf.DNS); add = np.zeros((1, n_cpu), dtype=nf.ADDITIONAL)
+    dns["latency"][0] = [0, 5_000, 70_000, 0]; dns["id"][0] = [0, 77, 0, 0]
+    add["flow_rtt"][0] = [10, 0, 999, 12]
+    feats = {"dns": (ids[1:2], dns), "additional": (ids[1:2], add)}
+    with nf.FlowTable(max_entries=64) as tab:
+        tracer = P.NewMapTracer(P.GPUMapFetcher(tab, lambda: (ids, m, feats, n_cpu)), 5.0, 5.0, nf.NoOp(), clock=lambda: NOW, mono_clock=lambda: now)
+        out = queue.Queue()
+        assert tracer.evictFlows(out) == 2
+    exported = out.get_nowait()
+    _check_decoration(nf, exported)
+    k2 = [f for f in exported if int(f.ID["src_port"]) == 333][0]
+    assert (k2.DNSLatency, k2.TimeFlowRtt) == (70_000, 999) and int(k2.DNSMetrics["id"]) == 77
+    k1 = [f for f in exported if int(f.ID["src_port"]) == 123][0]
+    assert (k1.DNSLatency, k1.TimeFlowRtt, k1.DNSMetrics) == (0, 0, None)
+    assert tracer.metrics.evicted_flows_total == {("hashmap", ""): 2}
