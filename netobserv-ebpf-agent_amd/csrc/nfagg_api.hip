@@ -644,7 +644,7 @@ static int map_merge_device_core(nfagg_handle* h, const nfagg_map_view* mm, cons
         total += v.n;
         if (v.n) align |= (uintptr_t)v.ids | (uintptr_t)v.values;
     }
-    if (total >= 0x7FFFFFFFull) return fail(h, NFAGG_ERANGE, "map merge: more than 2^31 rows");
+    if (total > (1ull << 30)) return fail(h, NFAGG_ERANGE, "map merge: more than 2^30 rows");
     in.off[7] = (uint32_t)total;
     *n_out = 0;
     if (n_dup) *n_dup = 0;
