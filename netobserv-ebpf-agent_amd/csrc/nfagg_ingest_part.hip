@@ -62,7 +62,7 @@ struct Stage {
 constexpr int kDoorBits = 32768;
 struct Door { uint32_t bits[kDoorBits / 32]; };
 
-NF_DEV uint32_t part_of(uint64_t h) { return (uint32_t)(h >> 29) & (kSpillParts - 1); }
+NF_DEV uint32_t part_of(uint64_t h, uint32_t shift) { return (uint32_t)(h >> shift) & (kSpillParts - 1); }
 
 NF_DEV void cache_init(Cache& L, int tid) {
     for (int e = tid; e < kEntries; e += kBlock) {
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
                 carry = 0xffffffffu;
             }
             if (valid && ent < 0) {
-                const uint32_t p = part_of(h);
+                const uint32_t p = part_of(h, q.part_shift);
                 const uint32_t at = atomicAdd(&S.cnt[p], 1u);
                 spilled++;
                 if (at < (uint32_t)kStage) S.buf[p][at] = (uint32_t)i;

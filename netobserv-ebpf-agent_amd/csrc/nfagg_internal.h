@@ -103,6 +103,7 @@ struct SpillView {
     uint32_t* ovf_tail;
     uint32_t ovf_cap;
     unsigned int* error;           // = &DevCounters.error
+    uint32_t part_shift;           // partition of a key = (hash >> part_shift) & (kSpillParts - 1); see nfagg_create
 };
 
 struct TableView {
