@@ -55,6 +55,33 @@ def test_device_ingest_parity_2m_records(nf, O, torch, ingest_variant):
     assert_records_equal(nf.sort_by_key(got), want)
 
 
+@pytest.mark.parametrize("hot_permille,sketches", [(0, False), (300, True)])
+def test_default_routing_exact_parity_8m_records(nf, O, torch, hot_permille, sketches):
+    """One 8 M-record call: the default routing takes the two-pass fold (>= 3 Mi records) with its admission filter
+    and slot-index partitions; exact against the oracle, every order-dependent field scrambled; then a second epoch
+    of mid-size calls (single-pass kernel) on the same handle, and the sketches of both epochs."""
+    n, keys = 8_000_000, 300_000
+    th = nf.synth.zipf_thresholds(keys, 1.1)
+    d = dev_stream(torch, nf.synth, n, seed=11, n_keys=keys, thresholds=th, variant=1, hot_permille=hot_permille)
+    host = O.gen_stream(n, seed=11, n_keys=keys, thresholds=th, variant=1, hot_permille=hot_permille)
+    want = O.run_accounter(host, 1 << 24)[0][1]
+    sk = (nf.SKETCH_CM | nf.SKETCH_HLL) if sketches else 0
+    with nf.FlowTable(max_entries=1 << 24, sketches=sk, cm_log2_width=16, hll_p=12) as tab:
+        out = torch.empty(len(want) * 144 + 16, dtype=torch.uint8, device="cuda")
+        for chunk in (n, 1_000_000):
+            for off in range(0, n, chunk):
+                m = min(chunk, n - off)
+                assert tab.ingest_device(d.data_ptr() + off * 144, m) == (nf.OK, m)
+            assert tab.evict_device(out.data_ptr(), len(want)) == len(want)
+            got = out[: len(want) * 144].cpu().numpy().view(nf.FLOW_RECORD)
+            assert_records_equal(nf.sort_by_key(got), want, f"chunk {chunk}")
+        assert tab.stats().records_bypassed > 0            # the cold tail did go through the partition queues
+        if sketches:
+            cm_s, cm_d, hs, hd = O.sketches(host, 4, 16, 12)
+            assert np.array_equal(tab.sketch_snapshot(nf.CM_SRC), 2 * cm_s) and np.array_equal(tab.sketch_snapshot(nf.CM_DST), 2 * cm_d)
+            assert np.array_equal(tab.sketch_snapshot(nf.HLL_SRC), hs) and np.array_equal(tab.sketch_snapshot(nf.HLL_DST), hd)
+
+
 def _i64(torch, buf, n):
     return buf.view(torch.int64).view(n, 18)
 
