@@ -89,20 +89,36 @@ RD void fold(nfagg_quic_metrics& p, const nfagg_quic_metrics& o) {
     if (p.seen_short_hdr < o.seen_short_hdr) p.seen_short_hdr = o.seen_short_hdr;
 }
 
+// CPU 0 adopted whole, CPUs 1.. folded in order (tracer.go:1057-1110 closures), buildBaseFromAdditional after every
+// partial. The partials of one flow are read four at a time: the loads of a group are independent and in flight together,
+// only the folds are sequential (a lane-strided stream is latency-bound, not bandwidth-bound).
+template <typename M>
+RD void fold_partials(const M* __restrict__ p, uint32_t n_cpu, nfagg_flow_metrics& b, M& acc) {
+    acc = p[0];
+    base_from(b, acc.start_mono_time_ts, acc.end_mono_time_ts, acc.eth_protocol);
+    uint32_t c = 1;
+    for (; c + 4 <= n_cpu; c += 4) {
+        const M o0 = p[c], o1 = p[c + 1], o2 = p[c + 2], o3 = p[c + 3];
+        base_from(b, o0.start_mono_time_ts, o0.end_mono_time_ts, o0.eth_protocol); fold(acc, o0);
+        base_from(b, o1.start_mono_time_ts, o1.end_mono_time_ts, o1.eth_protocol); fold(acc, o1);
+        base_from(b, o2.start_mono_time_ts, o2.end_mono_time_ts, o2.eth_protocol); fold(acc, o2);
+        base_from(b, o3.start_mono_time_ts, o3.end_mono_time_ts, o3.eth_protocol); fold(acc, o3);
+    }
+    for (; c < n_cpu; c++) {
+        const M o = p[c];
+        base_from(b, o.start_mono_time_ts, o.end_mono_time_ts, o.eth_protocol);
+        fold(acc, o);
+    }
+}
+
 template <typename M>
 __global__ __launch_bounds__(256) void k_rollup(const M* __restrict__ partials, uint64_t n_flows, uint64_t n_cpu,
                                                 nfagg_flow_metrics* __restrict__ base, M* __restrict__ folded) {
     const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_flows) return;
     nfagg_flow_metrics b = base[f];
-    const M* p = partials + f * n_cpu;
-    M acc = p[0];                                         // adopted whole (tracer.go / flow_content.go "== nil" arm)
-    base_from(b, acc.start_mono_time_ts, acc.end_mono_time_ts, acc.eth_protocol);
-    for (uint64_t c = 1; c < n_cpu; c++) {
-        const M o = p[c];
-        base_from(b, o.start_mono_time_ts, o.end_mono_time_ts, o.eth_protocol);
-        fold(acc, o);
-    }
+    M acc;
+    fold_partials(partials + f * n_cpu, (uint32_t)n_cpu, b, acc);
     base[f] = b;
     folded[f] = acc;
 }
@@ -194,14 +210,7 @@ RD bool merge_part(const MergeIn& in, int q, uint32_t row, nfagg_flow_metrics& b
     M acc;
     const bool have = row != 0xFFFFFFFFu;
     if (have) {
-        const M* p = reinterpret_cast<const M*>(in.vals[q]) + (size_t)row * in.n_cpu;
-        acc = p[0];                                       // CPU 0 adopted whole
-        base_from(b, acc.start_mono_time_ts, acc.end_mono_time_ts, acc.eth_protocol);
-        for (uint32_t c = 1; c < in.n_cpu; c++) {
-            const M o = p[c];
-            base_from(b, o.start_mono_time_ts, o.end_mono_time_ts, o.eth_protocol);
-            fold(acc, o);
-        }
+        fold_partials(reinterpret_cast<const M*>(in.vals[q]) + (size_t)row * in.n_cpu, in.n_cpu, b, acc);
     } else {
         memset(&acc, 0, sizeof acc);
     }
