@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <new>
 #include <string>
 #include <thread>
@@ -73,6 +74,7 @@ struct nfagg_handle {
     size_t d_sort_cap[2] = {};
     int sort_bits = 0;
     bool epoch_unclustered = false; // a batch of this epoch claimed slots in arrival order (single-pass / direct / dedup kernels)
+    std::vector<nfagg_intf_name> pb_names;   // host copy of the namer table, sorted (kept until the stream has consumed it)
     void* d_pb[15] = {};
     size_t d_pb_cap[15] = {};
     // spill queues of the two-pass ingest
@@ -933,12 +935,16 @@ static int encode_pb_device_core(nfagg_handle* h, const void* d_records, size_t 
     if ((rc = ensure_bytes(h, &h->d_pb[1], &h->d_pb_cap[1], blocks * sizeof(uint32_t))) != NFAGG_OK) return rc;
     if ((rc = ensure_bytes(h, &h->d_pb[2], &h->d_pb_cap[2], (blocks + 1) * sizeof(uint64_t))) != NFAGG_OK) return rc;
     if ((rc = ensure_bytes(h, &h->d_pb[3], &h->d_pb_cap[3], (size_t)(opt->n_names + 1) * sizeof(nfagg_intf_name))) != NFAGG_OK) return rc;
-    if (opt->n_names) HIP_TRY(h, hipMemcpyAsync(h->d_pb[3], opt->names, opt->n_names * sizeof(nfagg_intf_name), hipMemcpyHostToDevice, h->stream));
+    if (opt->n_names) {   // the kernels binary-search the table: stable sort by if_index keeps the scan-in-table-order answer
+        h->pb_names.assign(opt->names, opt->names + opt->n_names);
+        std::stable_sort(h->pb_names.begin(), h->pb_names.end(), [](const nfagg_intf_name& a, const nfagg_intf_name& b) { return a.if_index < b.if_index; });
+        HIP_TRY(h, hipMemcpyAsync(h->d_pb[3], h->pb_names.data(), opt->n_names * sizeof(nfagg_intf_name), hipMemcpyHostToDevice, h->stream));
+    }
     PbParams P{};
     P.now_sec = opt->now_unix_ns / 1000000000ll; P.now_nsec = opt->now_unix_ns % 1000000000ll;
     if (P.now_nsec < 0) { P.now_nsec += 1000000000ll; P.now_sec -= 1; }
     P.mono_now = opt->mono_now_ns;
-    memcpy(P.agent_ip, opt->agent_ip, 16);
+    memcpy(P.agent_ip_w, opt->agent_ip, 16);
     static const uint8_t v4pre[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0xff, 0xff};
     P.agent_is_v4 = memcmp(opt->agent_ip, v4pre, 12) == 0;     // net.IP.To4() != nil (proto.go:255-261)
     P.names = (const nfagg_intf_name*)h->d_pb[3]; P.n_names = opt->n_names;
@@ -950,7 +956,7 @@ static int encode_pb_device_core(nfagg_handle* h, const void* d_records, size_t 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     *out_bytes = (size_t)total;
     if (total > out_cap || !d_out) return NFAGG_TRUNCATED;
-    e = launch_pb_write(d_records, n, P, F, d_body_len, (const uint32_t*)h->d_pb[0], (const uint64_t*)h->d_pb[2], d_out, d_frame_offsets, d_kafka_keys, h->stream);
+    e = launch_pb_write(d_records, n, P, F, d_body_len, (const uint32_t*)h->d_pb[0], (const uint64_t*)h->d_pb[2], d_out, d_frame_offsets, d_kafka_keys, total, h->stream);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "protobuf encode launch failed: %s", hipGetErrorString(e));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NFAGG_OK;

@@ -9,9 +9,9 @@ namespace nfagg {
 struct PbParams {
     int64_t now_sec, now_nsec;    // currentTime, normalised (0 <= nsec < 1e9)
     uint64_t mono_now;
-    uint8_t agent_ip[16];
+    uint32_t agent_ip_w[4];       // Record.AgentIP as a 16-byte net.IP, four little-endian dwords
     uint32_t agent_is_v4;         // net.IP.To4() != nil
-    const nfagg_intf_name* names; // device copy of the namer table
+    const nfagg_intf_name* names; // device copy of the namer table, stably sorted by if_index
     uint32_t n_names;
     uint32_t unknown_len;
     char unknown[16];
@@ -32,6 +32,6 @@ struct PbFeat {
 hipError_t launch_pb_size(const void* d_recs, uint64_t n, const PbParams& P, const PbFeat& F, uint32_t* d_body_len, uint32_t* d_local_off,
                           uint32_t* d_block_sum, uint64_t* d_block_base, hipStream_t s);
 hipError_t launch_pb_write(const void* d_recs, uint64_t n, const PbParams& P, const PbFeat& F, const uint32_t* d_body_len, const uint32_t* d_local_off,
-                           const uint64_t* d_block_base, void* d_out, uint64_t* d_frame_offsets, void* d_kafka_keys, hipStream_t s);
+                           const uint64_t* d_block_base, void* d_out, uint64_t* d_frame_offsets, void* d_kafka_keys, uint64_t total_bytes, hipStream_t s);
 
 }  // namespace nfagg

@@ -54,14 +54,19 @@ template <typename S> NF_DEV void put_uint(S& s, uint32_t field, uint64_t v) { i
 NF_DEV uint32_t uint_len(uint32_t field, uint64_t v) { return v ? varint_len((uint64_t)field << 3) + varint_len(v) : 0; }
 
 // message IP { oneof { fixed32 ipv4 = 1; bytes ipv6 = 2; } } as a sub-message of `field`
-template <typename S> NF_DEV void put_ip(S& s, uint32_t field, const uint8_t ip[16], bool v6) {
+// The address travels as four little-endian dwords in registers, never as a byte pointer: a byte loop over global
+// memory is one exposed load latency per byte.
+struct Ip4w { uint32_t w[4]; };
+NF_DEV uint8_t ip_byte(const Ip4w& a, int k) { return (uint8_t)(a.w[k >> 2] >> (8 * (k & 3))); }
+template <typename S> NF_DEV void put_ip(S& s, uint32_t field, const Ip4w& ip, bool v6) {
     put_tag(s, field, 2);
     if (v6) {
         s.put(18); s.put(0x12); s.put(16);
-        for (int k = 0; k < 16; k++) s.put(ip[k]);
+#pragma unroll
+        for (int k = 0; k < 16; k++) s.put(ip_byte(ip, k));
     } else {   // model.IntEncodeV4 (record.go:202-204): big-endian value of the last four bytes; fixed32 is little-endian on the wire
         s.put(5); s.put(0x0D);
-        s.put(ip[15]); s.put(ip[14]); s.put(ip[13]); s.put(ip[12]);
+        s.put(ip_byte(ip, 15)); s.put(ip_byte(ip, 14)); s.put(ip_byte(ip, 13)); s.put(ip_byte(ip, 12));
     }
 }
 
@@ -82,33 +87,61 @@ template <typename S> NF_DEV void put_time(S& s, uint32_t field, const TimeParts
 }
 
 // interfaceNamer(ifIndex, mac) + udnsCache lookup, as a table: exact (index, MAC) row first,
-// then the row of that index that matches any MAC; no row -> the "unknown" name, no UDN.
-NF_DEV const nfagg_intf_name* lookup_name(const PbParams& P, uint32_t if_index, uint64_t mac48) {
-    const nfagg_intf_name* any = nullptr;
-    for (uint32_t k = 0; k < P.n_names; k++) {
-        const nfagg_intf_name* e = &P.names[k];
-        if (e->if_index != if_index) continue;
-        if (e->has_mac) {
-            uint64_t m = 0;
-            for (int b = 0; b < 6; b++) m = (m << 8) | e->mac[b];
+// then the first row of that index that matches any MAC; no row -> the "unknown" name, no UDN. The host hands the
+// table over STABLY SORTED by if_index (rows of one index keep their order, so the answer is that of a scan in table
+// order): binary search for the first row of the index, then only that index's rows. `tab` is a flat pointer: the
+// kernels stage the table in LDS when it fits (kNamesLdsRows rows), so a lookup costs LDS latencies, not HBM ones.
+// Row layout (nfagg_intf_name, 92 bytes): if_index@0 mac@4 has_mac@10 name_len@11 name@12 udn_len@28 udn@29.
+constexpr uint32_t kNameRowBytes = sizeof(nfagg_intf_name);
+constexpr uint32_t kNamesLdsRows = 96;
+static_assert(kNameRowBytes == 92 && kNameRowBytes % 4 == 0, "nfagg_intf_name layout");
+NF_DEV const uint8_t* lookup_name(const uint8_t* tab, uint32_t n_names, uint32_t if_index, uint64_t mac48) {
+    uint32_t lo = 0, hi = n_names;
+    while (lo < hi) {                                   // first row with if_index >= the one looked for
+        const uint32_t mid = (lo + hi) >> 1;
+        if (*reinterpret_cast<const uint32_t*>(tab + (size_t)mid * kNameRowBytes) < if_index) lo = mid + 1; else hi = mid;
+    }
+    const uint8_t* any = nullptr;
+    for (uint32_t k = lo; k < n_names; k++) {
+        const uint8_t* e = tab + (size_t)k * kNameRowBytes;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(e);
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        if (w0 != if_index) break;
+        if ((w2 >> 16) & 0xffu) {                       // has_mac: mac bytes 4..9, byte 4 most significant
+            const uint64_t m = ((uint64_t)__builtin_bswap32(w1) << 16) | (uint64_t)((w2 & 0xffu) << 8) | (uint64_t)((w2 >> 8) & 0xffu);
             if (m == mac48) return e;
         } else if (!any) any = e;
     }
     return any;
 }
 
+// Copy the namer table into LDS if it fits; returns the pointer the lookups use.
+template <int THREADS>
+NF_DEV const uint8_t* stage_names(const PbParams& P, uint32_t* lds_words) {
+    if (P.n_names > kNamesLdsRows) return reinterpret_cast<const uint8_t*>(P.names);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(P.names);
+    const uint32_t words = P.n_names * (kNameRowBytes / 4);
+    for (uint32_t k = threadIdx.x; k < words; k += THREADS) lds_words[k] = src[k];
+    __syncthreads();
+    return reinterpret_cast<const uint8_t*>(lds_words);
+}
+
 // message DupMapEntry { string interface = 1; Direction direction = 2; string udn = 3; } as Record.dup_list (26)
-template <typename S> NF_DEV void put_dup(S& s, const PbParams& P, uint32_t if_index, uint64_t mac48, uint32_t dir) {
-    const nfagg_intf_name* e = lookup_name(P, if_index, mac48);
-    const char* name = e ? e->name : P.unknown;
-    const uint32_t nlen = e ? e->name_len : P.unknown_len;
-    const uint32_t ulen = e ? e->udn_len : 0;
+template <typename S> NF_DEV void put_dup(S& s, const PbParams& P, const uint8_t* tab, uint32_t if_index, uint64_t mac48, uint32_t dir) {
+    const uint8_t* e = lookup_name(tab, P.n_names, if_index, mac48);
+    const uint32_t lens = e ? *reinterpret_cast<const uint32_t*>(e + 8) : 0u;      // bytes 8..11: mac[4..5], has_mac, name_len
+    const uint32_t nlen = e ? lens >> 24 : P.unknown_len;
+    const uint32_t ulen = e ? e[28] : 0u;
     const uint32_t body = (nlen ? 2 + nlen : 0) + uint_len(2, dir) + (ulen ? 2 + ulen : 0);
     put_tag(s, 26, 2);
     s.put((uint8_t)body);                  // < 128 by the table's field widths
-    if (nlen) { s.put(0x0A); s.put((uint8_t)nlen); for (uint32_t k = 0; k < nlen; k++) s.put((uint8_t)name[k]); }
+    if (nlen) {
+        s.put(0x0A); s.put((uint8_t)nlen);
+        if (e) { for (uint32_t k = 0; k < nlen; k++) s.put(e[12 + k]); }
+        else { for (uint32_t k = 0; k < nlen; k++) s.put((uint8_t)P.unknown[k]); }
+    }
     put_uint(s, 2, dir);
-    if (ulen) { s.put(0x1A); s.put((uint8_t)ulen); for (uint32_t k = 0; k < ulen; k++) s.put((uint8_t)e->udn[k]); }
+    if (ulen) { s.put(0x1A); s.put((uint8_t)ulen); for (uint32_t k = 0; k < ulen; k++) s.put(e[29 + k]); }
 }
 
 NF_DEV uint64_t mac_be(uint64_t mac_le48) {   // Rec::smac() holds byte 0 in the low bits; macToUint64 (proto.go:246-253) wants it on top
@@ -128,7 +161,7 @@ template <typename S> NF_DEV void put_duration(S& s, uint32_t field, uint64_t d_
     put_uint(s, 2, nanos);
 }
 
-// utils.DNSRawNameToDotted (pkg/utils/utils.go:18-58) over the 32-byte kernel copy at `raw` (global memory):
+// utils.DNSRawNameToDotted (pkg/utils/utils.go:18-58) over the 32-byte kernel copy at `raw` (the lane's LDS slot):
 // bytes up to the first NUL, label by label; stops at a zero length, a compression pointer, or a label that
 // runs past the end. EMIT = false only measures.
 template <bool EMIT, typename S> NF_DEV uint32_t dns_dotted(S& s, const uint8_t* __restrict__ raw) {
@@ -147,18 +180,34 @@ template <bool EMIT, typename S> NF_DEV uint32_t dns_dotted(S& s, const uint8_t*
     return out;
 }
 
-NF_DEV uint32_t ld32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
-NF_DEV uint64_t ld64(const uint8_t* p) { return *reinterpret_cast<const uint64_t*>(p); }
+template <int N> NF_DEV void load_dwords16(const uint8_t* p, uint32_t (&w)[N]) {   // N/4 16-byte loads
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int k = 0; k < N / 4; k++) { const uint4 v = q[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+}
+template <int N> NF_DEV void load_dwords8(const uint8_t* p, uint32_t (&w)[N]) {    // N/2 8-byte loads
+    const uint2* q = reinterpret_cast<const uint2*>(p);
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) { const uint2 v = q[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+}
 
-// The body of pbflow.Record for one flow: evicted record `r`, plus the feature parts of flow `i` when
-// F carries them. Same code sizes (CountSink) and writes (WindowSink).
-template <typename S> NF_DEV void encode_record(S& s, const Rec& r, const PbParams& P, const PbFeat& F, uint64_t i) {
+// The body of pbflow.Record for one flow: evicted record `r`, plus the feature parts of flow `i` when F carries
+// them — each part is read whole with vector loads before anything is emitted. `name_lds`: 32 bytes of LDS owned by
+// this lane (the DNS name is walked byte by byte). Same code sizes (CountSink) and writes (WindowSink).
+template <typename S> NF_DEV void encode_record(S& s, const Rec& r, const PbParams& P, const PbFeat& F, uint64_t i, uint8_t* name_lds, const uint8_t* tab) {
     const uint32_t have = F.present ? F.present[i] : 0u;
-    const uint8_t* add = (F.additional && (have & 1u)) ? F.additional + i * 32 : nullptr;
-    const uint8_t* dns = (F.dns && (have & 2u)) ? F.dns + i * 64 : nullptr;
-    const uint8_t* drp = (F.drops && (have & 4u)) ? F.drops + i * 32 : nullptr;
-    const uint8_t* xlt = (F.xlat && (have & 16u)) ? F.xlat + i * 56 : nullptr;
-    const uint8_t* quc = (F.quic && (have & 32u)) ? F.quic + i * 24 : nullptr;
+    const bool add = F.additional && (have & 1u), dns = F.dns && (have & 2u), drp = F.drops && (have & 4u);
+    const bool xlt = F.xlat && (have & 16u), quc = F.quic && (have & 32u);
+    uint32_t addw[8] = {}, dnsw[16] = {}, drpw[8] = {}, xltw[14] = {}, qucw[6] = {};
+    if (add) load_dwords16(F.additional + i * 32, addw);     // start@0 end@8 flow_rtt@16 ipsec_ret@24 eth@28 ipsec_encrypted@30
+    if (dns) load_dwords16(F.dns + i * 64, dnsw);            // latency@16 id@24 flags@26 eth@28 errno@30 name@31..62
+    if (drp) load_dwords16(F.drops + i * 32, drpw);          // bytes@16 packets@18 cause@20 flags@24 eth@26 state@28
+    if (xlt) load_dwords8(F.xlat + i * 56, xltw);            // saddr@16 daddr@32 sport@48 dport@50 zone@52
+    if (quc) load_dwords8(F.quic + i * 24, qucw);            // version@16 eth@20 long@22 short@23
+    if (dns) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) name_lds[k] = (uint8_t)(dnsw[(31 + k) >> 2] >> (8 * ((31 + k) & 3)));
+    }
     const uint32_t eth = r.eth();
     const uint32_t dirn = r.d[24] & 0xffu;
     put_uint(s, 1, eth);
@@ -170,9 +219,7 @@ template <typename S> NF_DEV void encode_record(S& s, const Rec& r, const PbPara
     put_uint(s, 1, smac); put_uint(s, 2, dmac);
     {   // Network: addresses by eth_protocol (proto.go:125-139), dscp
         const bool v6 = eth == 0x86DDu;    // model.IPv6Type
-        uint8_t sip[16], dip[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) { sip[k] = (uint8_t)(r.d[k / 4] >> (8 * (k & 3))); dip[k] = (uint8_t)(r.d[4 + k / 4] >> (8 * (k & 3))); }
+        const Ip4w sip{{r.d[0], r.d[1], r.d[2], r.d[3]}}, dip{{r.d[4], r.d[5], r.d[6], r.d[7]}};
         const uint32_t ipl = v6 ? 20 : 7;   // tag + len + body of one IP sub-message
         put_tag(s, 6, 2); s.put((uint8_t)(2 * ipl + uint_len(3, r.dscp())));
         put_ip(s, 1, sip, v6); put_ip(s, 2, dip, v6);
@@ -185,54 +232,54 @@ template <typename S> NF_DEV void encode_record(S& s, const Rec& r, const PbPara
     }
     put_uint(s, 8, r.bytes());
     put_uint(s, 9, r.packets());
-    put_ip(s, 12, P.agent_ip, !P.agent_is_v4);
+    put_ip(s, 12, Ip4w{{P.agent_ip_w[0], P.agent_ip_w[1], P.agent_ip_w[2], P.agent_ip_w[3]}}, !P.agent_is_v4);
     put_uint(s, 13, r.flags());
     put_uint(s, 14, (r.d[9] >> 8) & 0xffu);      // icmp_type
     put_uint(s, 15, (r.d[9] >> 16) & 0xffu);     // icmp_code
     if (drp) {                                   // proto.go:92-98
-        const uint32_t bp = ld32(drp + 16), fe = ld32(drp + 24);
+        const uint32_t bp = drpw[4], fe = drpw[6];
         put_uint(s, 16, bp & 0xffffu); put_uint(s, 17, bp >> 16);
-        put_uint(s, 18, fe & 0xffffu); put_uint(s, 19, drp[28]);
-        put_uint(s, 20, ld32(drp + 20));
+        put_uint(s, 18, fe & 0xffffu); put_uint(s, 19, drpw[7] & 0xffu);
+        put_uint(s, 20, drpw[5]);
     }
     if (dns) {                                   // proto.go:79-91, record.go:116-120
-        const uint32_t idf = ld32(dns + 24);
+        const uint32_t idf = dnsw[6];
         put_uint(s, 21, idf & 0xffffu); put_uint(s, 22, idf >> 16);
-        const uint64_t lat = ld64(dns + 16);
+        const uint64_t lat = (uint64_t)dnsw[4] | ((uint64_t)dnsw[5] << 32);
         if (lat) put_duration(s, 23, lat);
     }
-    put_duration(s, 24, add ? ld64(add + 16) : 0ull);   // time_flow_rtt = durationpb.New(fr.TimeFlowRtt): always present
-    if (dns) put_uint(s, 25, dns[30]);
+    put_duration(s, 24, add ? ((uint64_t)addw[4] | ((uint64_t)addw[5] << 32)) : 0ull);   // time_flow_rtt = durationpb.New(fr.TimeFlowRtt): always present
+    if (dns) put_uint(s, 25, (dnsw[7] >> 16) & 0xffu);
     {   // dup_list = record.Interfaces (record.go:100-114)
         const uint64_t lmac = mac_be(dirn == 0 ? r.dmac() : r.smac());
-        put_dup(s, P, r.d[21], lmac, dirn);
+        put_dup(s, P, tab, r.d[21], lmac, dirn);
         uint32_t nb = r.d[24] >> 24; if (nb > 6) nb = 6;
         for (uint32_t k = 0; k < nb; k++) {
             const uint32_t od = k < 4 ? (r.d[25] >> (8 * k)) & 0xffu : (r.d[26] >> (8 * (k - 4))) & 0xffu;
             uint32_t oi = r.d[27];
 #pragma unroll
             for (int q = 1; q < 6; q++) oi = ((uint32_t)q == k) ? r.d[27 + q] : oi;
-            put_dup(s, P, oi, lmac, od);
+            put_dup(s, P, tab, oi, lmac, od);
         }
     }
     if (xlt) {                                   // proto.go:99-105,129-138: address family by the FLOW's eth_protocol
         const bool v6 = eth == 0x86DDu;
-        const uint32_t sd = ld32(xlt + 48), ze = ld32(xlt + 52);
+        const uint32_t sd = xltw[12], ze = xltw[13];
         const uint32_t ipl = v6 ? 20 : 7;
         put_tag(s, 28, 2);
         s.put((uint8_t)(2 * ipl + uint_len(3, sd & 0xffffu) + uint_len(4, sd >> 16) + uint_len(5, ze & 0xffffu)));
-        put_ip(s, 1, xlt + 16, v6); put_ip(s, 2, xlt + 32, v6);
+        put_ip(s, 1, Ip4w{{xltw[4], xltw[5], xltw[6], xltw[7]}}, v6); put_ip(s, 2, Ip4w{{xltw[8], xltw[9], xltw[10], xltw[11]}}, v6);
         put_uint(s, 3, sd & 0xffffu); put_uint(s, 4, sd >> 16); put_uint(s, 5, ze & 0xffffu);
     }
     put_uint(s, 29, r.sampling());
     if (add) {                                   // proto.go:106-111
-        put_uint(s, 30, add[30] ? 1u : 0u);
-        put_uint(s, 31, (uint64_t)(int64_t)(int32_t)ld32(add + 24));
+        put_uint(s, 30, ((addw[7] >> 16) & 0xffu) ? 1u : 0u);
+        put_uint(s, 31, (uint64_t)(int64_t)(int32_t)addw[6]);
     }
     if (dns) {                                   // dns_name = 32
         CountSink c;
-        const uint32_t nl = dns_dotted<false>(c, dns + 31);
-        if (nl) { put_tag(s, 32, 2); s.put((uint8_t)nl); dns_dotted<true>(s, dns + 31); }
+        const uint32_t nl = dns_dotted<false>(c, name_lds);
+        if (nl) { put_tag(s, 32, 2); s.put((uint8_t)nl); dns_dotted<true>(s, name_lds); }
     }
     put_uint(s, 33, r.d[33] & 0xffffu);          // ssl_version
     put_uint(s, 34, (r.d[34] >> 24) & 1u);       // HasSSLMismatch (record.go:255-257)
@@ -240,10 +287,10 @@ template <typename S> NF_DEV void encode_record(S& s, const Rec& r, const PbPara
     put_uint(s, 36, r.d[33] >> 16);              // tls_cipher_suite
     put_uint(s, 37, r.d[34] & 0xffffu);          // tls_key_share
     if (quc) {                                   // proto.go:112-118
-        const uint32_t ver = ld32(quc + 16);
+        const uint32_t ver = qucw[4], lh = (qucw[5] >> 16) & 0xffu, sh = qucw[5] >> 24;
         put_tag(s, 38, 2);
-        s.put((uint8_t)(uint_len(1, ver) + uint_len(2, quc[22]) + uint_len(3, quc[23])));
-        put_uint(s, 1, ver); put_uint(s, 2, quc[22]); put_uint(s, 3, quc[23]);
+        s.put((uint8_t)(uint_len(1, ver) + uint_len(2, lh) + uint_len(3, sh)));
+        put_uint(s, 1, ver); put_uint(s, 2, lh); put_uint(s, 3, sh);
     }
 }
 
@@ -254,6 +301,9 @@ __global__ __launch_bounds__(kScanBlock) void k_pb_size(const void* __restrict__
                                                         uint32_t* __restrict__ body_len, uint32_t* __restrict__ local_off,
                                                         uint32_t* __restrict__ block_sum) {
     __shared__ uint32_t wave_tot[kScanBlock / 64];
+    __shared__ __align__(4) uint8_t name_lds[kScanBlock][32];
+    __shared__ uint32_t tab_lds[kNamesLdsRows * (kNameRowBytes / 4)];
+    const uint8_t* tab = stage_names<kScanBlock>(P, tab_lds);
     const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x;
     uint32_t frame = 0;
     if (i < n) {
@@ -261,7 +311,7 @@ __global__ __launch_bounds__(kScanBlock) void k_pb_size(const void* __restrict__
         load_record(recs, i, r);
         r.canonicalize();
         CountSink c;
-        encode_record(c, r, P, F, i);
+        encode_record(c, r, P, F, i, name_lds[threadIdx.x], tab);
         body_len[i] = c.n;
         frame = 1 + varint_len(c.n) + c.n;
     }
@@ -295,14 +345,20 @@ __global__ __launch_bounds__(1024) void k_pb_scan_blocks(const uint32_t* __restr
 }
 
 // ---- kernel 3: encode. One wave per 64 consecutive records, one kPbWindow-byte window of its output at a time.
-constexpr uint32_t kPbWindow = 16384;   // LDS per wave: ten waves per CU; 64 typical frames (~110 B) fit one window
-constexpr uint32_t kPbMaxFrame = 1040;  // upper bound of one frame: 64 of them span at most five windows
+// The window (LDS per wave, beside 2 KiB of DNS-name slots and the 8.6 KiB namer table) is chosen by the host from the
+// average frame length the size pass found: the whole encoder runs once per window a wave's 64 frames span, so the
+// window should hold them all (64 x ~110 B for Accounter records, 64 x ~270 B with every feature part).
+// (a frame is at most 1033 bytes, DESIGN.md §4.7: any window of at least that size makes progress)
 
+template <uint32_t kPbWindow>
 __global__ __launch_bounds__(64) void k_pb_write(const void* __restrict__ recs, uint64_t n, PbParams P, PbFeat F,
                                                  const uint32_t* __restrict__ body_len, const uint32_t* __restrict__ local_off,
                                                  const uint64_t* __restrict__ block_base, uint8_t* __restrict__ out,
                                                  uint64_t* __restrict__ frame_offsets, uint8_t* __restrict__ kafka_keys) {
     __shared__ __align__(16) unsigned char lds[kPbWindow];
+    __shared__ __align__(4) uint8_t name_lds[64][32];
+    __shared__ uint32_t tab_lds[kNamesLdsRows * (kNameRowBytes / 4)];
+    const uint8_t* tab = stage_names<64>(P, tab_lds);
     const uint64_t i0 = (uint64_t)blockIdx.x * 64, i = i0 + threadIdx.x;
     const uint64_t wave_base = block_base[i0 / kScanBlock] + local_off[i0];
     const uint32_t shift = (uint32_t)(wave_base & 15);       // the LDS image has the alignment of the destination
@@ -341,7 +397,7 @@ __global__ __launch_bounds__(64) void k_pb_write(const void* __restrict__ recs, 
             WindowSink s{lds, p0, lo, hi - lo};
             s.put(0x0A);                                          // Records.entries = 1, length-delimited
             put_varint(s, bl);
-            encode_record(s, r, P, F, i);
+            encode_record(s, r, P, F, i, name_lds[threadIdx.x], tab);
         }
         __syncthreads();
         for (uint32_t c = lo + threadIdx.x * 16; c < hi; c += 64 * 16) {
@@ -373,11 +429,16 @@ hipError_t launch_scan_block_sums(const uint32_t* d_block_sum, uint32_t n_blocks
 }
 
 hipError_t launch_pb_write(const void* d_recs, uint64_t n, const PbParams& P, const PbFeat& F, const uint32_t* d_body_len, const uint32_t* d_local_off,
-                           const uint64_t* d_block_base, void* d_out, uint64_t* d_frame_offsets, void* d_kafka_keys, hipStream_t s) {
-    static_assert(64 * kPbMaxFrame + 16 <= 5 * kPbWindow, "window count bound");
+                           const uint64_t* d_block_base, void* d_out, uint64_t* d_frame_offsets, void* d_kafka_keys, uint64_t total_bytes, hipStream_t s) {
+    const uint64_t avg = n ? total_bytes / n : 0;
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_pb_write, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_recs, n, P, F, d_body_len, d_local_off, d_block_base,
-                       (uint8_t*)d_out, d_frame_offsets, (uint8_t*)d_kafka_keys);
+    if (avg <= 120)
+        hipLaunchKernelGGL(k_pb_write<8192>, grid, block, 0, s, d_recs, n, P, F, d_body_len, d_local_off, d_block_base, (uint8_t*)d_out, d_frame_offsets, (uint8_t*)d_kafka_keys);
+    else if (avg <= 248)
+        hipLaunchKernelGGL(k_pb_write<16384>, grid, block, 0, s, d_recs, n, P, F, d_body_len, d_local_off, d_block_base, (uint8_t*)d_out, d_frame_offsets, (uint8_t*)d_kafka_keys);
+    else
+        hipLaunchKernelGGL(k_pb_write<24576>, grid, block, 0, s, d_recs, n, P, F, d_body_len, d_local_off, d_block_base, (uint8_t*)d_out, d_frame_offsets, (uint8_t*)d_kafka_keys);
     return hipGetLastError();
 }
 

@@ -10,8 +10,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-NAMES = [(1, None, "lo", ""), (2, None, "eth0", "default"), (3, bytes.fromhex("020000000001"), "veth3a", "udn-blue"),
-         (3, None, "veth3", ""), (4, None, "ovn-k8s-mp0", "t"), (6, None, "", "nameless"), (8, None, "x" * 16, "u" * 63)]
+# deliberately NOT sorted by index, with several rows per index: the answer must be that of a scan in table order
+# (exact (index, MAC) row wherever it stands, else the FIRST any-MAC row of the index)
+NAMES = [(8, None, "x" * 16, "u" * 63), (3, bytes.fromhex("020000000001"), "veth3a", "udn-blue"), (1, None, "lo", ""),
+         (3, None, "veth3", ""), (2, None, "eth0", "default"), (3, None, "veth3-second-any", "never"),
+         (3, bytes.fromhex("aabbccddeeff"), "veth3b", "udn-late"), (4, None, "ovn-k8s-mp0", "t"), (6, None, "", "nameless"),
+         (2, bytes.fromhex("020000000002"), "eth0-mac", "")]
 AGENT4 = bytes(10) + b"\xff\xff" + bytes([10, 1, 2, 3])
 
 
@@ -65,6 +69,20 @@ def test_stream_parity_with_oracle(nf, O, n):
     assert got == want
     assert int(off[0]) == 0 and int(off[-1]) == len(buf) and (np.diff(off.astype(np.int64)) > 0).all()
     assert np.array_equal(keys, O.kafka_keys(recs))
+
+
+def test_namer_table_larger_than_lds(nf, O):
+    """More rows than the kernels stage in LDS (96): the lookups go to the table in HBM, same bytes."""
+    rows = [(1000 + k, None, "if%d" % k, "u%d" % k) for k in range(150)] + NAMES
+    recs = O.gen_stream(3000, seed=8, n_keys=500, variant=1)
+    recs["metrics"]["if_index_first_seen"][::2] = 1000 + (np.arange(1500) % 150)
+    recs["metrics"]["src_mac"][::3] = np.frombuffer(bytes.fromhex("aabbccddeeff"), dtype=np.uint8)
+    recs["metrics"]["dst_mac"][::3] = np.frombuffer(bytes.fromhex("020000000002"), dtype=np.uint8)
+    now, mono = 1_700_000_000_000_000_000, 10**9
+    want = O.pb_encode(recs, O.pb_options(now, mono, AGENT4, O.intf_table(rows)))
+    with nf.FlowTable(max_entries=64) as tab:
+        buf, off, blen = tab.encode_pb(recs.view(nf.FLOW_RECORD), now, mono, AGENT4, nf.intf_table(rows))
+    assert frames(buf, off, blen) == want
 
 
 def test_empty_truncated_and_unknown_names(nf, O):
