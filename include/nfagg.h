@@ -445,6 +445,20 @@ int nfagg_hll_estimate(nfagg_handle* h, int which, double* estimate);
 /* Count-Min point query for one 16-byte IP: min over rows. Host-side read of
  * d counters. which = NFAGG_CM_SRC / NFAGG_CM_DST. */
 int nfagg_cm_query(nfagg_handle* h, int which, const uint8_t ip[16], uint64_t* estimate);
+/* Heavy hitters: the k endpoints with the largest Count-Min byte estimate among the addresses that occur in `records`
+ * — Count-Min stores no keys, so the candidates come from a record batch, typically the one nfagg_evict just returned
+ * (the sketch is keyed by src address for NFAGG_CM_SRC, by dst address for NFAGG_CM_DST, and the same side of each
+ * record is looked up). Order: estimate descending, then the 16 address bytes ascending; *n_out = min(k, distinct
+ * addresses). Estimates are computed and sorted on the device; `out` is HOST memory. */
+typedef struct nfagg_heavy_hitter {
+    uint8_t  ip[16];
+    uint64_t estimate;
+} nfagg_heavy_hitter;            /* 24 bytes */
+int nfagg_cm_topk(nfagg_handle* h, int which, const void* records, size_t n, size_t k,
+                  nfagg_heavy_hitter* out, size_t* n_out);
+/* Same with d_records in DEVICE memory (16-byte aligned), e.g. straight from nfagg_evict_device. */
+int nfagg_cm_topk_device(nfagg_handle* h, int which, const void* d_records, size_t n, size_t k,
+                         nfagg_heavy_hitter* out, size_t* n_out);
 /* The HLL estimator itself, on a host histogram hist[0..64] of register
  * values for m = 1<<p registers (exposed so callers can estimate after a
  * cross-GPU max-merge). */

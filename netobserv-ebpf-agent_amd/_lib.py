@@ -120,6 +120,8 @@ SIGNATURES = {
     "nfagg_ringbuf_drain": (C.c_int, [C.POINTER(RingBuf), _vp, _sz, _psz, _psz, _vp]),
     "nfagg_encode_pb": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
     "nfagg_encode_pb_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
+    "nfagg_cm_topk": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _vp, _psz]),
+    "nfagg_cm_topk_device": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _vp, _psz]),
     "nfagg_map_merge": (C.c_int, [_vp, C.POINTER(MapView), C.POINTER(MapView), _sz, C.POINTER(MergedFlows), _sz, _psz, _psz]),
     "nfagg_map_merge_device": (C.c_int, [_vp, C.POINTER(MapView), C.POINTER(MapView), _sz, C.POINTER(MergedFlows), _sz, _psz, _psz]),
     "nfagg_encode_pb_content": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbFeatures), C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),

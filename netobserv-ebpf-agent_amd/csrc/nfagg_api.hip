@@ -9,6 +9,7 @@
 #include <string.h>
 #include <algorithm>
 #include <new>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -70,6 +71,8 @@ struct nfagg_handle {
     // (host variant) [6..12] ids, [13..19] values, [20..27] outputs
     void* d_mm[28] = {};
     size_t d_mm_cap[28] = {};
+    void* d_hh[7] = {};            // heavy hitters: est, est sorted, idx, idx sorted, sort scratch, gathered rows, (host variant) records
+    size_t d_hh_cap[7] = {};
     void* d_sort[2] = {};          // eviction: live list in slot order, radix-sort scratch
     size_t d_sort_cap[2] = {};
     int sort_bits = 0;
@@ -414,6 +417,7 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->d_spill) hipFree(h->d_spill);
     for (int k = 0; k < 15; k++) if (h->d_pb[k]) hipFree(h->d_pb[k]);
     for (int k = 0; k < 2; k++) if (h->d_sort[k]) hipFree(h->d_sort[k]);
+    for (int k = 0; k < 7; k++) if (h->d_hh[k]) hipFree(h->d_hh[k]);
     for (int k = 0; k < 28; k++) if (h->d_mm[k]) hipFree(h->d_mm[k]);
     if (h->tv.spill.qtail) hipFree(h->tv.spill.qtail);
     if (h->d_evict) hipFree(h->d_evict);
@@ -861,6 +865,79 @@ int nfagg_cm_query(nfagg_handle* h, int which, const uint8_t ip[16], uint64_t* e
     }
     *estimate = best;
     return NFAGG_OK;
+}
+
+// Heavy hitters. Device: estimate per record, radix sort by estimate (descending). Host: walk the sorted order, keep the
+// first occurrence of every address, stop once k distinct addresses are known AND the estimate has dropped below the
+// k-th one (ties at the boundary are resolved by address bytes, so every candidate with the boundary estimate must be seen).
+static int cm_topk_core(nfagg_handle* h, int which, const void* d_records, size_t n, size_t k, nfagg_heavy_hitter* out, size_t* n_out) {
+    if (!h || !n_out || (k && !out) || (n && !d_records)) return fail(h, NFAGG_EINVAL, "null argument");
+    if (which != NFAGG_CM_SRC && which != NFAGG_CM_DST) return fail(h, NFAGG_EINVAL, "which must be a CM sketch");
+    if (n >= (1ull << 31)) return fail(h, NFAGG_ERANGE, "heavy hitters: more than 2^31 candidate records");
+    *n_out = 0;
+    void* cm; size_t cm_bytes;
+    int rc = sketch_info(h, which, &cm, &cm_bytes);
+    if (rc != NFAGG_OK) return rc;
+    if (n == 0 || k == 0) return NFAGG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int side = which - NFAGG_CM_SRC;
+    size_t temp_bytes = 0;
+    hipError_t e = launch_cm_sort_desc(nullptr, nullptr, nullptr, nullptr, n, nullptr, &temp_bytes, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "sort size query failed: %s", hipGetErrorString(e));
+    if ((rc = ensure_bytes(h, &h->d_hh[0], &h->d_hh_cap[0], n * sizeof(uint64_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_hh[1], &h->d_hh_cap[1], n * sizeof(uint64_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_hh[2], &h->d_hh_cap[2], n * sizeof(uint32_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_hh[3], &h->d_hh_cap[3], n * sizeof(uint32_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_hh[4], &h->d_hh_cap[4], temp_bytes + 16)) != NFAGG_OK) return rc;
+    e = launch_cm_estimate((const uint64_t*)cm, h->sk.cm_depth, h->sk.cm_log2w, side, d_records, n, (uint64_t*)h->d_hh[0], (uint32_t*)h->d_hh[2], h->stream);
+    if (e == hipSuccess) e = launch_cm_sort_desc((const uint64_t*)h->d_hh[0], (uint64_t*)h->d_hh[1], (const uint32_t*)h->d_hh[2], (uint32_t*)h->d_hh[3], n,
+                                                 h->d_hh[4], &temp_bytes, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "heavy-hitter launch failed: %s", hipGetErrorString(e));
+    struct Row { uint64_t lo, hi, est; };
+    std::vector<Row> rows, best;                         // best: distinct addresses in order of appearance (estimate descending)
+    std::set<std::pair<uint64_t, uint64_t>> group;       // addresses already taken at the current estimate
+    uint64_t group_est = ~0ull;
+    size_t seen = 0, m = k * 16 < 4096 ? 4096 : k * 16;
+    for (;;) {
+        if (m > n) m = n;
+        if ((rc = ensure_bytes(h, &h->d_hh[5], &h->d_hh_cap[5], m * sizeof(Row))) != NFAGG_OK) return rc;
+        e = launch_cm_gather(d_records, side, (const uint64_t*)h->d_hh[1], (const uint32_t*)h->d_hh[3], m, (uint64_t*)h->d_hh[5], h->stream);
+        if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "heavy-hitter gather failed: %s", hipGetErrorString(e));
+        rows.resize(m);
+        HIP_TRY(h, hipMemcpyAsync(rows.data(), h->d_hh[5], m * sizeof(Row), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        bool done = false;
+        for (; seen < m; seen++) {
+            const Row& r = rows[seen];
+            if (best.size() >= k && r.est < best[k - 1].est) { done = true; break; }   // below the boundary: nothing further can enter
+            // an address always carries the same estimate, so a duplicate can only sit among the entries with THIS estimate
+            if (r.est != group_est) { group.clear(); group_est = r.est; }
+            if (group.insert(std::make_pair(r.lo, r.hi)).second) best.push_back(r);
+        }
+        if (done || m == n) break;
+        m *= 4;
+    }
+    std::sort(best.begin(), best.end(), [](const Row& a, const Row& b) {
+        if (a.est != b.est) return a.est > b.est;
+        return memcmp(&a.lo, &b.lo, 16) < 0;             // lo,hi are adjacent: the 16 address bytes in order
+    });
+    const size_t cnt = best.size() < k ? best.size() : k;
+    for (size_t q = 0; q < cnt; q++) { memcpy(out[q].ip, &best[q].lo, 16); out[q].estimate = best[q].est; }
+    *n_out = cnt;
+    return NFAGG_OK;
+}
+
+int nfagg_cm_topk_device(nfagg_handle* h, int which, const void* d_records, size_t n, size_t k, nfagg_heavy_hitter* out, size_t* n_out) {
+    return cm_topk_core(h, which, d_records, n, k, out, n_out);
+}
+
+int nfagg_cm_topk(nfagg_handle* h, int which, const void* records, size_t n, size_t k, nfagg_heavy_hitter* out, size_t* n_out) {
+    if (!h || (n && !records)) return fail(h, NFAGG_EINVAL, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_bytes(h, &h->d_hh[6], &h->d_hh_cap[6], n * kRecordBytes + 16);
+    if (rc != NFAGG_OK) return rc;
+    if (n) HIP_TRY(h, hipMemcpyAsync(h->d_hh[6], records, n * kRecordBytes, hipMemcpyHostToDevice, h->stream));
+    return cm_topk_core(h, which, h->d_hh[6], n, k, out, n_out);
 }
 
 // ---------------------------------------------------------------- misc

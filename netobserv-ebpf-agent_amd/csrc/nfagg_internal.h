@@ -152,6 +152,12 @@ hipError_t launch_sort_slots(const uint32_t* d_in, uint32_t* d_out, uint64_t n, 
 hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);
 // Sketch update over a batch (nfagg_sketch.hip).
 hipError_t launch_sketch_update(const SketchView& sk, const TableView& t, const void* d_records, uint64_t n, hipStream_t s);
+hipError_t launch_cm_estimate(const uint64_t* d_cm, uint32_t depth, uint32_t log2w, int side, const void* d_records, uint64_t n,
+                              uint64_t* d_est, uint32_t* d_idx, hipStream_t s);
+hipError_t launch_cm_sort_desc(const uint64_t* d_est, uint64_t* d_est_sorted, const uint32_t* d_idx, uint32_t* d_idx_sorted, uint64_t n,
+                               void* d_temp, size_t* temp_bytes, hipStream_t s);
+hipError_t launch_cm_gather(const void* d_records, int side, const uint64_t* d_est_sorted, const uint32_t* d_idx_sorted, uint64_t m,
+                            uint64_t* d_rows, hipStream_t s);
 hipError_t launch_hll_histogram(const uint32_t* d_regs, uint32_t p, uint32_t* d_hist65, hipStream_t s);
 hipError_t launch_hll_pack(const uint32_t* d_regs, uint32_t p, uint8_t* d_out, hipStream_t s);
 

@@ -220,6 +220,21 @@ class FlowTable:
         self._check(L.lib.nfagg_cm_query(self._h, which, buf, C.byref(v)))
         return v.value
 
+    HEAVY_HITTER = np.dtype([("ip", "u1", 16), ("estimate", "<u8")])
+
+    def cm_topk(self, which, records, k: int, device_ptr: int = 0, n: int = 0) -> np.ndarray:
+        """nfagg_cm_topk: the k heaviest endpoints (Count-Min estimate) among the addresses of `records` (host array), or of
+        the n records at device_ptr."""
+        out = np.zeros(max(k, 1), dtype=self.HEAVY_HITTER)
+        n_out = C.c_size_t(0)
+        if device_ptr:
+            rc = L.lib.nfagg_cm_topk_device(self._h, which, C.c_void_p(device_ptr), n, k, out.ctypes.data_as(C.c_void_p), C.byref(n_out))
+        else:
+            r = np.ascontiguousarray(records)
+            rc = L.lib.nfagg_cm_topk(self._h, which, r.ctypes.data_as(C.c_void_p), r.nbytes // 144, k, out.ctypes.data_as(C.c_void_p), C.byref(n_out))
+        self._check(rc)
+        return out[: n_out.value]
+
     # -- misc
     # -- export encode (record -> protobuf), nfagg_encode_pb
     def _pb_options(self, now_unix_ns, mono_now_ns, agent_ip16, names, unknown):

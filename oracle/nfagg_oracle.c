@@ -401,6 +401,30 @@ uint64_t orc_cm_query(const uint64_t* cm, uint32_t depth, uint32_t log2w, const 
     return best;
 }
 
+/* Heavy hitters (our own spec): among the distinct src (side 0) / dst (side 1) addresses of `records`, the k with
+ * the largest Count-Min estimate; order: estimate descending, then address bytes ascending. out: k x {ip[16], u64 estimate}. */
+typedef struct { uint8_t ip[16]; uint64_t est; } hh_row;
+static int hh_ip_cmp(const void* a, const void* b) { return memcmp(a, b, 16); }
+static int hh_rank_cmp(const void* a, const void* b) {
+    const hh_row* x = (const hh_row*)a; const hh_row* y = (const hh_row*)b;
+    if (x->est != y->est) return x->est > y->est ? -1 : 1;
+    return memcmp(x->ip, y->ip, 16);
+}
+size_t orc_cm_topk(const uint64_t* cm, uint32_t depth, uint32_t log2w, const void* records, size_t n, int side, size_t k, void* out) {
+    const orc_flow_record* r = (const orc_flow_record*)records;
+    hh_row* rows = (hh_row*)calloc(n ? n : 1, sizeof *rows);
+    for (size_t i = 0; i < n; i++) memcpy(rows[i].ip, side ? r[i].id.dst_ip : r[i].id.src_ip, 16);
+    qsort(rows, n, sizeof *rows, hh_ip_cmp);
+    size_t d = 0;
+    for (size_t i = 0; i < n; i++) if (i == 0 || memcmp(rows[i].ip, rows[d - 1].ip, 16)) rows[d++] = rows[i];
+    for (size_t i = 0; i < d; i++) rows[i].est = orc_cm_query(cm, depth, log2w, rows[i].ip);
+    qsort(rows, d, sizeof *rows, hh_rank_cmp);
+    if (d > k) d = k;
+    memcpy(out, rows, d * sizeof *rows);
+    free(rows);
+    return d;
+}
+
 void orc_hll_update(uint8_t* regs, uint32_t p, const uint8_t ip[16]) {
     uint64_t h = orc_ip_hash(ip, 2);
     uint64_t idx = h >> (64 - p);

@@ -128,6 +128,9 @@ uint32_t orc_shard_of(const void* key40, uint32_t n_shards);
 /* cm: uint64[depth<<log2w]; adds `add` to one counter per row */
 void   orc_cm_update(uint64_t* cm, uint32_t depth, uint32_t log2w, const uint8_t ip[16], uint64_t add);
 uint64_t orc_cm_query(const uint64_t* cm, uint32_t depth, uint32_t log2w, const uint8_t ip[16]);
+/* the k heaviest distinct src/dst addresses of `records` by Count-Min estimate (estimate desc, address bytes asc);
+ * out: k rows of {uint8_t ip[16]; uint64_t estimate}; returns the number of rows */
+size_t orc_cm_topk(const uint64_t* cm, uint32_t depth, uint32_t log2w, const void* records, size_t n, int side, size_t k, void* out);
 void   orc_hll_update(uint8_t* regs, uint32_t p, const uint8_t ip[16]);
 /* scalar HLL estimate straight from the registers, register order */
 double orc_hll_estimate(const uint8_t* regs, uint32_t p);

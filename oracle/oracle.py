@@ -46,6 +46,7 @@ def lib():
             "orc_shard_of": (C.c_uint32, [_vp, C.c_uint32]),
             "orc_cm_update": (None, [_vp, C.c_uint32, C.c_uint32, _vp, _u64]),
             "orc_cm_query": (_u64, [_vp, C.c_uint32, C.c_uint32, _vp]),
+            "orc_cm_topk": (_sz, [_vp, C.c_uint32, C.c_uint32, _vp, _sz, C.c_int, _sz, _vp]),
             "orc_hll_update": (None, [_vp, C.c_uint32, _vp]),
             "orc_hll_estimate": (C.c_double, [_vp, C.c_uint32]),
             "orc_sketch_ingest": (None, [_vp, _sz, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint32]),
@@ -182,6 +183,16 @@ def sketches(records, depth=4, log2w=20, p=14):
     hd = np.zeros(1 << p, dtype=np.uint8)
     lib().orc_sketch_ingest(_p(r), r.nbytes // 144, _p(cm_s), _p(cm_d), depth, log2w, _p(hs), _p(hd), p)
     return cm_s, cm_d, hs, hd
+
+
+HEAVY_HITTER = np.dtype([("ip", "u1", 16), ("estimate", "<u8")])
+
+
+def cm_topk(cm, depth, log2w, records, side, k):
+    r = np.ascontiguousarray(records)
+    out = np.zeros(max(k, 1), dtype=HEAVY_HITTER)
+    n = lib().orc_cm_topk(_p(np.ascontiguousarray(cm)), depth, log2w, _p(r), r.nbytes // 144, side, k, _p(out))
+    return out[:n]
 
 
 def hll_estimate(regs, p):

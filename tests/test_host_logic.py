@@ -120,3 +120,19 @@ def test_config1_plumbing_through_oracle(O):
     assert len(ev) == len(np.unique(recs["id"]["src_port"]))
     assert int(ev["metrics"]["bytes"].sum()) == int(recs["metrics"]["bytes"].sum())
     assert int(ev["metrics"]["packets"].sum()) == int(recs["metrics"]["packets"].sum())
+
+
+def test_oracle_heavy_hitters_against_numpy(O):
+    """orc_cm_topk against an independent numpy composition (unique addresses, per-address orc_cm_query, lexsort)."""
+    recs = O.gen_stream(20000, seed=6, n_keys=3000, thresholds=O.zipf_thresholds(3000, 1.2), variant=1)
+    cm_s, cm_d, _, _ = O.sketches(recs, 4, 10, 10)
+    for side, cm, col in ((0, cm_s, "src_ip"), (1, cm_d, "dst_ip")):
+        ips = np.unique(recs["id"][col], axis=0)
+        est = np.array([O.lib().orc_cm_query(cm.ctypes.data, 4, 10, ip.tobytes()) for ip in ips], dtype=np.uint64)
+        order = sorted(range(len(ips)), key=lambda i: (-int(est[i]), ips[i].tobytes()))
+        for k in (1, 7, 500, len(ips) + 5):
+            got = O.cm_topk(cm, 4, 10, recs, side, k)
+            want = order[:k]
+            assert len(got) == len(want)
+            assert [g["ip"].tobytes() for g in got] == [ips[i].tobytes() for i in want]
+            assert [int(g["estimate"]) for g in got] == [int(est[i]) for i in want]

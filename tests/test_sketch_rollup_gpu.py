@@ -107,3 +107,24 @@ def test_rollup_reference_vectors(nf):
         b, f = tab.rollup("dns", d, 2, base)
         assert (b["start_mono_time_ts"][0], b["end_mono_time_ts"][0]) == (10, 30)
         assert (f["start_mono_time_ts"][0], f["end_mono_time_ts"][0], f["latency"][0], f["id"][0], f["flags"][0]) == (25, 25, 2000, 1, 0b1011)
+
+
+@pytest.mark.parametrize("k,log2w", [(1, 16), (10, 16), (100, 12), (5000, 8), (10**6, 16)])
+def test_heavy_hitters_match_scalar_oracle(nf, O, k, log2w):
+    """nfagg_cm_topk: estimates and order (estimate desc, address bytes asc) bit-exact vs the oracle. log2w = 8 collides
+    almost every address with others: long runs of equal estimates across the k-th position exercise the tie rule."""
+    import torch
+    th = O.zipf_thresholds(30000, 1.1)
+    recs = O.gen_stream(300000, seed=21, n_keys=30000, thresholds=th, variant=1)
+    with nf.FlowTable(max_entries=1 << 16, sketches=nf.SKETCH_CM, cm_depth=3, cm_log2_width=log2w) as tab:
+        tab.ingest(recs.view(nf.FLOW_RECORD))
+        ev = tab.evict(nf.REASON_TIMEOUT)
+        cm_s, cm_d, _, _ = O.sketches(recs, 3, log2w, 14)
+        for which, cm, side in ((nf.CM_SRC, cm_s, 0), (nf.CM_DST, cm_d, 1)):
+            want = O.cm_topk(cm, 3, log2w, ev.view(O.FLOW_RECORD), side, k)
+            got = tab.cm_topk(which, ev, k)
+            assert len(got) == len(want) == min(k, len(np.unique(ev["id"]["dst_ip" if side else "src_ip"], axis=0)))
+            assert got.tobytes() == want.tobytes()
+        d_ev = torch.from_numpy(ev.view(np.uint8).reshape(-1).copy()).cuda()
+        assert tab.cm_topk(nf.CM_SRC, None, k, device_ptr=d_ev.data_ptr(), n=len(ev)).tobytes() == O.cm_topk(cm_s, 3, log2w, ev.view(O.FLOW_RECORD), 0, k).tobytes()
+        assert len(tab.cm_topk(nf.CM_SRC, ev[:0], k)) == 0 and len(tab.cm_topk(nf.CM_SRC, ev, 0)) == 0
