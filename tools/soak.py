@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Randomised soak of the ingest/evict path against the oracle (run on the GPU box): random stream shapes, batch
+splits, kernel routings, table sizes and modes; every eviction compared bit for bit. Usage: soak.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import netobserv_ebpf_agent_amd as nf
+from oracle import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end = time.time() + budget
+rounds = recs_total = 0
+while time.time() < t_end:
+    n = int(rng.choice([50_000, 400_000, 1_500_000, 3_500_000, 5_000_000]))
+    keys = int(rng.choice([1, 50, 3_000, 100_000, 700_000]))
+    s = float(rng.choice([0.0, 0.8, 1.1, 1.6]))
+    hot = int(rng.choice([0, 0, 500, 900, 999]))
+    dedup = bool(rng.integers(0, 4) == 0)
+    variant = int(rng.choice([1, 2] if dedup else [1, 1, 1, 0]))       # stream variant: scrambled fields (2: interfaces for dedup)
+    ingest_variant = int(rng.choice([0, 0, 0, 7, 10, 11, 1])) if not dedup else int(rng.choice([0, 0, 1, 10]))
+    max_entries = int(rng.choice([1 << 20, 1 << 23, max(2, keys // 3), keys + 5]))
+    sketches = (nf.SKETCH_CM | nf.SKETCH_HLL) if (not dedup and rng.integers(0, 3) == 0) else 0
+    seed = int(rng.integers(1, 1 << 30))
+    th = O.zipf_thresholds(keys, s) if s > 0 and keys > 1 else None
+    recs = O.gen_stream(n, seed=seed, n_keys=keys, thresholds=th, hot_permille=hot, variant=variant)
+    want = O.run_accounter(recs, max_entries, 1 if dedup else 0)
+    cuts = np.sort(rng.integers(0, n, int(rng.integers(0, 6))))
+    bounds = [0, *cuts.tolist(), n]
+    got = []
+    with nf.FlowTable(max_entries=max_entries, mode=nf.MODE_KERNEL_DEDUP if dedup else nf.MODE_ACCOUNTER, sketches=sketches,
+                      cm_log2_width=14, hll_p=10, ingest_variant=ingest_variant) as tab:
+        view = recs.view(nf.FLOW_RECORD)
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            off = a
+            while off < b:
+                rc, c = tab.ingest(view[off:b])
+                off += c
+                if rc == nf.FULL:
+                    got.append(("full", nf.sort_by_key(tab.evict(nf.REASON_FULL))))
+        got.append(("closing", nf.sort_by_key(tab.evict(nf.REASON_CLOSING))))
+        if sketches:
+            cm_s, cm_d, hs, hd = O.sketches(recs, 4, 14, 10)
+            assert np.array_equal(tab.sketch_snapshot(nf.CM_SRC), cm_s) and np.array_equal(tab.sketch_snapshot(nf.HLL_DST), hd)
+    desc = dict(n=n, keys=keys, s=s, hot=hot, dedup=dedup, variant=variant, ingest_variant=ingest_variant, max_entries=max_entries, seed=seed, cuts=cuts.tolist())
+    assert [r for r, _ in got] == [r for r, _ in want], ("eviction sequence", desc)
+    for k, ((_, g), (_, w)) in enumerate(zip(got, want)):
+        assert g.tobytes() == w.tobytes(), ("eviction %d differs" % k, desc)
+    rounds += 1; recs_total += n
+print(f"soak ok: {rounds} rounds, {recs_total} records, every eviction bit-exact vs the oracle")
