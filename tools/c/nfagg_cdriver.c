@@ -1,0 +1,92 @@
+/* nfagg_cdriver.c — libnfagg driven from plain C, the way the cgo shim of INTEGRATION.md drives it: no Python, no torch,
+ * only include/nfagg.h and lib/libnfagg.so. Reads 144-byte flow_record_t from a file, feeds them through
+ * nfagg_ingest in ring-sized batches with the Accounter's evict-on-full loop (pkg/flow/account.go:81-96), evicts on
+ * close, serialises the evicted flows with nfagg_encode_pb, and writes
+ *   <out>.records : every evicted batch back to back (144-byte records)
+ *   <out>.pb      : the pbflow.Records frames of the LAST eviction
+ *   stdout        : one line per eviction "reason n_flows", then "hll_src <estimate>" when sketches are on.
+ * usage: nfagg_cdriver <records.bin> <out-prefix> <max_entries> <batch_records> <sketches 0|1>
+ *   cc -std=c11 -O2 -I include tools/c/nfagg_cdriver.c -o nfagg_cdriver -L <libdir> -lnfagg -Wl,-rpath,<libdir> */
+#include <inttypes.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "nfagg.h"
+
+static void die(nfagg_handle* h, const char* what, int rc) {
+    fprintf(stderr, "%s failed: %d: %s\n", what, rc, nfagg_last_error(h) ? nfagg_last_error(h) : "");
+    exit(2);
+}
+
+int main(int argc, char** argv) {
+    if (argc != 6) { fprintf(stderr, "usage: %s records.bin out-prefix max_entries batch sketches\n", argv[0]); return 1; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror(argv[1]); return 1; }
+    fseek(f, 0, SEEK_END);
+    const size_t n = (size_t)ftell(f) / sizeof(nfagg_flow_record);
+    fseek(f, 0, SEEK_SET);
+    nfagg_flow_record* recs = malloc(n ? n * sizeof *recs : 1);
+    if (fread(recs, sizeof *recs, n, f) != n) { fprintf(stderr, "short read\n"); return 1; }
+    fclose(f);
+    const uint64_t max_entries = strtoull(argv[3], 0, 10);
+    const size_t batch = (size_t)strtoull(argv[4], 0, 10);
+    const int sketches = atoi(argv[5]);
+
+    nfagg_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
+    cfg.max_entries = max_entries;
+    cfg.sketch_flags = sketches ? (NFAGG_SKETCH_CM | NFAGG_SKETCH_HLL) : 0;
+    nfagg_handle* h = 0;
+    int rc = nfagg_create(&cfg, &h);
+    if (rc != NFAGG_OK) die(0, "nfagg_create", rc);
+
+    char path[4096];
+    snprintf(path, sizeof path, "%s.records", argv[2]);
+    FILE* fo = fopen(path, "wb");
+    nfagg_flow_record* out = malloc((size_t)(max_entries ? max_entries : 1) * sizeof *out);
+    size_t n_out = 0, off = 0;
+    while (off < n) {                                            /* the record arm of Accounter.Account, batched */
+        const size_t m = n - off < batch ? n - off : batch;
+        size_t consumed = 0;
+        rc = nfagg_ingest(h, recs + off, m, &consumed);
+        if (rc < 0) die(h, "nfagg_ingest", rc);
+        off += consumed;
+        if (rc == NFAGG_FULL) {                                  /* account.go:85-94: evict, then resubmit the rest */
+            if ((rc = nfagg_evict(h, NFAGG_REASON_FULL, out, (size_t)max_entries, &n_out)) != NFAGG_OK) die(h, "nfagg_evict(full)", rc);
+            fwrite(out, sizeof *out, n_out, fo);
+            printf("full %zu\n", n_out);
+        }
+    }
+    if ((rc = nfagg_evict(h, NFAGG_REASON_CLOSING, out, (size_t)max_entries, &n_out)) != NFAGG_OK) die(h, "nfagg_evict(closing)", rc);
+    fwrite(out, sizeof *out, n_out, fo);
+    fclose(fo);
+    printf("closing %zu\n", n_out);
+
+    nfagg_intf_name names[2];
+    memset(names, 0, sizeof names);
+    names[0].if_index = 2; names[0].name_len = 4; memcpy(names[0].name, "eth0", 4);
+    names[1].if_index = 3; names[1].name_len = 4; memcpy(names[1].name, "eth1", 4); names[1].udn_len = 7; memcpy(names[1].udn, "default", 7);
+    nfagg_pb_options opt;
+    memset(&opt, 0, sizeof opt);
+    opt.struct_size = sizeof opt;
+    opt.n_names = 2; opt.names = names;
+    opt.now_unix_ns = 1700000000000000000ll; opt.mono_now_ns = 3000000;
+    opt.agent_ip[10] = 0xff; opt.agent_ip[11] = 0xff; opt.agent_ip[12] = 10; opt.agent_ip[15] = 1;
+    memcpy(opt.unknown_name, "unknown", 7); opt.unknown_len = 7;
+    uint64_t* offs = malloc((n_out + 1) * sizeof *offs);
+    uint32_t* lens = malloc((n_out ? n_out : 1) * sizeof *lens);
+    size_t need = 0, cap = 64;
+    uint8_t* pb = malloc(cap);
+    while ((rc = nfagg_encode_pb(h, out, n_out, &opt, pb, cap, offs, lens, 0, &need)) == NFAGG_TRUNCATED) { cap = need; pb = realloc(pb, cap); }
+    if (rc != NFAGG_OK) die(h, "nfagg_encode_pb", rc);
+    snprintf(path, sizeof path, "%s.pb", argv[2]);
+    fo = fopen(path, "wb"); fwrite(pb, 1, need, fo); fclose(fo);
+    if (sketches) {
+        double est = 0;
+        if ((rc = nfagg_hll_estimate(h, NFAGG_HLL_SRC, &est)) != NFAGG_OK) die(h, "nfagg_hll_estimate", rc);
+        printf("hll_src %.17g\n", est);
+    }
+    nfagg_destroy(h);
+    return 0;
+}
