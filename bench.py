@@ -248,6 +248,19 @@ def main():
                 assert sum(g[0] for g in got) == m and sum(g[1] for g in got) == len(ev)
                 out["cpu_baseline"]["multicore"] = {"value": round(m / mc_dt / 1e6, 3), "unit": "Mrecords/s", "cores": T, "kind": "port",
                                                     "sample": "same sample, key-hash split over %d threads, %.1f s" % (T, mc_dt)}
+        # ---- the chip's copy bandwidth in this very run (state the peak used, confirm it with a D2D copy):
+        # up to 4 GiB device-to-device (the stream's first half over its second: nothing reads the stream after this point),
+        # read + written bytes over the time of the copy
+        try:
+            nb = min(4 << 30, (n * 144) // 2 // 256 * 256)
+            src_t, dst_t = d_recs[:nb], d_recs[nb:2 * nb]
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dst_t.copy_(src_t); torch.cuda.synchronize()
+            ev0.record(); dst_t.copy_(src_t); ev1.record(); torch.cuda.synchronize()
+            out["roofline"]["hbm_copy_measured_GBs"] = round(2 * nb / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
+        except Exception as exc:                      # a diagnostic, never a reason to lose the bench line
+            out["roofline"]["hbm_copy_measured_GBs"] = None
+            out["roofline"]["hbm_copy_error"] = str(exc)[:100]
         print(json.dumps(out), flush=True)
     tab.close()
     if world > 1:
