@@ -75,6 +75,11 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if rank == 0:
+        import __graft_entry__
+        __graft_entry__.ensure_built()      # fresh checkout: compile the HIP library first (git-ignored artefact)
+    if world > 1:
+        dist.barrier()
     import netobserv_ebpf_agent_amd as nf
     from netobserv_ebpf_agent_amd import synth
 

@@ -11,6 +11,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import __graft_entry__
+    __graft_entry__.ensure_built()          # a fresh checkout has no .so yet (git-ignored): compile the product, never replace it
 
 
 @pytest.fixture(scope="session")
