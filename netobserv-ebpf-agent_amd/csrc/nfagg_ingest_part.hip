@@ -1,4 +1,4 @@
-// nfagg_ingest_part.hip — two-pass partitioned ingest (ingest_variant 7).
+// nfagg_ingest_part.hip — two-pass partitioned ingest (the default from 3 Mi records per call; ingest_variant 10 forces it).
 //
 // The single-pass cached kernel (nfagg_ingest_cached.hip) folds the hot head of a
 // Zipf stream in LDS, but every record of the cold tail (40 % of configs[1]) goes to
@@ -9,7 +9,7 @@
 //   pass 1  k_fold<.., false>  streams the batch once. Hot flows are folded in the
 //           workgroup's LDS flow cache exactly as before; a record whose flow gets no
 //           cache entry is SPILLED: its 32-bit index is appended to the queue of its
-//           key-hash partition (2048 partitions), staged four at a time in LDS so a
+//           partition (2048 partitions = the top bits of its home slot index), staged four at a time in LDS so a
 //           spill costs one 16-byte store and a quarter of an atomic.
 //   pass 2  k_fold<.., true>   one workgroup per partition gathers the spilled
 //           records by index and folds them in ITS LDS cache. A partition holds

@@ -114,7 +114,7 @@ struct TableView {
     DevCounters* ctr;
     uint64_t mask;                 // slots - 1
     uint32_t n_shards, shard_id;
-    SpillView spill;               // set by the API for ingest_variant 7
+    SpillView spill;               // set by the API for the two-pass fold
 };
 
 struct SketchView {

@@ -168,9 +168,9 @@ hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d
         if (variant == 1 || (variant != 10 && n < kDedupCachedMinBatch)) return launch_ingest_dedup(t, d_records, n, seq_base, s);
         return launch_ingest_dedup_cached(t, d_records, n, seq_base, s);
     }
-    // 0 (default): two-pass partitioned fold (nfagg_ingest_part.hip; 8/9 = its phase-timing builds) — batches too
-    // small to amortise its extra launches take the single-pass cached kernel, which is what variant 7 always runs.
-    // 3..5: other geometries of the cached kernel, 6: its phase-timing build; 1: direct; 2: per-tile LDS fold.
+    // 0 (default): by batch size (see kDirectMaxBatch / kPartMinBatch above) — direct kernel, single-pass cached kernel
+    // (what variant 7 always runs), two-pass partitioned fold (nfagg_ingest_part.hip; 8/9 = its phase-timing builds).
+    // 3..5: other geometries of the cached kernel, 6: its phase-timing build; 1: direct always; 2: per-tile LDS fold.
     if (takes_two_pass(variant, n))   // 10: two-pass whatever the size; 11: same without the admission filter
         return launch_ingest_part(t, sk, t.spill, d_records, n, seq_base, variant, s);
     if (variant == 2) return launch_ingest_lds(t, d_records, n, seq_base, variant, s);
