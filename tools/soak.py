@@ -21,15 +21,18 @@ while time.time() < t_end:
     ingest_variant = int(rng.choice([0, 0, 0, 7, 10, 11, 1])) if not dedup else int(rng.choice([0, 0, 1, 10]))
     max_entries = int(rng.choice([1 << 20, 1 << 23, max(2, keys // 3), keys + 5]))
     sketches = (nf.SKETCH_CM | nf.SKETCH_HLL) if (not dedup and rng.integers(0, 3) == 0) else 0
+    n_shards = int(rng.choice([1, 1, 2, 8]))
+    shard_id = int(rng.integers(0, n_shards))
     seed = int(rng.integers(1, 1 << 30))
     th = O.zipf_thresholds(keys, s) if s > 0 and keys > 1 else None
     recs = O.gen_stream(n, seed=seed, n_keys=keys, thresholds=th, hot_permille=hot, variant=variant)
-    want = O.run_accounter(recs, max_entries, 1 if dedup else 0)
+    mine = recs if n_shards == 1 else recs[nf.distributed.shard_ids(recs.view(nf.FLOW_RECORD), n_shards) == shard_id]
+    want = O.run_accounter(mine, max_entries, 1 if dedup else 0)
     cuts = np.sort(rng.integers(0, n, int(rng.integers(0, 6))))
     bounds = [0, *cuts.tolist(), n]
     got = []
     with nf.FlowTable(max_entries=max_entries, mode=nf.MODE_KERNEL_DEDUP if dedup else nf.MODE_ACCOUNTER, sketches=sketches,
-                      cm_log2_width=14, hll_p=10, ingest_variant=ingest_variant) as tab:
+                      cm_log2_width=14, hll_p=10, ingest_variant=ingest_variant, n_shards=n_shards, shard_id=shard_id) as tab:
         view = recs.view(nf.FLOW_RECORD)
         for a, b in zip(bounds[:-1], bounds[1:]):
             off = a
@@ -40,9 +43,9 @@ while time.time() < t_end:
                     got.append(("full", nf.sort_by_key(tab.evict(nf.REASON_FULL))))
         got.append(("closing", nf.sort_by_key(tab.evict(nf.REASON_CLOSING))))
         if sketches:
-            cm_s, cm_d, hs, hd = O.sketches(recs, 4, 14, 10)
+            cm_s, cm_d, hs, hd = O.sketches(mine, 4, 14, 10)
             assert np.array_equal(tab.sketch_snapshot(nf.CM_SRC), cm_s) and np.array_equal(tab.sketch_snapshot(nf.HLL_DST), hd)
-    desc = dict(n=n, keys=keys, s=s, hot=hot, dedup=dedup, variant=variant, ingest_variant=ingest_variant, max_entries=max_entries, seed=seed, cuts=cuts.tolist())
+    desc = dict(n=n, keys=keys, s=s, hot=hot, dedup=dedup, variant=variant, ingest_variant=ingest_variant, max_entries=max_entries, seed=seed, cuts=cuts.tolist(), n_shards=n_shards, shard_id=shard_id)
     assert [r for r, _ in got] == [r for r, _ in want], ("eviction sequence", desc)
     for k, ((_, g), (_, w)) in enumerate(zip(got, want)):
         assert g.tobytes() == w.tobytes(), ("eviction %d differs" % k, desc)
