@@ -42,6 +42,14 @@ NF_DEV void topk_insert(const TableView& t, uint64_t* w, uint64_t v) {
     atomicExch(&t.ctr->error, 4u);
 }
 
+// the part of record_prologue after the load (for loops that request the next tile's record ahead of time)
+NF_DEV bool record_keys(const TableView& t, Rec& r, uint64_t w[5], uint64_t& h) {
+    r.canonicalize();
+    r.key_words(w);
+    h = key_hash(w);
+    return !(t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id);
+}
+
 NF_DEV bool record_prologue(const TableView& t, const void* recs, uint64_t i, Rec& r, uint64_t w[5], uint64_t& h) {
     load_record(recs, i, r);
     r.canonicalize();

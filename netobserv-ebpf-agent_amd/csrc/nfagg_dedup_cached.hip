@@ -117,12 +117,18 @@ __global__ __launch_bounds__(kBlock) void k_dedup_claim_cached(TableView t, cons
     __syncthreads();
     const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
     unsigned long long skipped = 0;
+    // software pipeline: the next tile's record is requested (unconditionally, on a clamped index) before this one is processed
+    uint64_t i = (uint64_t)blockIdx.x * kBlock + tid;
+    bool valid = i < n;
+    Rec r;
+    load_record(recs, valid ? i : 0, r);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t i = tile * kBlock + tid;
-        bool valid = i < n;
-        Rec r;
+        const uint64_t i_n = (tile + gridDim.x) * kBlock + tid;
+        const bool valid_n = i_n < n;
+        Rec r_n;
+        load_record(recs, valid_n ? i_n : 0, r_n);
         uint64_t w[5], h = 0;
-        if (valid && !record_prologue(t, recs, i, r, w, h)) { valid = false; skipped++; }
+        if (valid && !record_keys(t, r, w, h)) { valid = false; skipped++; }
         const uint32_t seq32 = (uint32_t)(seq_base + i);
         const uint32_t ifx = valid ? r.d[21] : 0;
         const int ent0 = valid ? claim<ClaimCache<kClaimEntries>, kClaimEntries, kClaimDoorBits>(L, door, subflow_hash(h, ifx), w, ifx) : -1;
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_dedup_claim_cached(TableView t, cons
             }
         }
         // the next tile's claims only write h64/key/ifx of NEW entries; min_seq reads/updates are ordered by its barrier
+        r = r_n; valid = valid_n; i = i_n;
     }
     __syncthreads();
     for (int e = tid; e < kClaimEntries; e += kBlock) {
@@ -169,12 +176,18 @@ __global__ __launch_bounds__(kBlock) void k_dedup_fold_cached(TableView t, const
     __syncthreads();
     const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
     unsigned long long direct = 0;
+    // software pipeline, as in the claim pass
+    uint64_t i = (uint64_t)blockIdx.x * kBlock + tid;
+    bool valid = i < n;
+    Rec r;
+    load_record(recs, valid ? i : 0, r);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t i = tile * kBlock + tid;
-        bool valid = i < n;
-        Rec r;
+        const uint64_t i_n = (tile + gridDim.x) * kBlock + tid;
+        const bool valid_n = i_n < n;
+        Rec r_n;
+        load_record(recs, valid_n ? i_n : 0, r_n);
         uint64_t w[5], h = 0;
-        if (valid && !record_prologue(t, recs, i, r, w, h)) valid = false;
+        if (valid && !record_keys(t, r, w, h)) valid = false;
         const uint32_t seq32 = (uint32_t)(seq_base + i);
         const uint32_t ifx = valid ? r.d[21] : 0;
         const int ent0 = valid ? claim<FoldCache<kFoldEntries>, kFoldEntries, kFoldDoorBits>(L, door, subflow_hash(h, ifx), w, ifx) : -1;
@@ -205,6 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_dedup_fold_cached(TableView t, const
                 dedup_fold_record(t, r, w, h, seq32);            // no entry for this sub-flow
             }
         }
+        r = r_n; valid = valid_n; i = i_n;
     }
     __syncthreads();
     for (int e = tid; e < kFoldEntries; e += kBlock) {
