@@ -156,7 +156,8 @@ static bool takes_two_pass(int variant, uint64_t n) { return (variant >= 8 && va
 static bool takes_direct(int variant, uint64_t n, uint32_t sketch_flags) {
     return variant == 1 || (variant == 0 && n < kDirectMaxBatch && sketch_flags == 0);   // with sketches on, the cached kernel fuses them: one launch
 }
-bool ingest_needs_spill(int mode, int variant, uint64_t n) { return mode == 0 && takes_two_pass(variant, n); }
+static bool dedup_takes_cached(int variant, uint64_t n) { return !(variant == 1 || (variant != 10 && n < kDedupCachedMinBatch)); }
+bool ingest_needs_spill(int mode, int variant, uint64_t n) { return mode == 0 ? takes_two_pass(variant, n) : dedup_takes_cached(variant, n); }
 bool ingest_fuses_sketches(int mode, int variant, uint64_t n, uint32_t sketch_flags) {
     return mode == 0 && !takes_direct(variant, n, sketch_flags) && variant != 2 && variant != 6 && variant != 8 && variant != 9;
 }
@@ -165,7 +166,7 @@ hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d
                          int mode, int variant, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (mode == 1) {   // NFAGG_MODE_KERNEL_DEDUP: LDS-cached passes; direct per-record passes for small batches (variant 1: always, 10: never)
-        if (variant == 1 || (variant != 10 && n < kDedupCachedMinBatch)) return launch_ingest_dedup(t, d_records, n, seq_base, s);
+        if (!dedup_takes_cached(variant, n)) return launch_ingest_dedup(t, d_records, n, seq_base, s);
         return launch_ingest_dedup_cached(t, d_records, n, seq_base, s);
     }
     // 0 (default): by batch size (see kDirectMaxBatch / kPartMinBatch above) — direct kernel, single-pass cached kernel
