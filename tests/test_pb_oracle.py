@@ -124,3 +124,37 @@ def test_kafka_key_orders_the_two_addresses(O):
     for r, k in zip(recs, keys):
         a, b = r["id"]["src_ip"].tobytes(), r["id"]["dst_ip"].tobytes()
         assert k.tobytes() == (a + b if a <= b else b + a)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_oracle_matches_protobuf_runtime_on_random_contents(O, seed):
+    """Beyond the committed golden vectors: random flows and feature parts, the C oracle against the Python protobuf
+    runtime filled by the independent Python restatement of NewRecord/FlowToPB (tests/golden/gen_pb_golden.py)."""
+    import gen_pb_golden as G
+    Record, _ = G.build_classes()
+    rng = np.random.default_rng(seed)
+    n = 150
+    recs = O.gen_stream(n, seed=seed, n_keys=60, variant=1)
+    m = recs["metrics"]
+    m["if_index_first_seen"] = rng.choice(np.array([0, 1, 2, 3, 4, 7, 9, 4321], dtype=np.uint32), n)
+    m["observed_intf"] = rng.choice(np.array([0, 1, 2, 3, 4, 7, 9, 4321], dtype=np.uint32), (n, 6))
+    m["eth_protocol"][rng.integers(0, 3, n) == 0] = 0x86DD
+    m["start"][rng.integers(0, 5, n) == 0] = 0
+    contents = G.gen_contents(O, rng, recs)
+    for name in ("has_dns", "has_drops", "has_netev", "has_xlat", "has_additional", "has_quic"):
+        contents[name] = rng.integers(0, 2, n)
+    contents["dns"]["latency"] = rng.integers(0, 1 << 63, n, dtype=np.uint64) * rng.integers(0, 3, n).astype(np.uint64)
+    contents["additional"]["flow_rtt"] = rng.integers(0, 1 << 40, n, dtype=np.uint64) * rng.integers(0, 2, n).astype(np.uint64)
+    contents["additional"]["ipsec_ret"] = rng.integers(-(1 << 31), 1 << 31, n)
+    names_rows = G.NAMES
+    namer = G.namer_from(names_rows)
+    now, mono = int(rng.integers(10**9, 2 * 10**18)), int(rng.integers(0, 10**15))
+    agent = bytes(10) + b"\xff\xff" + bytes(rng.integers(0, 256, 4, dtype=np.uint8)) if seed % 2 else bytes(rng.integers(0, 256, 16, dtype=np.uint8))
+    opts = O.pb_options(now, mono, agent, O.intf_table(names_rows))
+    got_r = O.pb_encode(recs, opts)
+    got_c = O.pb_encode_contents(recs["id"], contents, opts)
+    for k in range(n):
+        want_r = G.flow_to_pb(Record, recs[k], now, mono, agent, namer).SerializeToString(deterministic=True)
+        want_c = G.flow_to_pb(Record, recs[k], now, mono, agent, namer, content=contents[k]).SerializeToString(deterministic=True)
+        assert got_r[k] == want_r, f"record {k}"
+        assert got_c[k] == want_c, f"content {k}"
