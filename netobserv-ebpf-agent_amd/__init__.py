@@ -17,5 +17,6 @@ from .accounter import (Accounter, NewAccounter, NewRecord, Record, IntfDirUdn, 
                         SetInterfaceNamer, SetGlobalIP)
 from . import synth
 from . import pipeline
-from .pipeline import (CapacityLimiter, RecordToMap, DirectFLPStdout, BpfFlowContent, GPUMapFetcher, MapTracer, NewMapTracer)
+from .pipeline import (CapacityLimiter, RecordToMap, DirectFLPStdout, BpfFlowContent, GPUMapFetcher, MapTracer, NewMapTracer,
+                       FlowsToPBMessages)
 from . import distributed

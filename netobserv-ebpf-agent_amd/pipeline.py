@@ -186,3 +186,12 @@ class MapTracer:
 
 def NewMapTracer(fetcher, evictionTimeout, staleEntriesEvictTimeout, m=None, s=None, udnEnabled=False, **kw) -> MapTracer:
     return MapTracer(fetcher, evictionTimeout, staleEntriesEvictTimeout, m, s, udnEnabled, **kw)
+
+
+def FlowsToPBMessages(buf, frame_offsets, max_len: int):
+    """pbflow.FlowsToPB(records, maxLen) (pkg/pbflow/proto.go:18-36) over the output of nfagg_encode_pb: the serialized
+    pbflow.Records messages GRPCProto.ExportFlows sends (pkg/exporter/grpc_proto.go:120), at most max_len entries each —
+    byte ranges of `buf`, no copy of the frames' contents, no per-record allocation."""
+    n = len(frame_offsets) - 1
+    raw = memoryview(np.ascontiguousarray(buf))
+    return [raw[int(frame_offsets[a]):int(frame_offsets[min(a + max_len, n)])] for a in range(0, n, max_len)]

@@ -261,3 +261,29 @@ def test_content_rollup_then_encode_device(nf, O):
         assert rc == nf.OK and wrote == need
         got = frames(d_out[:need].cpu().numpy(), d_off.cpu().numpy().astype(np.uint64), d_len.cpu().numpy().astype(np.uint32))
     assert got == want
+
+
+def test_grpc_split_large_messages(nf, O):
+    """pkg/exporter/grpc_proto_test.go:120-163 TestGRPCProto_SplitLargeMessages: 25 000 IPv6 flows, GRPC_MESSAGE_MAX_FLOWS =
+    10 000 -> three pbflow.Records messages of 10 000, 10 000 and 5 000 entries; here the messages are byte ranges of the
+    device-encoded buffer, parsed back with the protobuf runtime."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import gen_pb_golden as G
+    _, Records = G.build_classes()
+    recs = np.zeros(25000, dtype=nf.FLOW_RECORD)
+    recs["metrics"]["eth_protocol"] = 0x86DD
+    recs["id"]["src_port"] = np.arange(25000) % 60000                      # tell the entries apart
+    agent = bytes.fromhex("11110000000000000000000000001111")             # 1111::1111
+    names = nf.intf_table([(0, None, "12345678", "")])
+    with nf.FlowTable(max_entries=64) as tab:
+        buf, off, blen = tab.encode_pb(recs, 10**18, 10**9, agent, names)
+    msgs = nf.FlowsToPBMessages(buf, off, 10_000)
+    assert len(msgs) == 3
+    seen = 0
+    for m, want in zip(msgs, (10_000, 10_000, 5_000)):
+        rs = Records.FromString(bytes(m))
+        assert len(rs.entries) == want
+        assert rs.entries[0].eth_protocol == 0x86DD and rs.entries[0].agent_ip.ipv6 == agent
+        assert rs.entries[0].dup_list[0].interface == "12345678" and rs.entries[0].transport.src_port == seen % 60000
+        seen += want
