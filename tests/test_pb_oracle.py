@@ -158,3 +158,15 @@ def test_oracle_matches_protobuf_runtime_on_random_contents(O, seed):
         want_c = G.flow_to_pb(Record, recs[k], now, mono, agent, namer, content=contents[k]).SerializeToString(deterministic=True)
         assert got_r[k] == want_r, f"record {k}"
         assert got_c[k] == want_c, f"content {k}"
+
+
+def test_reference_identical_keys(O):
+    """pkg/exporter/kafka_proto_test.go:88-122 TestIdenticalKeys: A->B and B->A of one conversation get the same Kafka key."""
+    r = np.zeros(2, dtype=O.FLOW_RECORD)
+    a = np.frombuffer(bytes(10) + b"\xff\xff" + bytes([192, 1, 2, 3]), dtype=np.uint8)
+    b = np.frombuffer(bytes(10) + b"\xff\xff" + bytes([127, 3, 2, 1]), dtype=np.uint8)
+    r["id"]["src_ip"][0], r["id"]["dst_ip"][0] = a, b
+    r["id"]["src_ip"][1], r["id"]["dst_ip"][1] = b, a
+    r["id"]["src_port"], r["id"]["dst_port"], r["id"]["icmp_type"], r["id"]["proto"] = 4321, 1234, 8, 210
+    keys = O.kafka_keys(r)
+    assert keys[0].tobytes() == keys[1].tobytes() == b.tobytes() + a.tobytes()
