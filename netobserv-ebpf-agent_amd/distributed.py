@@ -35,3 +35,20 @@ def merge_sketches(cm_tensors, hll_tensors, group=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     for t in hll_tensors:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+
+
+def merge_topk(per_rank_lists, k: int) -> np.ndarray:
+    """Node-wide heavy hitters from the ranks' nfagg_cm_topk lists, taken AFTER merge_sketches (every rank's Count-Min
+    then holds the node-wide counters, so an address carries the same estimate wherever it shows up): union, one row per
+    address, estimate descending then address bytes ascending, first k. The shards partition FLOWS, not addresses — an
+    address can appear in several ranks' lists."""
+    rows = np.concatenate([np.asarray(l) for l in per_rank_lists]) if len(per_rank_lists) else np.zeros(0, dtype=[("ip", "u1", 16), ("estimate", "<u8")])
+    best = {}
+    for r in rows:
+        best[r["ip"].tobytes()] = int(r["estimate"])
+    order = sorted(best.items(), key=lambda kv: (-kv[1], kv[0]))[:k]
+    out = np.zeros(len(order), dtype=rows.dtype)
+    for i, (ip, est) in enumerate(order):
+        out[i]["ip"] = np.frombuffer(ip, dtype=np.uint8)
+        out[i]["estimate"] = est
+    return out

@@ -51,6 +51,10 @@ def _worker(rank, world, port, q):
               and np.array_equal(hll[0].numpy().astype(np.uint8), whs) and np.array_equal(hll[1].numpy().astype(np.uint8), whd))
         est = nf.hll_estimate_from_histogram(np.bincount(hll[0].numpy(), minlength=65).astype(np.uint32), 12)
         ok = ok and abs(est - O.hll_estimate(whs, 12)) <= np.spacing(est)
+        # heavy hitters: every rank's top-k over ITS evicted flows with the MERGED sketch, merged on rank 0 = the unsharded answer
+        tops = [O.cm_topk(cm[0].numpy().view(np.uint64), 4, 14, np.frombuffer(b, dtype=O.FLOW_RECORD), 0, 25) for b in gathered]
+        want_top = O.cm_topk(wcm_s, 4, 14, whole, 0, 25)
+        ok = ok and nf.distributed.merge_topk(tops, 25).tobytes() == want_top.tobytes()
         q.put(bool(ok))
     dist.barrier()
     dist.destroy_process_group()
