@@ -1,4 +1,4 @@
-"""Tiny GPU probe used while bringing the kernels up: each case in its own table, with a watchdog."""
+"""Test infrastructure (uses the oracle as checker). Tiny GPU probe used while bringing the kernels up (run from the repo root): each case in its own table, with a watchdog."""
 import faulthandler, sys, time
 faulthandler.dump_traceback_later(150, exit=True)
 sys.path.insert(0, ".")

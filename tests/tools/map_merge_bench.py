@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Throughput of the device-resident LookupAndDeleteMap join (nfagg_map_merge_device) and of the
+"""Test infrastructure (under tests/: the CPU oracle is timed beside the device path). Throughput of the device-resident LookupAndDeleteMap join (nfagg_map_merge_device) and of the
 merged-flows -> protobuf hand-off, against the CPU oracle's join on the same arrays (run on the GPU box)."""
 import os, sys, time
 import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import netobserv_ebpf_agent_amd as nf
 from oracle import oracle as O
 

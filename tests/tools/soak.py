@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Randomised soak of the ingest/evict path against the oracle (run on the GPU box): random stream shapes, batch
-splits, kernel routings, table sizes and modes; every eviction compared bit for bit. Usage: soak.py [seconds] [seed]"""
+"""Test infrastructure (lives under tests/ because it uses the oracle as its checker). Randomised soak of the ingest/evict
+path against the oracle (run on the GPU box): random stream shapes, batch
+splits, kernel routings, table sizes and modes; every eviction compared bit for bit. Usage: python tests/tools/soak.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import netobserv_ebpf_agent_amd as nf
 from oracle import oracle as O
 
