@@ -21,6 +21,8 @@ while time.time() < t_end:
     variant = int(rng.choice([1, 2] if dedup else [1, 1, 1, 0]))       # stream variant: scrambled fields (2: interfaces for dedup)
     ingest_variant = int(rng.choice([0, 0, 0, 7, 10, 11, 1])) if not dedup else int(rng.choice([0, 0, 1, 10]))
     max_entries = int(rng.choice([1 << 20, 1 << 23, max(2, keys // 3), keys + 5]))
+    if max_entries < keys:
+        n = min(n, 50_000)          # evict-on-full every few records: thousands of eviction round trips, keep the round short
     sketches = (nf.SKETCH_CM | nf.SKETCH_HLL) if (not dedup and rng.integers(0, 3) == 0) else 0
     n_shards = int(rng.choice([1, 1, 2, 8]))
     shard_id = int(rng.integers(0, n_shards))
