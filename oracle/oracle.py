@@ -307,3 +307,47 @@ def kafka_keys(records):
     for k in range(len(raw)):
         lib().orc_kafka_key(raw[k].ctypes.data_as(C.c_void_p), out[k].ctypes.data_as(C.c_void_p))
     return out
+
+
+# ---- oracle/_ref: the reference's own bpf/flows.c dedup merge compiled from /root/reference (Makefile target `ref`)
+_REF_SO = os.path.join(_HERE, "_ref", "libref_flows.so")
+_ref = None
+
+
+def ref_available(build_if_possible=True) -> bool:
+    """True when oracle/_ref/libref_flows.so exists (it is built only where /root/reference exists; the built file
+    travels to the GPU box with the snapshot)."""
+    if not os.path.exists(_REF_SO) and build_if_possible and os.path.exists("/root/reference/bpf/flows.c"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return os.path.exists(_REF_SO)
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        l = C.CDLL(_REF_SO)
+        l.ref_update_existing_flow.restype, l.ref_update_existing_flow.argtypes = None, [_vp, _vp]
+        l.ref_dedup_run.restype = _sz
+        l.ref_dedup_run.argtypes = [_vp, _sz, _u64, _vp, _sz, _vp, _sz, _vp]
+        l.ref_counter_observed_intf_missed.restype, l.ref_counter_observed_intf_missed.argtypes = _u64, []
+        l.ref_counters_reset.restype, l.ref_counters_reset.argtypes = None, []
+        _ref = l
+    return _ref
+
+
+def run_ref_dedup(records, max_entries):
+    """Same shape of result as run_accounter(records, max_entries, mode=1), computed by the REFERENCE's
+    update_existing_flow/add_observed_intf (bpf/flows.c:76-143) behind an Accounter-shaped map driver."""
+    r = np.ascontiguousarray(records)
+    n = r.nbytes // 144
+    out = np.zeros(max(n, 1), dtype=FLOW_RECORD)
+    blen = np.zeros(n + 2, dtype=np.uint64)
+    nb = C.c_size_t(0)
+    w = ref_lib().ref_dedup_run(_p(r), n, max_entries, _p(out), len(out), _p(blen), len(blen), C.byref(nb))
+    assert w != C.c_size_t(-1).value
+    res, at = [], 0
+    for k in range(nb.value):
+        m = int(blen[k])
+        res.append(("closing" if k == nb.value - 1 else "full", out[at:at + m].copy()))
+        at += m
+    return res

@@ -6,38 +6,10 @@ parity unpinned); the oracle follows the source text line by line."""
 import numpy as np
 import pytest
 
-from conftest import assert_records_equal
+from conftest import assert_records_equal, dedup_stream
 from test_parity_gpu import drive_product
 
 pytestmark = pytest.mark.gpu
-
-
-def dedup_stream(O, n, seed, n_keys, thresholds=None, hot_permille=0, style=0):
-    """Scrambled records (variant 1: if_index 1..8, direction 0/1, first-record observed
-    lists of 0..6 entries, ssl/tls fields) re-shaped per `style` to reach every branch
-    of flows.c:98-143."""
-    r = O.gen_stream(n, seed=seed, n_keys=n_keys, thresholds=thresholds, hot_permille=hot_permille, variant=1)
-    m = r["metrics"]
-    rng = np.random.default_rng(seed)
-    if style == 1:      # few interfaces, clean first records: the common shape (two interfaces, both directions)
-        m["if_index_first_seen"] = 2 + rng.integers(0, 2, n)
-        m["nb_observed_intf"] = 0
-        m["observed_intf"] = 0
-        m["observed_direction"] = 0
-    elif style == 2:    # many interfaces (capacity cut-off), zero if_index, odd direction bytes, BOTH pre-set
-        m["if_index_first_seen"] = rng.integers(0, 14, n)
-        m["direction_first_seen"] = rng.choice(np.array([0, 1, 1, 0, 2, 3, 7], dtype=np.uint8), n)
-        m["nb_observed_intf"] = rng.choice(np.array([0, 0, 1, 2, 5, 6, 7, 255], dtype=np.uint8), n)
-        m["observed_intf"] = rng.integers(0, 14, (n, 6))
-        m["observed_direction"] = rng.integers(0, 4, (n, 6))
-        m["ssl_version"] = rng.choice(np.array([0, 0, 0, 0x0303, 0x0304], dtype=np.uint16), n)
-        m["tls_types"] = rng.choice(np.array([0, 1, 2, 2, 4], dtype=np.uint8), n)
-        m["tls_cipher_suite"] = rng.choice(np.array([0, 0x1301, 0x1302, 0xc02f], dtype=np.uint16), n)
-        m["tls_key_share"] = rng.choice(np.array([0, 0x001d, 0x0017], dtype=np.uint16), n)
-    elif style == 3:    # 64-bit end values (both tagged halves matter), end going backwards
-        m["end"] = rng.integers(0, 1 << 63, n, dtype=np.uint64) * rng.integers(0, 2, n, dtype=np.uint64)
-        m["if_index_first_seen"] = rng.integers(0, 4, n)
-    return r
 
 
 def check_dedup(nf, O, records, max_entries, batch, **kw):
