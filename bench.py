@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 ALG_BYTES_INGEST = 392      # 144 read record + 144 read slot + 104 write value
 ALG_BYTES_SKETCH = 130      # CM 2 keys x 4 rows x (8+8) + HLL 2 x (1+1)
 ALG_BYTES_EVICT = 296       # per evicted flow
-DEFAULT_MAX_ENTRIES = 1 << 27   # CACHE_MAX_FLOWS of the bench table (tests/test_full_size_gpu.py uses the same)
+DEFAULT_MAX_ENTRIES = 1 << 21   # CACHE_MAX_FLOWS of the bench table: SURVEY.md §8(d) config 2 sizing (2^22 slots = 1 GiB); tests/test_full_size_gpu.py uses the same
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -100,8 +100,8 @@ def main():
                         d_pop_index=d_pop.data_ptr() if d_pop is not None else 0)
     torch.cuda.synchronize()
 
-    # CACHE_MAX_FLOWS. A batch is folded by ONE launch when live + batch <= max_entries (no record of it can
-    # trigger the evict-on-full of account.go:85), so a GPU deployment sets it generously: 2^27 flows = a 64 GiB table.
+    # CACHE_MAX_FLOWS. The 100 M-record call has live + batch > max_entries, so the library folds it optimistically
+    # (one fold, then the proof that no record found the table full: n_live <= max_entries) — DESIGN.md §2.
     max_entries = args.max_entries or DEFAULT_MAX_ENTRIES
     sk_flags = (nf.SKETCH_CM | nf.SKETCH_HLL) if args.sketches else 0
     ext = None

@@ -165,7 +165,12 @@ enum {
     /* >0: the caller must act, nothing went wrong */
     NFAGG_FULL     = 1,  /* ingest stopped before a record whose NEW key would
                             exceed max_entries (account.go:85): evict with
-                            NFAGG_REASON_FULL, then resubmit the remainder */
+                            NFAGG_REASON_FULL, then resubmit the remainder.
+                            Also returned (stats.seq_space_evictions) when an
+                            epoch reaches 2^32-16 records — sequence numbers
+                            are epoch-relative and 32 bits wide; the reference
+                            has no such limit, the flows are merely exported
+                            one eviction early */
     NFAGG_TRUNCATED = 2, /* output buffer smaller than the result */
     /* <0: errors */
     NFAGG_EINVAL   = -1,
@@ -173,7 +178,7 @@ enum {
     NFAGG_ENOMEM   = -3,
     NFAGG_EDEVICE  = -4, /* a HIP call failed; see nfagg_last_error */
     NFAGG_ESTATE   = -5, /* call not valid in the handle's current state */
-    NFAGG_ERANGE   = -6, /* per-epoch sequence space exhausted */
+    NFAGG_ERANGE   = -6, /* an argument is out of the supported range (e.g. map merge over more than 2^30 rows) */
 };
 
 /* Eviction reasons — the label values of the reference's Prometheus counters
@@ -221,7 +226,7 @@ typedef struct nfagg_config {
     uint32_t struct_size;        /* sizeof(nfagg_config); ABI guard */
     int32_t  device;             /* HIP device ordinal */
     uint64_t max_entries;        /* CACHE_MAX_FLOWS (config.go:146); 0 -> 5000 */
-    uint32_t table_log2_slots;   /* 0 -> smallest 2^k >= 2*max_entries (min 2^10) */
+    uint32_t table_log2_slots;   /* 0 -> smallest 2^k >= 2*max_entries (min 2^16) */
     uint32_t mode;               /* NFAGG_MODE_* */
     uint32_t sketch_flags;       /* NFAGG_SKETCH_* */
     uint32_t cm_depth;           /* 0 -> 4  (1..8) */
@@ -265,6 +270,9 @@ typedef struct nfagg_stats {
     uint64_t max_probe;          /* longest probe sequence seen */
     uint64_t records_bypassed;   /* records that found no entry in a pass-1 LDS flow cache (spilled to the
                                     second pass, or merged into HBM one by one by the single-pass kernel) */
+    uint64_t optimistic_folds;   /* batches with live + batch > max_entries folded whole and checked afterwards */
+    uint64_t optimistic_rollbacks; /* ... of which crossed max_entries (account.go:85) and were rolled back and split */
+    uint64_t seq_space_evictions;  /* NFAGG_FULL returned because an epoch reached 2^32-16 records (no reference counterpart) */
 } nfagg_stats;
 
 uint32_t nfagg_abi_version(void);
@@ -607,6 +615,9 @@ int nfagg_stats_reset_profile(nfagg_handle* h);
 int nfagg_sync(nfagg_handle* h);
 /* The hipStream_t the handle launches on (as void*), for event timing by the caller. */
 void* nfagg_stream(nfagg_handle* h);
+/* Testing aid: account for `records` more records in the current eviction epoch without folding any (their sequence
+ * numbers are skipped), so that the 2^32-16 records-per-epoch boundary can be reached without feeding 600 GB. */
+int nfagg_debug_skip_sequence(nfagg_handle* h, uint64_t records);
 
 #ifdef __cplusplus
 }

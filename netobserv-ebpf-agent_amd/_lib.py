@@ -86,6 +86,7 @@ class Stats(C.Structure):
         ("evict_launches", C.c_uint64), ("evict_kernel_ms", C.c_double),
         ("sketch_launches", C.c_uint64), ("sketch_kernel_ms", C.c_double), ("max_probe", C.c_uint64),
         ("records_bypassed", C.c_uint64),
+        ("optimistic_folds", C.c_uint64), ("optimistic_rollbacks", C.c_uint64), ("seq_space_evictions", C.c_uint64),
     ]
 
 
@@ -134,6 +135,7 @@ SIGNATURES = {
     "nfagg_stats_reset_profile": (C.c_int, [_vp]),
     "nfagg_sync": (C.c_int, [_vp]),
     "nfagg_stream": (_vp, [_vp]),
+    "nfagg_debug_skip_sequence": (C.c_int, [_vp, C.c_uint64]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

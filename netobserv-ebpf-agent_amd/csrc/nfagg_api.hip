@@ -80,6 +80,10 @@ struct nfagg_handle {
     std::vector<nfagg_intf_name> pb_names;   // host copy of the namer table, sorted (kept until the stream has consumed it)
     void* d_pb[15] = {};
     size_t d_pb_cap[15] = {};
+    // optimistic fold: [0] raw slot snapshot, [1] sketch snapshot, [2] first sequence numbers (+ sorted), [3] sort scratch
+    void* d_opt[4] = {};
+    size_t d_opt_cap[4] = {};
+    uint64_t opt_hint = 0;         // records per optimistic chunk suggested by the last split (0 = the whole batch)
     // spill queues of the two-pass ingest
     void* d_spill = nullptr;
     size_t d_spill_cap = 0;
@@ -191,6 +195,99 @@ int refresh_counters(nfagg_handle* h) {
     return NFAGG_OK;
 }
 
+// ---- optimistic fold -------------------------------------------------------------------------------------------
+// A batch that MIGHT reach `len(entries) >= maxEntries` at a new key (account.go:85) — live + batch > max_entries — is
+// folded whole, by the same kernels as any other batch, and checked afterwards: the sequential Accounter finds the table
+// full iff the number of distinct keys (live + new ones of the batch) exceeds max_entries, so `n_live <= max_entries`
+// after the fold proves that no record of the batch triggered the eviction, and the fold stands as it is. Otherwise
+// the fold is rolled back — the slots claimed by the batch are zeroed, the slots that were live before it are restored
+// from a raw copy taken before the fold, the sketches from theirs — and the exact split point is read off the table: every
+// slot carries its flow's first sequence number (the tag of id0), so the record whose new key finds the table full is the
+// (room+1)-th smallest first sequence number among the slots the batch claimed. The prefix before it is folded again
+// (now exactly `room` new keys: it fits), the caller gets NFAGG_FULL + consumed as the reference's eviction demands.
+// Claims are bounded by TableView.claim_limit whatever the batch holds: a batch with more new keys than the table has
+// room for is `aborted` by the kernels (some claims refused), rolled back the same way and retried with a quarter of it.
+constexpr uint64_t kCarefulMaxBatch = 16384;   // below this the claim + flag path decides (two small launches, one host round trip)
+
+int snapshot_sketches(nfagg_handle* h, bool restore) {
+    if (!h->sk.flags) return NFAGG_OK;
+    const size_t cmb = (h->sk.flags & NFAGG_SKETCH_CM) ? ((size_t)h->sk.cm_depth << h->sk.cm_log2w) * sizeof(uint64_t) : 0;
+    const size_t hlb = (h->sk.flags & NFAGG_SKETCH_HLL) ? ((size_t)1 << h->sk.hll_p) * sizeof(uint32_t) : 0;
+    int rc = ensure_bytes(h, &h->d_opt[1], &h->d_opt_cap[1], 2 * (cmb + hlb));
+    if (rc != NFAGG_OK) return rc;
+    char* snap = (char*)h->d_opt[1];
+    for (int k = 0; k < 2; k++) {
+        if (cmb) HIP_TRY(h, restore ? hipMemcpyAsync(h->sk.cm[k], snap + k * cmb, cmb, hipMemcpyDeviceToDevice, h->stream)
+                                    : hipMemcpyAsync(snap + k * cmb, h->sk.cm[k], cmb, hipMemcpyDeviceToDevice, h->stream));
+        if (hlb) HIP_TRY(h, restore ? hipMemcpyAsync(h->sk.hll[k], snap + 2 * cmb + k * hlb, hlb, hipMemcpyDeviceToDevice, h->stream)
+                                    : hipMemcpyAsync(snap + 2 * cmb + k * hlb, h->sk.hll[k], hlb, hipMemcpyDeviceToDevice, h->stream));
+    }
+    return NFAGG_OK;
+}
+
+// Fold d[0..chunk) optimistically (h->live exact on entry). On return: *folded = records folded for good,
+// *full = the record after them found the table full (account.go:85), *retry = nothing folded, try a shorter chunk.
+int fold_optimistic(nfagg_handle* h, const void* d, uint64_t chunk, uint64_t* folded, bool* full, bool* retry) {
+    const uint64_t maxe = h->cfg.max_entries, old_live = h->live, seq0 = h->epoch_seq;
+    const uint64_t room = maxe > old_live ? maxe - old_live : 0;
+    *folded = 0; *full = false; *retry = false;
+    int rc;
+    const DevCounters before = *h->h_ctr;                     // refreshed by the caller
+    if (old_live) {
+        if ((rc = ensure_bytes(h, &h->d_opt[0], &h->d_opt_cap[0], snapshot_bytes(h->tv, old_live))) != NFAGG_OK) return rc;
+        hipError_t e = launch_snapshot(h->tv, old_live, h->d_opt[0], false, h->stream);
+        if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "snapshot launch failed: %s", hipGetErrorString(e));
+    }
+    if ((rc = snapshot_sketches(h, false)) != NFAGG_OK) return rc;
+    const bool was_unclustered = h->epoch_unclustered;
+    if ((rc = launch_ingest_profiled(h, d, chunk, seq0)) != NFAGG_OK) return rc;
+    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;
+    const uint64_t n_after = h->h_ctr->n_live;
+    const bool aborted = h->h_ctr->aborted != 0;
+    h->stats.optimistic_folds++;
+    if (!aborted && n_after <= maxe) {                         // no record of the chunk found the table full
+        h->live = h->live_ub = n_after;
+        *folded = chunk;
+        return NFAGG_OK;
+    }
+    // ---- the chunk crossed max_entries: find the split (unless aborted), roll back
+    h->stats.optimistic_rollbacks++;
+    uint64_t split = 0;
+    if (!aborted) {
+        const uint64_t m = n_after - old_live;                 // slots claimed by the chunk; m > room
+        size_t temp_bytes = 0;
+        hipError_t e = launch_sort_u32(nullptr, nullptr, m, nullptr, &temp_bytes, h->stream);
+        if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "sort size query failed: %s", hipGetErrorString(e));
+        if ((rc = ensure_bytes(h, &h->d_opt[2], &h->d_opt_cap[2], 2 * m * sizeof(uint32_t))) != NFAGG_OK) return rc;
+        if ((rc = ensure_bytes(h, &h->d_opt[3], &h->d_opt_cap[3], temp_bytes + 16)) != NFAGG_OK) return rc;
+        uint32_t* seqs = (uint32_t*)h->d_opt[2];
+        e = launch_first_seqs(h->tv, old_live, n_after, seqs, h->stream);
+        if (e == hipSuccess) e = launch_sort_u32(seqs, seqs + m, m, h->d_opt[3], &temp_bytes, h->stream);
+        if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "split search failed: %s", hipGetErrorString(e));
+        uint32_t split_seq = 0;
+        HIP_TRY(h, hipMemcpyAsync(&split_seq, seqs + m + room, sizeof split_seq, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if ((uint64_t)split_seq < seq0 || (uint64_t)split_seq - seq0 >= chunk)
+            return fail(h, NFAGG_EDEVICE, "optimistic fold: split sequence %u outside the batch [%llu, %llu)", split_seq,
+                        (unsigned long long)seq0, (unsigned long long)(seq0 + chunk));
+        split = (uint64_t)split_seq - seq0;
+    }
+    hipError_t e = launch_discard(h->tv, old_live, n_after, h->stream);
+    if (e == hipSuccess && old_live) e = launch_snapshot(h->tv, old_live, h->d_opt[0], true, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "rollback launch failed: %s", hipGetErrorString(e));
+    if ((rc = snapshot_sketches(h, true)) != NFAGG_OK) return rc;
+    *h->h_ctr = before;                                        // n_live, n_reserved, the diagnostic counters: as before the chunk
+    HIP_TRY(h, hipMemcpyAsync(h->tv.ctr, h->h_ctr, sizeof(DevCounters), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));               // h_ctr is reused by the next refresh
+    h->epoch_unclustered = was_unclustered;
+    h->live_ub = old_live;
+    if (aborted) { *retry = true; return NFAGG_OK; }
+    if (split > 0 && (rc = launch_ingest_profiled(h, d, split, seq0)) != NFAGG_OK) return rc;
+    h->live = h->live_ub = maxe;                               // exactly `room` new keys in the prefix: len(entries) == maxEntries
+    *folded = split; *full = true;
+    return NFAGG_OK;
+}
+
 // The record arm of Accounter.Account (account.go:81-96) for a device-resident batch.
 int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t* consumed_out) {
     size_t consumed = 0;
@@ -198,11 +295,20 @@ int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t*
     const char* base = static_cast<const char*>(d_records);
     int rc = NFAGG_OK;
     if (h->must_evict) { if (consumed_out) *consumed_out = 0; return n ? NFAGG_FULL : NFAGG_OK; }
+    constexpr uint64_t kSeqLimit = 0xFFFFFFF0ull;   // sequence numbers are epoch-relative and 32 bits wide
     while (consumed < n) {
-        const uint64_t rem = n - consumed;
-        if (h->epoch_seq + rem >= 0xFFFFFFF0ull) {
-            rc = fail(h, NFAGG_ERANGE, "more than 2^32-16 records in one eviction epoch; evict first");
-            break;
+        uint64_t rem = n - consumed;
+        if (h->epoch_seq + rem >= kSeqLimit) {
+            // The epoch's sequence space is nearly used up (the reference has no such limit): fold what still fits, then
+            // ask for an eviction as if the table were full — flows are exported a little early, nothing is lost or refused.
+            rem = h->epoch_seq < kSeqLimit - 1 ? kSeqLimit - 1 - h->epoch_seq : 0;
+            if (rem == 0) {
+                if ((rc = refresh_counters(h)) != NFAGG_OK) break;
+                h->must_evict = true; h->split_seq = ~0ull;
+                h->stats.seq_space_evictions++;
+                rc = NFAGG_FULL;
+                break;
+            }
         }
         const void* d = base + consumed * kRecordBytes;
         if (h->live_ub + rem <= maxe) {
@@ -210,11 +316,37 @@ int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t*
             if ((rc = launch_ingest_profiled(h, d, rem, h->epoch_seq)) != NFAGG_OK) break;
             h->live_ub += rem; h->epoch_seq += rem; consumed += rem;
             h->stats.records_ingested += rem;
-            break;
+            continue;
         }
         if ((rc = refresh_counters(h)) != NFAGG_OK) break;
         const uint64_t room = maxe > h->live ? maxe - h->live : 0;
         if (room >= rem) continue;
+        if (rem > kCarefulMaxBatch) {
+            // ---- optimistic path (see fold_optimistic): the whole remainder, or what the last split suggests
+            uint64_t chunk = rem;
+            if (h->opt_hint && chunk > h->opt_hint) chunk = h->opt_hint;
+            uint64_t folded = 0; bool full = false, retry = false;
+            if ((rc = fold_optimistic(h, d, chunk, &folded, &full, &retry)) != NFAGG_OK) break;
+            if (retry) {
+                // more new keys than the table takes (claim_limit): a quarter of it next, but never less than what cannot
+                // abort at all — a chunk of claim_limit - live records claims at most that many slots
+                const uint64_t safe = h->tv.claim_limit > h->live_ub ? h->tv.claim_limit - h->live_ub : 0;
+                if (chunk <= safe) { rc = fail(h, NFAGG_EDEVICE, "optimistic fold aborted although the chunk fits the table"); break; }
+                h->opt_hint = chunk / 4 > safe ? chunk / 4 : safe;
+                continue;
+            }
+            h->epoch_seq += folded; consumed += folded;
+            h->stats.records_ingested += folded;
+            if (full) {
+                // epochs of this stream are about `folded` records long: do not fold (and throw away) far more than that next time
+                h->opt_hint = folded * 2 > (1ull << 16) ? folded * 2 : (1ull << 16);
+                h->must_evict = true; h->split_seq = h->epoch_seq;
+                rc = NFAGG_FULL;
+                break;
+            }
+            if (h->opt_hint && chunk == h->opt_hint) h->opt_hint *= 2;       // it fitted: be bolder
+            continue;
+        }
         if (room >= 65536 || (room > 0 && room >= rem / 4)) {
             // the first `room` records cannot overflow either
             if ((rc = launch_ingest_profiled(h, d, room, h->epoch_seq)) != NFAGG_OK) break;
@@ -222,7 +354,7 @@ int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t*
             h->stats.records_ingested += room;
             continue;
         }
-        // ---- careful path: the split point may lie inside this chunk
+        // ---- careful path (small batches): the split point may lie inside this chunk
         const uint64_t chunk = rem < h->careful_chunk ? rem : h->careful_chunk;
         const uint64_t seq0 = h->epoch_seq;
         h->epoch_unclustered = true;
@@ -350,6 +482,7 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
     CREATE_TRY(hipMemsetAsync(h->tv.ctr, 0, sizeof(DevCounters), h->stream));
     CREATE_TRY(hipHostMalloc((void**)&h->h_ctr, sizeof(DevCounters), hipHostMallocDefault));
     h->tv.mask = slots - 1; h->tv.n_shards = cfg.n_shards; h->tv.shard_id = cfg.shard_id;
+    h->tv.claim_limit = slots / 4 * 3 + 16;   // max_entries <= slots/2 plus a careful chunk <= slots/4 always fit
     // careful path: never let claimed slots exceed 3/4 of the table
     h->careful_chunk = slots / 4;
     if (h->careful_chunk > (1ull << 22)) h->careful_chunk = 1ull << 22;
@@ -415,6 +548,7 @@ void nfagg_destroy(nfagg_handle* h) {
     for (int k = 0; k < 3; k++) if (h->d_roll[k]) hipFree(h->d_roll[k]);
     if (h->d_hist) hipFree(h->d_hist);
     if (h->d_spill) hipFree(h->d_spill);
+    for (int k = 0; k < 4; k++) if (h->d_opt[k]) hipFree(h->d_opt[k]);
     for (int k = 0; k < 15; k++) if (h->d_pb[k]) hipFree(h->d_pb[k]);
     for (int k = 0; k < 2; k++) if (h->d_sort[k]) hipFree(h->d_sort[k]);
     for (int k = 0; k < 7; k++) if (h->d_hh[k]) hipFree(h->d_hh[k]);
@@ -970,6 +1104,13 @@ int nfagg_sync(nfagg_handle* h) {
 }
 
 void* nfagg_stream(nfagg_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int nfagg_debug_skip_sequence(nfagg_handle* h, uint64_t records) {
+    if (!h) return NFAGG_EINVAL;
+    if (h->epoch_seq + records >= 0xFFFFFFF0ull) return fail(h, NFAGG_ERANGE, "would pass the end of the epoch's sequence space");
+    h->epoch_seq += records;
+    return NFAGG_OK;
+}
 
 int nfagg_stats_get(nfagg_handle* h, nfagg_stats* out) {
     if (!h || !out) return fail(h, NFAGG_EINVAL, "null argument");

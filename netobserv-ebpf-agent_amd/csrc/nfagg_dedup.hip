@@ -177,6 +177,7 @@ hipError_t launch_ingest_dedup(const TableView& t, const void* d_records, uint64
 
 __global__ void k_reset_after_evict_dedup(DevCounters* c) {
     c->n_live = 0;
+    c->aborted = 0;
     c->max_probe = 0;
 }
 

@@ -161,15 +161,29 @@ NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t 
         SlotHot* s = &t.hot[idx];
         uint64_t tag = ald(&s->tag);
         if (tag == 0) {
+            // Claims are bounded: at most claim_limit slots are ever claimed in an epoch, however many new keys an
+            // (optimistically folded, nfagg_api.hip) batch holds. The position handed out by the n_live increment decides
+            // (a separate look at n_live before the CAS cost 2.5x in pass 2: every claimer of the chip loading the one
+            // word all of them increment): a claim beyond the limit is undone — tag back to empty, the increment taken
+            // back; positions below the limit stay dense and unique because n_live never drops below the limit once it
+            // got there. A refused claim drops this lane's contribution and raises `aborted`: the API rolls the whole
+            // batch back and folds a shorter prefix, so what the table holds meanwhile is moot.
             const uint64_t old = acas(&s->tag, (uint64_t)0, locked);
             if (old == 0) {
-#pragma unroll
-                for (int k = 0; k < 5; k++) ast(&s->key[k], w[k]);
                 const unsigned long long pos = aadd(&t.ctr->n_live, 1ull);
-                t.live_list[pos] = (uint32_t)idx;   // read by the evict kernel only (kernel boundary)
-                drain_stores();
-                ast(&s->tag, ready);
-                result = (uint32_t)idx; done = 1;
+                if (pos >= t.claim_limit) {
+                    ast(&s->tag, (uint64_t)0);
+                    aadd(&t.ctr->n_live, ~0ull);
+                    atomicExch(&t.ctr->aborted, 1u);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) ast(&s->key[k], w[k]);
+                    t.live_list[pos] = (uint32_t)idx;   // read by the evict kernel only (kernel boundary)
+                    drain_stores();
+                    ast(&s->tag, ready);
+                    result = (uint32_t)idx;
+                }
+                done = 1;
             }
             // else: somebody else claimed it; re-examine the same slot next trip
         } else if (tag == ready) {

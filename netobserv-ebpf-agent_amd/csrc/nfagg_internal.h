@@ -89,8 +89,10 @@ struct DevCounters {
     unsigned int error;            // non-zero: a kernel bailed out (probe overflow)
     unsigned int max_probe;
     unsigned long long n_direct;   // two-pass ingest: records merged one by one in pass 2 / pass 3 (no LDS entry, queue overflow)
-    unsigned long long pad1;
-    unsigned long long phase[8];   // ingest_variant 6 only: per-phase wave-cycle sums (diagnostics)
+    unsigned int aborted;          // a claim was refused because n_live reached TableView.claim_limit: the fold of this
+                                   // batch is incomplete and the API rolls it back (optimistic fold, nfagg_api.hip)
+    unsigned int pad1;
+    unsigned long long phase[8];   // diagnostic builds only: per-phase wave-cycle sums
 };
 
 // Two-pass partitioned ingest (nfagg_ingest_part.hip): per-partition queues of spilled record indices.
@@ -113,6 +115,7 @@ struct TableView {
     uint32_t* live_list;           // slot indices claimed this epoch, in claim order
     DevCounters* ctr;
     uint64_t mask;                 // slots - 1
+    uint64_t claim_limit;          // hard bound on claimed slots per epoch (3/4 of the table): claims beyond it are refused
     uint32_t n_shards, shard_id;
     SpillView spill;               // set by the API for the two-pass fold
 };
@@ -150,6 +153,15 @@ hipError_t launch_first_flags(const TableView& t, const uint32_t* d_slot_idx, ui
 // record (dense, order unspecified), zero every claimed slot, reset n_live.
 hipError_t launch_sort_slots(const uint32_t* d_in, uint32_t* d_out, uint64_t n, int end_bit, void* d_temp, size_t* temp_bytes, hipStream_t s);
 hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);
+// Optimistic fold support (nfagg_api.hip: a batch that MIGHT cross max_entries is folded whole and rolled back if it did).
+// Raw copies of the claimed slots live_list[0..n) (hot, cold and — dedup mode — aux lines) into / out of a scratch area laid
+// out as [n hot lines][n cold lines][n aux pairs]; zeroing of the slots live_list[from..to); the first sequence number of
+// the slots live_list[from..to) (what the split point is selected from); counters rewritten after a rollback.
+size_t snapshot_bytes(const TableView& t, uint64_t n);
+hipError_t launch_snapshot(const TableView& t, uint64_t n, void* d_snap, bool restore, hipStream_t s);
+hipError_t launch_discard(const TableView& t, uint64_t from, uint64_t to, hipStream_t s);
+hipError_t launch_first_seqs(const TableView& t, uint64_t from, uint64_t to, uint32_t* d_out, hipStream_t s);
+hipError_t launch_sort_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, void* d_temp, size_t* temp_bytes, hipStream_t s);
 // Sketch update over a batch (nfagg_sketch.hip).
 hipError_t launch_sketch_update(const SketchView& sk, const TableView& t, const void* d_records, uint64_t n, hipStream_t s);
 hipError_t launch_cm_estimate(const uint64_t* d_cm, uint32_t depth, uint32_t log2w, int side, const void* d_records, uint64_t n,

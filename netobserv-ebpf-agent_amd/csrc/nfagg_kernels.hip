@@ -128,7 +128,47 @@ __global__ __launch_bounds__(256) void k_evict(TableView t, uint64_t n_live, uin
 
 __global__ void k_reset_after_evict(DevCounters* c) {
     c->n_live = 0;
+    c->aborted = 0;
     c->max_probe = 0;
+}
+
+// ------------------------------------------------------------------
+// Optimistic fold (nfagg_api.hip): raw slot copies, discard, first sequence numbers.
+// One 16-byte chunk per lane: consecutive lanes copy consecutive chunks of one slot's lines.
+// ------------------------------------------------------------------
+template <bool RESTORE>
+__global__ __launch_bounds__(256) void k_snapshot(TableView t, uint64_t n, uint4* __restrict__ snap) {
+    const int per = t.aux ? 32 : 16;                       // 16-byte chunks per slot: hot 8 + cold 8 (+ aux 16)
+    const uint64_t total = n * (uint64_t)per, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint64_t i = g / per; const int c = (int)(g % per);
+        const uint32_t idx = t.live_list[i];
+        uint4* p; uint4* q;
+        if (c < 8) { p = reinterpret_cast<uint4*>(&t.hot[idx]) + c; q = snap + i * 8 + c; }
+        else if (c < 16) { p = reinterpret_cast<uint4*>(&t.cold[idx]) + (c - 8); q = snap + n * 8 + i * 8 + (c - 8); }
+        else { p = reinterpret_cast<uint4*>(&t.aux[idx]) + (c - 16); q = snap + n * 16 + i * 16 + (c - 16); }
+        if (RESTORE) *p = *q; else *q = *p;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_discard(TableView t, uint64_t from, uint64_t to) {
+    const int per = t.aux ? 32 : 16;
+    const uint64_t total = (to - from) * (uint64_t)per, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint64_t i = from + g / per; const int c = (int)(g % per);
+        const uint32_t idx = t.live_list[i];
+        uint4* p = c < 8 ? reinterpret_cast<uint4*>(&t.hot[idx]) + c
+                 : c < 16 ? reinterpret_cast<uint4*>(&t.cold[idx]) + (c - 8) : reinterpret_cast<uint4*>(&t.aux[idx]) + (c - 16);
+        *p = make_uint4(0, 0, 0, 0);
+    }
+}
+
+// out[i - from] = epoch-relative sequence number of the first record of the flow in slot live_list[i]
+// (the tag of id0, resolved by every fold kernel in both modes).
+__global__ __launch_bounds__(256) void k_first_seqs(TableView t, uint64_t from, uint64_t to, uint32_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < to; i += stride)
+        out[i - from] = ~(uint32_t)(t.hot[t.live_list[i]].id0 >> 32);
 }
 
 static inline int grid_for(uint64_t n, int block, int max_blocks) {
@@ -201,6 +241,35 @@ hipError_t launch_first_flags(const TableView& t, const uint32_t* d_slot_idx, ui
 // lanes walk the table front to back. temp == nullptr: size query.
 hipError_t launch_sort_slots(const uint32_t* d_in, uint32_t* d_out, uint64_t n, int end_bit, void* d_temp, size_t* temp_bytes, hipStream_t s) {
     return hipcub::DeviceRadixSort::SortKeys(d_temp, *temp_bytes, d_in, d_out, (int)n, 0, end_bit, s);
+}
+
+size_t snapshot_bytes(const TableView& t, uint64_t n) { return (size_t)n * (t.aux ? 512 : 256); }
+
+hipError_t launch_snapshot(const TableView& t, uint64_t n, void* d_snap, bool restore, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const int grid = grid_for(n * (t.aux ? 32 : 16), 256, 256 * 16);
+    (void)hipGetLastError();
+    if (restore) hipLaunchKernelGGL(k_snapshot<true>, dim3(grid), dim3(256), 0, s, t, n, (uint4*)d_snap);
+    else hipLaunchKernelGGL(k_snapshot<false>, dim3(grid), dim3(256), 0, s, t, n, (uint4*)d_snap);
+    return hipGetLastError();
+}
+
+hipError_t launch_discard(const TableView& t, uint64_t from, uint64_t to, hipStream_t s) {
+    if (to <= from) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_discard, dim3(grid_for((to - from) * (t.aux ? 32 : 16), 256, 256 * 16)), dim3(256), 0, s, t, from, to);
+    return hipGetLastError();
+}
+
+hipError_t launch_first_seqs(const TableView& t, uint64_t from, uint64_t to, uint32_t* d_out, hipStream_t s) {
+    if (to <= from) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_first_seqs, dim3(grid_for(to - from, 256, 256 * 8)), dim3(256), 0, s, t, from, to, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sort_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, void* d_temp, size_t* temp_bytes, hipStream_t s) {
+    return hipcub::DeviceRadixSort::SortKeys(d_temp, *temp_bytes, d_in, d_out, (int)n, 0, 32, s);
 }
 
 hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s) {

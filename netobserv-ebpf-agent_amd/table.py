@@ -330,6 +330,9 @@ class FlowTable:
     def sync(self):
         self._check(L.lib.nfagg_sync(self._h))
 
+    def debug_skip_sequence(self, records: int):
+        self._check(L.lib.nfagg_debug_skip_sequence(self._h, records))
+
     @property
     def stream(self) -> int:
         return L.lib.nfagg_stream(self._h) or 0

@@ -1,0 +1,104 @@
+"""The optimistic fold (csrc/nfagg_api.hip: fold_optimistic): a batch with live + batch > max_entries is folded whole and
+checked afterwards; a batch that did cross max_entries (account.go:85-94) is rolled back and split at the exact record.
+Everything against the oracle's sequential Accounter: same eviction sequence, every evicted record bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import assert_records_equal, dedup_stream
+from test_parity_gpu import check_against_oracle, drive_product
+from test_dedup_gpu import check_dedup
+
+pytestmark = pytest.mark.gpu
+
+
+def _zipf(O, n, keys, seed, **kw):
+    return O.gen_stream(n, seed=seed, n_keys=keys, thresholds=O.zipf_thresholds(keys, 1.1), variant=1, **kw)
+
+
+@pytest.mark.parametrize("max_entries,batch", [(30_000, 1 << 30), (30_000, 700_001), (5_000, 1 << 30), (40_000, 250_000)])
+def test_large_batches_split_exactly(nf, O, max_entries, batch):
+    """2 M records over 100 k flows with a table for fewer: several evictions on full inside every call."""
+    recs = _zipf(O, 2_000_000, 100_000, seed=21)
+    with nf.FlowTable(max_entries=max_entries) as tab:
+        got = drive_product(tab, recs.view(nf.FLOW_RECORD), batch)
+        st = tab.stats()
+    want = O.run_accounter(recs, max_entries)
+    assert [r for r, _ in got] == [r for r, _ in want]
+    assert sum(1 for r, _ in want if r == "full") >= 3
+    for k, ((_, g), (_, w)) in enumerate(zip(got, want)):
+        assert_records_equal(g, w, f"eviction #{k}")
+    assert st.optimistic_rollbacks >= 3 and st.optimistic_folds >= st.optimistic_rollbacks
+
+
+def test_no_overflow_is_one_fold(nf, O):
+    """live + batch > max_entries but the distinct keys fit: one optimistic fold, no rollback, table as the oracle's."""
+    recs = _zipf(O, 4_000_000, 50_000, seed=22)
+    with nf.FlowTable(max_entries=60_000, profile=True) as tab:
+        assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
+        st = tab.stats()
+        assert (st.optimistic_folds, st.optimistic_rollbacks) == (st.ingest_launches, 0)
+        got = nf.sort_by_key(tab.evict(nf.REASON_CLOSING))
+    assert_records_equal(got, O.run_accounter(recs, 60_000)[0][1])
+
+
+def test_rollback_restores_the_flows_that_were_live(nf, O):
+    """Epoch state before the overflowing batch (every order-dependent field, sequence tags) must survive the rollback."""
+    a = _zipf(O, 300_000, 20_000, seed=23)
+    b = _zipf(O, 900_000, 200_000, seed=24)
+    recs = np.concatenate([a, b])
+    for me in (25_000, 60_000):
+        want = O.run_accounter(recs, me)
+        with nf.FlowTable(max_entries=me, sketches=nf.SKETCH_CM | nf.SKETCH_HLL, cm_log2_width=14, hll_p=10) as tab:
+            assert tab.ingest(a.view(nf.FLOW_RECORD)) == (nf.OK, len(a))
+            got = drive_product(tab, b.view(nf.FLOW_RECORD), 1 << 30)
+            assert tab.stats().optimistic_rollbacks >= 1
+            cm = tab.sketch_snapshot(nf.CM_SRC)
+            hll = tab.sketch_snapshot(nf.HLL_DST)
+        assert [r for r, _ in got] == [r for r, _ in want]
+        for k, ((_, g), (_, w)) in enumerate(zip(got, want)):
+            assert_records_equal(g, w, f"max_entries {me}, eviction #{k}")
+        cs, _, _, hd = O.sketches(recs, 4, 14, 10)          # every record counted exactly once, rolled-back folds not at all
+        assert np.array_equal(cm, cs) and np.array_equal(hll, hd)
+
+
+def test_more_new_keys_than_the_table_has_slots(nf, O):
+    """max_entries 100 -> a 65 536-slot table; 400 k distinct keys in one call: the kernels refuse claims beyond the
+    claim limit (aborted), the batch is rolled back and retried shorter until the split is found."""
+    n = 400_000
+    recs = O.gen_stream(n, seed=25, n_keys=n, variant=1)
+    recs["id"]["src_port"] = np.arange(n) & 0xffff
+    recs["id"]["dst_port"] = np.arange(n) >> 16          # all keys distinct
+    with nf.FlowTable(max_entries=100) as tab:
+        rc, c = tab.ingest(recs.view(nf.FLOW_RECORD))
+        assert (rc, c) == (nf.FULL, 100)
+        ev = tab.evict(nf.REASON_FULL)
+        assert len(ev) == 100
+        assert_records_equal(nf.sort_by_key(ev), O.run_accounter(recs[:100], 1000)[0][1])
+        assert tab.stats().optimistic_rollbacks >= 2
+        rc, c = tab.ingest(recs[100:].view(nf.FLOW_RECORD))
+        assert (rc, c) == (nf.FULL, 100)
+
+
+@pytest.mark.parametrize("style", [1, 2])
+def test_dedup_mode_large_batches_split_exactly(nf, O, style):
+    th = O.zipf_thresholds(60_000, 1.1)
+    recs = dedup_stream(O, 1_000_000, seed=26 + style, n_keys=60_000, thresholds=th, style=style)
+    want = check_dedup(nf, O, recs, 20_000, 1 << 30)
+    assert sum(1 for r, _ in want if r == "full") >= 2
+
+
+def test_epoch_sequence_space_ends_in_an_eviction_not_an_error(nf, O):
+    """2^32-16 records in one epoch used to fail the call with NFAGG_ERANGE. Now the records that still fit
+    are folded (their sequence numbers are the largest the kernels ever see) and NFAGG_FULL asks for an eviction."""
+    recs = _zipf(O, 50_000, 500, seed=27)
+    with nf.FlowTable(max_entries=1 << 16) as tab:
+        assert tab.ingest(recs[:10_000].view(nf.FLOW_RECORD)) == (nf.OK, 10_000)
+        tab.debug_skip_sequence(0xFFFFFFF0 - 10_000 - 1 - 25_000)          # 25 000 sequence numbers left
+        rc, c = tab.ingest(recs[10_000:].view(nf.FLOW_RECORD))
+        assert (rc, c) == (nf.FULL, 25_000)
+        assert tab.ingest(recs[35_000:].view(nf.FLOW_RECORD)) == (nf.FULL, 0)
+        got = nf.sort_by_key(tab.evict(nf.REASON_FULL))
+        assert_records_equal(got, O.run_accounter(recs[:35_000], 1 << 16)[0][1])
+        assert tab.stats().seq_space_evictions == 1
+        assert tab.ingest(recs[35_000:].view(nf.FLOW_RECORD)) == (nf.OK, 15_000)
+        assert_records_equal(nf.sort_by_key(tab.evict()), O.run_accounter(recs[35_000:], 1 << 16)[0][1])
