@@ -150,10 +150,16 @@ class Accounter:
     def Account(self, inp: "queue.Queue", out: "queue.Queue"):
         next_tick = time.monotonic() + self.evictTimeout
         while True:
-            timeout = max(0.0, next_tick - time.monotonic())
-            try:
-                item = inp.get(timeout=timeout)
-            except queue.Empty:                            # case <-evictTick.C (:63-71)
+            # Go's select serves evictTick.C as soon as it is ready, whether or not `in` has records waiting (:61-71);
+            # Queue.get(timeout=0) would keep returning queued items, so a due tick is served before the next item.
+            timeout = next_tick - time.monotonic()
+            item = None
+            if timeout > 0:
+                try:
+                    item = inp.get(timeout=timeout)
+                except queue.Empty:
+                    pass
+            if item is None:                               # case <-evictTick.C (:63-71)
                 next_tick = time.monotonic() + self.evictTimeout
                 if len(self.table) == 0:
                     continue

@@ -169,8 +169,8 @@ class FlowTable:
         out = L.MergedFlows(recs.ctypes.data, present.ctypes.data, *[parts[name].ctypes.data for name in self._KIND_ORDER])
         n_out, n_dup = C.c_size_t(0), C.c_size_t(0)
         rc = L.lib.nfagg_map_merge(self._h, C.byref(main), views, n_cpu, C.byref(out), cap, C.byref(n_out), C.byref(n_dup))
-        if rc == L.TRUNCATED:
-            return rc, n_out.value
+        if rc == L.TRUNCATED:                      # caller's cap too small: retry with the size the library reported (as evict does)
+            return self.map_merge(main_ids, main_vals, feats, n_cpu, cap=n_out.value)
         self._check(rc)
         n = n_out.value
         return recs[:n], present[:n], {k: v[:n] for k, v in parts.items()}, n_dup.value

@@ -113,6 +113,33 @@ def test_evict_period(nf):
     acc.close()
 
 
+def test_timeout_eviction_fires_under_sustained_load(nf):
+    """account.go:61-71: the ticker arm of the select is served although `in` never runs dry (the host mirror
+    used to starve it). Records keep arriving for ~5 evict periods; 'timeout' evictions must happen meanwhile."""
+    acc = nf.NewAccounter(1000, 0.25, lambda: 0, lambda: 1000, nf.NoOp())
+    len(acc.table)
+    inputs, evictor = queue.Queue(), queue.Queue()
+    th = threading.Thread(target=acc.Account, args=(inputs, evictor), daemon=True)
+    th.start()
+    R = nf.FLOW_RECORD
+    t_end = time.monotonic() + 1.3
+    fed = 0
+    while time.monotonic() < t_end:
+        while inputs.qsize() < 50:                           # the queue is never empty
+            inputs.put(mk(R, K1, PN, bytes=1, packets=1, start=1 + fed, end=1 + fed, flags=1))
+            fed += 1
+        time.sleep(0.001)
+    during = acc.metrics.evictions_total.get(("accounter", "timeout"), 0)
+    inputs.put(nf.CLOSE)
+    th.join(timeout=20)
+    assert during >= 3, f"{during} timeout evictions in 5 periods of sustained load"
+    total = 0
+    while not evictor.empty():
+        total += sum(int(r.Metrics["packets"]) for r in evictor.get())
+    assert total == fed                                      # nothing lost across the evictions
+    acc.close()
+
+
 # ---------------------------------------------------------------- seeded streams vs the oracle
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3, 4, 5, 7, 10, 11])
