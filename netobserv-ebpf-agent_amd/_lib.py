@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnfagg.so")
+# NFAGG_LIB: tools/phase_timing.py points this at lib/libnfagg_diag.so (the -DNFAGG_DIAG build with the phase-timing kernels)
+LIB_PATH = os.environ.get("NFAGG_LIB") or os.path.join(_HERE, "lib", "libnfagg.so")
 SYNTH_PATH = os.path.join(_HERE, "lib", "libnfagg_synth.so")
 
 if not os.path.exists(LIB_PATH):

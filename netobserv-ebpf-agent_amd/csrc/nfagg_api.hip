@@ -438,6 +438,8 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
     if (cfg.max_entries == 0) cfg.max_entries = 5000;   // CACHE_MAX_FLOWS default (pkg/config/config.go:146)
     if (cfg.mode != NFAGG_MODE_ACCOUNTER && cfg.mode != NFAGG_MODE_KERNEL_DEDUP)
         return fail(nullptr, NFAGG_EINVAL, "unknown mode %u", cfg.mode);
+    if (!ingest_variant_supported((int)cfg.ingest_variant))
+        return fail(nullptr, NFAGG_EINVAL, "ingest_variant %u is not part of this build (phase-timing builds live in libnfagg_diag.so)", cfg.ingest_variant);
     if (cfg.cm_depth == 0) cfg.cm_depth = 4;
     if (cfg.cm_log2_width == 0) cfg.cm_log2_width = 20;
     if (cfg.hll_p == 0) cfg.hll_p = 14;
@@ -519,8 +521,6 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
         int bits = 0;
         while ((1ull << bits) < slots) bits++;
         h->tv.spill.part_shift = (uint32_t)(bits - 11);
-        const char* ev = getenv("NFAGG_PART_HASHBITS");           // A/B: the previous choice, hash bits 29..39
-        if (ev && ev[0] == '1') h->tv.spill.part_shift = 29;
     }
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
@@ -695,7 +695,6 @@ static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device
     // partition (partition = top bits of the slot index), the live list is clustered already and the sort does not pay
     // (0.27 ms unsorted against 0.40 ms sorted per 1 M flows of a 64 GiB table; 0.49 ms before either).
     bool sort_slots = claimed >= (1u << 16) && h->slots >= (1ull << 24) && claimed < (1ull << 31) && h->epoch_unclustered;
-    { const char* ev = getenv("NFAGG_EVICT_SORT"); if (ev) sort_slots = sort_slots && ev[0] != '0'; }   // A/B
     size_t temp_bytes = 0;
     if (sort_slots) {
         int bits = 0;
@@ -1248,7 +1247,8 @@ int nfagg_encode_pb_content(nfagg_handle* h, const void* records, size_t n, cons
     return encode_pb_host_core(h, records, n, features, opt, out, out_cap, frame_offsets, body_len, kafka_keys, out_bytes);
 }
 
-// Diagnostics (not part of the drop-in ABI): per-phase wave-cycle sums of ingest_variant 6.
+#ifdef NFAGG_DIAG
+// libnfagg_diag.so only (not part of the drop-in ABI): per-phase wave-cycle sums of the phase-timing builds (variants 6/8/9).
 int nfagg_debug_phase_cycles(nfagg_handle* h, uint64_t out[8]) {
     if (!h || !out) return NFAGG_EINVAL;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1257,6 +1257,7 @@ int nfagg_debug_phase_cycles(nfagg_handle* h, uint64_t out[8]) {
     for (int k = 0; k < 8; k++) out[k] = h->h_ctr->phase[k];
     return NFAGG_OK;
 }
+#endif
 
 int nfagg_stats_reset_profile(nfagg_handle* h) {
     if (!h) return NFAGG_EINVAL;

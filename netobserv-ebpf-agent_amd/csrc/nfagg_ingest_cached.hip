@@ -246,7 +246,9 @@ hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const 
                          : run_cached<256, 256, false>(t, sk, d_records, n, seq_base, 4, s);
         case 5: return f ? run_cached<1024, 512, true>(t, sk, d_records, n, seq_base, 2, s)
                          : run_cached<1024, 512, false>(t, sk, d_records, n, seq_base, 2, s);
+#ifdef NFAGG_DIAG
         case 6: return run_cached<1024, 1024, false, true>(t, sk, d_records, n, seq_base, 1, s);    // diagnostics: phase timing
+#endif
         default: return f ? run_cached<1024, 1024, true>(t, sk, d_records, n, seq_base, 1, s)    // 7 (and 0 for small batches): 1 WG/CU x 120 KB
                           : run_cached<1024, 1024, false>(t, sk, d_records, n, seq_base, 1, s);
     }

@@ -433,8 +433,10 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
 hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                               uint64_t seq_base, int variant, hipStream_t s) {
     if (!q.queue || !q.qtail || !q.ovf || !q.ovf_tail || q.qcap < 4 || (q.qcap & 3u)) return hipErrorInvalidValue;
+#ifdef NFAGG_DIAG
     if (variant == 8) return part::run<false, true, false>(t, sk, q, d_records, n, seq_base, s);   // diagnostics: pass-1 phase timing
     if (variant == 9) return part::run<false, false, true>(t, sk, q, d_records, n, seq_base, s);   // diagnostics: pass-2 phase timing
+#endif
     if (variant == 11)   // A/B: pass 1 without the admission filter (first come, first served)
         return sk.flags ? part::run<true, false, false, false>(t, sk, q, d_records, n, seq_base, s)
                         : part::run<false, false, false, false>(t, sk, q, d_records, n, seq_base, s);

@@ -134,6 +134,7 @@ struct SketchView {
 hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                          int mode, int variant, hipStream_t s);
 bool ingest_fuses_sketches(int mode, int variant, uint64_t n, uint32_t sketch_flags);
+bool ingest_variant_supported(int variant);
 bool ingest_needs_spill(int mode, int variant, uint64_t n);
 hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                               uint64_t seq_base, int variant, hipStream_t s);

@@ -178,8 +178,6 @@ static inline int grid_for(uint64_t n, int block, int max_blocks) {
     return (int)g;
 }
 
-hipError_t launch_ingest_lds(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,
-                             int variant, hipStream_t s);  // nfagg_ingest_lds.hip
 hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                                 int variant, hipStream_t s);  // nfagg_ingest_cached.hip
 
@@ -193,13 +191,21 @@ constexpr uint64_t kDirectMaxBatch = 6144;
 constexpr uint64_t kPartMinBatch = 3u << 20;
 constexpr uint64_t kDedupCachedMinBatch = 1u << 16;
 static bool takes_two_pass(int variant, uint64_t n) { return (variant >= 8 && variant <= 11) || (variant == 0 && n >= kPartMinBatch); }
+// Shipping variants: 0 (by batch size), 1 direct, 3/4/5/7 geometries of the single-pass cached kernel, 10/11 two-pass
+// (with / without the admission filter). 6/8/9 are the phase-timing builds and exist only in libnfagg_diag.so (-DNFAGG_DIAG).
+bool ingest_variant_supported(int variant) {
+#ifdef NFAGG_DIAG
+    if (variant == 6 || variant == 8 || variant == 9) return true;
+#endif
+    return variant == 0 || variant == 1 || variant == 3 || variant == 4 || variant == 5 || variant == 7 || variant == 10 || variant == 11;
+}
 static bool takes_direct(int variant, uint64_t n, uint32_t sketch_flags) {
     return variant == 1 || (variant == 0 && n < kDirectMaxBatch && sketch_flags == 0);   // with sketches on, the cached kernel fuses them: one launch
 }
 static bool dedup_takes_cached(int variant, uint64_t n) { return !(variant == 1 || (variant != 10 && n < kDedupCachedMinBatch)); }
 bool ingest_needs_spill(int mode, int variant, uint64_t n) { return mode == 0 ? takes_two_pass(variant, n) : dedup_takes_cached(variant, n); }
 bool ingest_fuses_sketches(int mode, int variant, uint64_t n, uint32_t sketch_flags) {
-    return mode == 0 && !takes_direct(variant, n, sketch_flags) && variant != 2 && variant != 6 && variant != 8 && variant != 9;
+    return mode == 0 && !takes_direct(variant, n, sketch_flags) && variant != 6 && variant != 8 && variant != 9;
 }
 
 hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
@@ -211,10 +217,9 @@ hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d
     }
     // 0 (default): by batch size (see kDirectMaxBatch / kPartMinBatch above) — direct kernel, single-pass cached kernel
     // (what variant 7 always runs), two-pass partitioned fold (nfagg_ingest_part.hip; 8/9 = its phase-timing builds).
-    // 3..5: other geometries of the cached kernel, 6: its phase-timing build; 1: direct always; 2: per-tile LDS fold.
+    // 3..5: other geometries of the cached kernel, 6: its phase-timing build (diag library only); 1: direct always.
     if (takes_two_pass(variant, n))   // 10: two-pass whatever the size; 11: same without the admission filter
         return launch_ingest_part(t, sk, t.spill, d_records, n, seq_base, variant, s);
-    if (variant == 2) return launch_ingest_lds(t, d_records, n, seq_base, variant, s);
     if (!takes_direct(variant, n, sk.flags)) return launch_ingest_cached(t, sk, d_records, n, seq_base, variant, s);
     (void)hipGetLastError(); hipLaunchKernelGGL(k_ingest_direct, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, t, d_records, n, seq_base);
     return hipGetLastError();

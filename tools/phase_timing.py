@@ -8,7 +8,9 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("NFAGG_LIB", os.path.join(ROOT, "netobserv-ebpf-agent_amd", "lib", "libnfagg_diag.so"))   # phase-timing builds
 import netobserv_ebpf_agent_amd as nf
 from netobserv_ebpf_agent_amd import synth
 
@@ -22,7 +24,7 @@ torch.cuda.synchronize()
 synth.stream_device(d.data_ptr(), n, seed=2, n_keys=flows, d_thresholds=d_th.data_ptr())
 torch.cuda.synchronize()
 out = torch.empty(flows * 144 + 16, dtype=torch.uint8, device="cuda")
-tab = nf.FlowTable(max_entries=1 << 27, profile=True, ingest_variant=variant)
+tab = nf.FlowTable(max_entries=1 << 21, profile=True, ingest_variant=variant)
 for it in range(3):
     tab.ingest_device(d.data_ptr(), n)
     tab.evict_device(out.data_ptr(), flows)
