@@ -170,6 +170,8 @@ int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t 
     }
     if (prof) { if (h->ev_pending.size() >= 8192) prof_resolve(h); prof_begin(h, ep, 0); }
     hipError_t e = launch_ingest(h->tv, h->sk, d, n, seq_base, (int)h->cfg.mode, (int)h->cfg.ingest_variant, h->stream);
+    // identity dwords of the flows this batch created, from the batch (the caller owns it until the call returns)
+    if (e == hipSuccess) e = launch_finalize(h->tv, d, n, seq_base, h->stream);
     if (prof) prof_end(h, ep);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "ingest launch failed: %s", hipGetErrorString(e));
     if (h->sk.flags && !ingest_fuses_sketches((int)h->cfg.mode, (int)h->cfg.ingest_variant, n, h->sk.flags)) {
@@ -485,6 +487,7 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
     CREATE_TRY(hipHostMalloc((void**)&h->h_ctr, sizeof(DevCounters), hipHostMallocDefault));
     h->tv.mask = slots - 1; h->tv.n_shards = cfg.n_shards; h->tv.shard_id = cfg.shard_id;
     h->tv.claim_limit = slots / 4 * 3 + 16;   // max_entries <= slots/2 plus a careful chunk <= slots/4 always fit
+    h->tv.epoch_bits = 1ull << 48;            // eviction epoch 1; 0 is "never used"
     // careful path: never let claimed slots exceed 3/4 of the table
     h->careful_chunk = slots / 4;
     if (h->careful_chunk > (1ull << 22)) h->careful_chunk = 1ull << 22;
@@ -725,6 +728,14 @@ static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device
     h->stats.evicted_flows[reason] += legit;
     h->epoch_seq = 0; h->live = 0; h->live_ub = 0; h->must_evict = false; h->split_seq = 0;
     h->epoch_unclustered = false;
+    // The table itself was not touched: the slots of the evicted flows simply belong to a past epoch now.
+    // Tags hold 16 bits of epoch; when they wrap (every 65 535 evictions) the tags are cleared once.
+    uint64_t next_epoch = (h->tv.epoch_bits >> 48) + 1;
+    if (next_epoch > 0xFFFFull) {
+        HIP_TRY(h, hipMemsetAsync(h->tv.hot, 0, h->slots * sizeof(SlotHot), h->stream));
+        next_epoch = 1;
+    }
+    h->tv.epoch_bits = next_epoch << 48;
     return NFAGG_OK;
 }
 

@@ -150,7 +150,8 @@ NF_DEV void dedup_merge(const TableView& t, uint32_t idx, const Hints& x, const 
     if (fl & ~x.flags) aor(&H->flags, fl);
 }
 
-// The first record of the flow in this epoch is stored whole (account.go:95).
+// The first record of the flow in this epoch is stored whole (account.go:95): start, eth_protocol and the MACs here
+// (plain values: only this record ever writes them in dedup mode), the identity dwords by k_finalize.
 NF_DEV void dedup_publish_first(const TableView& t, uint32_t idx, const Rec& r, uint32_t seq32) {
     SlotHot* H = &t.hot[idx];
     SlotCold* C = &t.cold[idx];
@@ -161,8 +162,6 @@ NF_DEV void dedup_publish_first(const TableView& t, uint32_t idx, const Rec& r, 
     ast(&C->smac_hi, tagged(inv, (uint32_t)(r.smac() >> 32)));
     ast(&H->dmac_lo, tagged(inv, (uint32_t)r.dmac()));
     ast(&C->dmac_hi, tagged(inv, (uint32_t)(r.dmac() >> 32)));
-#pragma unroll
-    for (int k = 1; k < 15; k++) ast(&C->id[k - 1], tagged(inv, r.d[21 + k]));
 }
 
 // ---- the two passes for ONE record, straight on the table (direct kernels; cache misses)

@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256) void k_evict_dedup(TableView t, uint64_t n_liv
             d[19] = (uint32_t)((smac >> 32) & 0xffffu) | (uint32_t)((dmac & 0xffffu) << 16);
             d[20] = (uint32_t)(dmac >> 16);
             d[21] = (uint32_t)hv.id0;
+            d[22] = cv.id[0];
 #pragma unroll
-            for (int k = 0; k < 14; k++) d[22 + k] = (uint32_t)cv.id[k];
+            for (int k = 1; k < 12; k++) d[23 + k] = cv.id[k];
+            d[35] = 0;
             d[23] = (uint32_t)hv.samp_tag;
             d[24] = (d[24] & 0xff00ffffu) | ((uint32_t)(hv.dscp_tag & 0xffu) << 16);
             // tls / ssl (flows.c:112-125)
@@ -146,13 +148,7 @@ __global__ __launch_bounds__(256) void k_evict_dedup(TableView t, uint64_t n_liv
 #pragma unroll
             for (int k = 0; k < 9; k++) o[k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
         }
-        uint4* hz = reinterpret_cast<uint4*>(H);
-        uint4* cz = reinterpret_cast<uint4*>(C);
-        uint4* az = reinterpret_cast<uint4*>(A);
-#pragma unroll
-        for (int k = 0; k < 8; k++) { hz[k] = make_uint4(0, 0, 0, 0); cz[k] = make_uint4(0, 0, 0, 0); }
-#pragma unroll
-        for (int k = 0; k < 16; k++) az[k] = make_uint4(0, 0, 0, 0);
+        // the table is left as it is: the API bumps the epoch, stale slots are re-initialised by whoever claims them
     }
 }
 
@@ -177,6 +173,7 @@ hipError_t launch_ingest_dedup(const TableView& t, const void* d_records, uint64
 
 __global__ void k_reset_after_evict_dedup(DevCounters* c) {
     c->n_live = 0;
+    c->n_finalized = 0;
     c->aborted = 0;
     c->max_probe = 0;
 }

@@ -90,8 +90,11 @@ NF_DEV void load_record(const void* base, uint64_t i, Rec& r) {
     }
 }
 
-NF_DEV uint64_t tag_ready(uint64_t h) { return ((h >> 2) << 2) | 3ull; }
-NF_DEV uint64_t tag_locked(uint64_t h) { return ((h >> 2) << 2) | 2ull; }
+// tag = epoch (16 bits) | fingerprint = top 46 bits of the key hash | state
+constexpr uint64_t kEpochMask = 0xFFFFull << 48;
+NF_DEV uint64_t tag_ready(const TableView& t, uint64_t h) { return t.epoch_bits | ((h >> 18) << 2) | 3ull; }
+NF_DEV uint64_t tag_locked(const TableView& t, uint64_t h) { return t.epoch_bits | ((h >> 18) << 2) | 2ull; }
+NF_DEV bool tag_is_free(const TableView& t, uint64_t tag) { return (tag & kEpochMask) != t.epoch_bits; }
 
 // Possibly stale copies of the slot's monotone words, read with plain 16-byte
 // loads. Every one of these words only ever grows (max / OR) within an epoch and
@@ -122,7 +125,7 @@ NF_DEV uint32_t probe_home(const TableView& t, const uint64_t w[5], uint64_t h, 
     const uint64_t idx = h & t.mask;
     const uint4* L = reinterpret_cast<const uint4*>(&t.hot[idx]);
     const uint4 a = L[0], b = L[1], c = L[2], l3 = L[3], l4 = L[4], l6 = L[6], l7 = L[7];
-    const bool eq = (((uint64_t)a.x | ((uint64_t)a.y << 32)) == tag_ready(h)) &
+    const bool eq = (((uint64_t)a.x | ((uint64_t)a.y << 32)) == tag_ready(t, h)) &
                     (((uint64_t)a.z | ((uint64_t)a.w << 32)) == w[0]) &
                     (((uint64_t)b.x | ((uint64_t)b.y << 32)) == w[1]) & (((uint64_t)b.z | ((uint64_t)b.w << 32)) == w[2]) &
                     (((uint64_t)c.x | ((uint64_t)c.y << 32)) == w[3]) & (((uint64_t)c.z | ((uint64_t)c.w << 32)) == w[4]);
@@ -150,7 +153,7 @@ NF_DEV uint32_t probe_home(const TableView& t, const uint64_t w[5], uint64_t h, 
 // compiler cannot move the publishing code out of the loop (where it would run
 // only after every wave-mate had left the loop: SIMT deadlock).
 NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t h) {
-    const uint64_t ready = tag_ready(h), locked = tag_locked(h);
+    const uint64_t ready = tag_ready(t, h), locked = tag_locked(t, h);
     uint64_t idx = h & t.mask;
     uint64_t probes = 0;
     uint32_t result = kNoSlot;
@@ -160,7 +163,7 @@ NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t 
         if (++trips > kSpinLimit) { atomicExch(&t.ctr->error, 2u); break; }
         SlotHot* s = &t.hot[idx];
         uint64_t tag = ald(&s->tag);
-        if (tag == 0) {
+        if (tag_is_free(t, tag)) {       // never used, or left over from an earlier epoch (eviction does not clear the table)
             // Claims are bounded: at most claim_limit slots are ever claimed in an epoch, however many new keys an
             // (optimistically folded, nfagg_api.hip) batch holds. The position handed out by the n_live increment decides
             // (a separate look at n_live before the CAS cost 2.5x in pass 2: every claimer of the chip loading the one
@@ -168,17 +171,28 @@ NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t 
             // back; positions below the limit stay dense and unique because n_live never drops below the limit once it
             // got there. A refused claim drops this lane's contribution and raises `aborted`: the API rolls the whole
             // batch back and folds a shorter prefix, so what the table holds meanwhile is moot.
-            const uint64_t old = acas(&s->tag, (uint64_t)0, locked);
-            if (old == 0) {
+            const uint64_t old = acas(&s->tag, tag, locked);
+            if (old == tag) {
                 const unsigned long long pos = aadd(&t.ctr->n_live, 1ull);
                 if (pos >= t.claim_limit) {
                     ast(&s->tag, (uint64_t)0);
                     aadd(&t.ctr->n_live, ~0ull);
                     atomicExch(&t.ctr->aborted, 1u);
                 } else {
+                    // the claimer owns the slot until it publishes `ready`: key, then every word the folds combine into
+                    // back to its identity (the slot may hold a flow of an earlier epoch)
+                    uint64_t* hw = reinterpret_cast<uint64_t*>(s);
 #pragma unroll
-                    for (int k = 0; k < 5; k++) ast(&s->key[k], w[k]);
-                    t.live_list[pos] = (uint32_t)idx;   // read by the evict kernel only (kernel boundary)
+                    for (int k = 0; k < 5; k++) ast(&hw[1 + k], w[k]);
+#pragma unroll
+                    for (int k = 6; k < 16; k++) ast(&hw[k], (uint64_t)0);
+                    ast(&t.cold[idx].smac_hi, (uint64_t)0);
+                    ast(&t.cold[idx].dmac_hi, (uint64_t)0);
+                    if (t.aux) {
+                        uint64_t* aw = reinterpret_cast<uint64_t*>(&t.aux[idx]);
+                        for (int k = 0; k < (int)(sizeof(SlotAux) / 8); k++) ast(&aw[k], (uint64_t)0);
+                    }
+                    t.live_list[pos] = (uint32_t)idx;   // read by the finalize / evict kernels only (kernel boundary)
                     drain_stores();
                     ast(&s->tag, ready);
                     result = (uint32_t)idx;
@@ -193,7 +207,7 @@ NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t 
             if (eq) { result = (uint32_t)idx; done = 1; }
             else { idx = (idx + 1) & t.mask; probes++; }
         } else if (tag == locked) {
-            // same fingerprint, key not yet published: look again next trip
+            // same fingerprint, key (and zeroes) not yet published: look again next trip
         } else {
             idx = (idx + 1) & t.mask; probes++;
         }
@@ -214,7 +228,8 @@ struct Partial {
     uint32_t first_inv;                    // ~seq of the first record
     uint32_t smac_inv, dmac_inv;           // ~seq of the first record with a non-zero mac; 0 = none
     uint64_t smac, dmac;                   // 48-bit
-    uint32_t ident[15];                    // first record's dwords 21..35
+    uint32_t ident0;                       // first record's dword 21 (if_index_first_seen); the other identity dwords are
+                                           // copied from the batch by k_finalize, no fold kernel carries them
 };
 
 NF_DEV void partial_from_record(const Rec& r, uint64_t seq, Partial& p) {
@@ -229,8 +244,7 @@ NF_DEV void partial_from_record(const Rec& r, uint64_t seq, Partial& p) {
     p.smac = r.smac(); p.dmac = r.dmac();
     p.smac_inv = p.smac ? ~(uint32_t)seq : 0u;
     p.dmac_inv = p.dmac ? ~(uint32_t)seq : 0u;
-#pragma unroll
-    for (int k = 0; k < 15; k++) p.ident[k] = r.d[21 + k];
+    p.ident0 = r.d[21];
 }
 
 // model.AccumulateBase(stored, &record.Metrics) (flow_content.go:28-61) for a
@@ -248,13 +262,10 @@ NF_DEV void merge_partial(const TableView& t, uint32_t idx, const Partial& p, co
     if (p.eth_tag) amax(&H->eth_tag, p.eth_tag);
     if (p.dscp_tag) amax(&H->dscp_tag, p.dscp_tag);
     if (p.samp_tag) amax(&H->samp_tag, p.samp_tag);
-    // First-record identity: "<=" because the careful path plants id0 in its claim phase.
-    const uint64_t my0 = tagged(p.first_inv, p.ident[0]);
-    if (x.id0 <= my0) {
-        amax(&H->id0, my0);
-#pragma unroll
-        for (int k = 1; k < 15; k++) amax(&C->id[k - 1], tagged(p.first_inv, p.ident[k]));
-    }
+    // First record: only its sequence number (the tag) has to win; "<=" because the careful path plants id0 in its
+    // claim phase. The identity dwords follow in k_finalize.
+    const uint64_t my0 = tagged(p.first_inv, p.ident0);
+    if (x.id0 <= my0) amax(&H->id0, my0);
     if (p.smac_inv) {
         const uint64_t lo = tagged(p.smac_inv, (uint32_t)p.smac);
         if (x.smac_lo <= lo) { amax(&H->smac_lo, lo); amax(&C->smac_hi, tagged(p.smac_inv, (uint32_t)(p.smac >> 32))); }

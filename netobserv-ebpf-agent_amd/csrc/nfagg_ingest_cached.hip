@@ -42,17 +42,11 @@ struct FlowCache {
 
 constexpr int kCacheProbe = 8;   // probe window: a flow that finds no entry within it bypasses the cache
 
-// Merge only the identity words / MAC words (used by the records that are the
-// workgroup's earliest for their flow).
+// Publish "first record" / MAC words (used by the records that are the workgroup's earliest for their flow).
+// Only the first record's sequence number goes into the slot; its identity dwords follow in k_finalize.
 NF_DEV void merge_ident(const TableView& t, uint32_t idx, uint32_t inv, const Rec& r, const Hints& x) {
-    SlotHot* H = &t.hot[idx];
-    SlotCold* C = &t.cold[idx];
     const uint64_t my0 = tagged(inv, r.d[21]);
-    if (x.id0 <= my0) {
-        amax(&H->id0, my0);
-#pragma unroll
-        for (int k = 1; k < 15; k++) amax(&C->id[k - 1], tagged(inv, r.d[21 + k]));
-    }
+    if (x.id0 <= my0) amax(&t.hot[idx].id0, my0);
 }
 NF_DEV void merge_smac(const TableView& t, uint32_t idx, uint32_t inv, uint64_t mac, const Hints& x) {
     const uint64_t lo = tagged(inv, (uint32_t)mac);

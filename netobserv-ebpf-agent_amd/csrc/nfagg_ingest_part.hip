@@ -20,8 +20,9 @@
 // a cache entry is a partial (nfagg_device.h) carrying sequence-tagged fields, and
 // merging partials is associative and commutative. "First record" data (and the first
 // non-zero MACs) never enter the cache: an entry only tracks the smallest sequence
-// number, and the flush gathers that record again from the batch (still in HBM — the
-// caller owns it until the call returns) to publish its identity words.
+// numbers; the flush gathers the MACs from the batch (still in HBM — the caller owns it
+// until the call returns) and publishes the first record's sequence number, whose
+// identity dwords k_finalize (nfagg_kernels.hip) copies from the batch afterwards.
 #include "nfagg_device.h"
 
 namespace nfagg {
@@ -145,8 +146,8 @@ NF_DEV uint4 rec_chunk(const void* recs, uint64_t i, int k) {
     return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + i * kRecordBytes)[k];
 }
 
-// Merge cache entry e into the table: one partial per entry. The identity dwords of
-// the entry's earliest record (and its earliest non-zero MACs) are gathered from the batch.
+// Merge cache entry e into the table: one partial per entry. The entry's earliest non-zero MACs are
+// gathered from the batch; the first record's identity dwords are left to k_finalize.
 template <bool SKETCH>
 NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L, int e, const void* recs, uint32_t seq_base32) {
     if (L.h64[e] == 0 || L.first_seq[e] == 0xffffffffu) return;   // free, or claimed but never folded into
@@ -166,20 +167,10 @@ NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L
     p.packets = L.packets[e]; p.flags = L.flags[e];
     p.eth_tag = L.eth_tag[e]; p.dscp_tag = L.dscp_tag[e]; p.samp_tag = L.samp_tag[e];
     const uint32_t fs = L.first_seq[e], ss = L.smac_seq[e], ds = L.dmac_seq[e];
-    p.first_inv = ~fs;
-#pragma unroll
-    for (int k = 0; k < 15; k++) p.ident[k] = 0;
-    if ((uint32_t)(x.id0 >> 32) <= p.first_inv) {
-        // this entry's earliest record is (so far) the flow's first: fetch its dwords 20..35
-        const uint64_t ri = (uint64_t)(fs - seq_base32);
-        const uint4 c5 = rec_chunk(recs, ri, 5), c6 = rec_chunk(recs, ri, 6), c7 = rec_chunk(recs, ri, 7), c8 = rec_chunk(recs, ri, 8);
-        p.ident[0] = c5.y; p.ident[1] = c5.z; p.ident[2] = c5.w;
-        p.ident[3] = c6.x; p.ident[4] = c6.y; p.ident[5] = c6.z & 0x0000ffffu; p.ident[6] = c6.w;    // [5] = dword 26: pad2 cleared
-        p.ident[7] = c7.x; p.ident[8] = c7.y; p.ident[9] = c7.z; p.ident[10] = c7.w;
-        p.ident[11] = c8.x; p.ident[12] = c8.y; p.ident[13] = c8.z; p.ident[14] = 0;                 // dword 35: pad4 cleared
-    } else {
-        p.first_inv = 0;   // tagged(0, 0) = 0 never wins: merge_partial skips the identity words
-    }
+    // The entry's earliest record may be the flow's first: only its sequence number goes into the slot (the tag of
+    // id0); k_finalize copies that record's identity dwords from the batch after the last fold kernel of the call.
+    p.first_inv = ((uint32_t)(x.id0 >> 32) <= ~fs) ? ~fs : 0u;   // tagged(0, 0) = 0 never wins
+    p.ident0 = 0;
     p.smac_inv = 0; p.dmac_inv = 0; p.smac = 0; p.dmac = 0;
     if (ss != 0xffffffffu && (uint32_t)(x.smac_lo >> 32) <= ~ss) {
         const uint64_t ri = (uint64_t)(ss - seq_base32);

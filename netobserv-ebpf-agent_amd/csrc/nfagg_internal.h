@@ -20,16 +20,18 @@ constexpr int kKeyBytes = 40;       // bpf/types.h:191-204
 
 // All 64-bit words of a slot are accessed with agent-scope atomics while an
 // ingest kernel runs (per-XCD L2s are not coherent with each other; see
-// DESIGN.md §coherence). Identities are zero so that eviction resets a slot by
-// zeroing it. Sequence numbers are epoch-relative and fit 32 bits (the API
-// refuses to let an epoch grow past 2^32-16 records).
+// DESIGN.md §coherence). Identities are zero. A slot belongs to the eviction epoch
+// its tag names (bits 48..63): eviction does not touch the table at all, it bumps
+// TableView.epoch_bits, and whoever claims a slot with an older tag zeroes its
+// value words before publishing it. Sequence numbers are epoch-relative and fit 32
+// bits (an epoch that reaches 2^32-16 records ends in an eviction).
 //
 // "Tagged word": (~seq32) << 32 | data32, combined with atomic max: the word of
 // the record with the SMALLEST sequence number wins, independently per word, so
 // a group of tagged words written by the same records ends up holding the
 // earliest record's data with no lock (all words see the same set of tags).
 struct alignas(128) SlotHot {
-    uint64_t tag;        // 0 empty | (fp<<2)|2 claimed, key being written | (fp<<2)|3 ready
+    uint64_t tag;        // epoch<<48 | fp46<<2 | state: 2 claimed, key and zeroes being written; 3 ready. Another epoch = free
     uint64_t key[5];     // flow_id, byte 39 zero
     uint64_t bytes;      // sum, wraps (flow_content.go:42)
     uint64_t end;        // max          (:39-41)
@@ -46,12 +48,16 @@ struct alignas(128) SlotHot {
 };
 static_assert(sizeof(SlotHot) == 128, "hot line");
 
-struct alignas(128) SlotCold {
-    uint64_t id[14];     // tagged: record dwords 22..35 of the first record
+// Half a line of "first record" data per slot. The MAC halves are tagged words like their low halves in the hot line
+// (several workgroups may race for "first non-zero MAC"). The identity dwords are PLAIN: no fold kernel writes them;
+// k_finalize (nfagg_kernels.hip), the last launch of every ingest call, copies them from the batch record that the
+// slot's id0 tag names as the flow's first (the batch is still in HBM: the caller owns it until the call returns).
+struct alignas(64) SlotCold {
     uint64_t smac_hi;    // tagged: high 16 bits of the first non-zero src_mac
     uint64_t dmac_hi;
+    uint32_t id[12];     // first record's dwords 22, 24..34 (23 = sampling comes from samp_tag, 35 = pad4 is zero)
 };
-static_assert(sizeof(SlotCold) == 128, "cold line");
+static_assert(sizeof(SlotCold) == 64, "cold half line");
 
 // Kernel-dedup mode only (NFAGG_MODE_KERNEL_DEDUP, bpf/flows.c:76-143): two more
 // lines per slot. In this mode the hot line's start_inv holds the FIRST record's raw
@@ -89,6 +95,7 @@ struct DevCounters {
     unsigned int error;            // non-zero: a kernel bailed out (probe overflow)
     unsigned int max_probe;
     unsigned long long n_direct;   // two-pass ingest: records merged one by one in pass 2 / pass 3 (no LDS entry, queue overflow)
+    unsigned long long n_finalized;// live_list[0..n_finalized) have their identity dwords written (k_finalize)
     unsigned int aborted;          // a claim was refused because n_live reached TableView.claim_limit: the fold of this
                                    // batch is incomplete and the API rolls it back (optimistic fold, nfagg_api.hip)
     unsigned int pad1;
@@ -116,6 +123,7 @@ struct TableView {
     DevCounters* ctr;
     uint64_t mask;                 // slots - 1
     uint64_t claim_limit;          // hard bound on claimed slots per epoch (3/4 of the table): claims beyond it are refused
+    uint64_t epoch_bits;           // current eviction epoch (1..65535) << 48: the tags of this epoch's slots carry it
     uint32_t n_shards, shard_id;
     SpillView spill;               // set by the API for the two-pass fold
 };
@@ -151,7 +159,7 @@ constexpr int kFlagBlock = 1024;
 hipError_t launch_first_flags(const TableView& t, const uint32_t* d_slot_idx, uint64_t n, uint64_t seq_base,
                               uint8_t* d_flags, uint32_t* d_block_counts, hipStream_t s);
 // Write every live flow whose first record has seq < seq_limit as a 144-byte
-// record (dense, order unspecified), zero every claimed slot, reset n_live.
+// record (dense, order unspecified), reset n_live. The table is not touched: the caller bumps the epoch.
 hipError_t launch_sort_slots(const uint32_t* d_in, uint32_t* d_out, uint64_t n, int end_bit, void* d_temp, size_t* temp_bytes, hipStream_t s);
 hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);
 // Optimistic fold support (nfagg_api.hip: a batch that MIGHT cross max_entries is folded whole and rolled back if it did).
@@ -162,6 +170,8 @@ size_t snapshot_bytes(const TableView& t, uint64_t n);
 hipError_t launch_snapshot(const TableView& t, uint64_t n, void* d_snap, bool restore, hipStream_t s);
 hipError_t launch_discard(const TableView& t, uint64_t from, uint64_t to, hipStream_t s);
 hipError_t launch_first_seqs(const TableView& t, uint64_t from, uint64_t to, uint32_t* d_out, hipStream_t s);
+// Last launch of an ingest call: identity dwords of the slots claimed since the previous finalize, from records[0..n).
+hipError_t launch_finalize(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
 hipError_t launch_sort_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, void* d_temp, size_t* temp_bytes, hipStream_t s);
 // Sketch update over a batch (nfagg_sketch.hip).
 hipError_t launch_sketch_update(const SketchView& sk, const TableView& t, const void* d_records, uint64_t n, hipStream_t s);

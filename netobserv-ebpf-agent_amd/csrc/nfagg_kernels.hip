@@ -77,57 +77,150 @@ __global__ __launch_bounds__(kFlagBlock) void k_first_flags(TableView t, const u
 }
 
 // ------------------------------------------------------------------
-// Evict: Accounter.evict (account.go:102-124) up to NewRecord. One lane per
-// claimed slot: rebuild the 144-byte flow_record_t, write it densely, zero
-// the slot (zero is every field's identity, so the next epoch needs no init).
+// Evict: Accounter.evict (account.go:102-124) up to NewRecord. Reads one 128-byte hot line + one 64-byte cold half line
+// per flow and writes one 144-byte record; nothing is zeroed (epoch tags, nfagg_internal.h). A wave takes 64 claimed
+// slots at a time: eight lanes fetch one hot line (16 bytes each: every load instruction covers eight whole lines), four
+// lanes one cold half line, through LDS; then one lane per slot rebuilds its record into the wave's LDS window at the
+// rank a ballot gave it (one n_out atomic per wave, not per lane), and the window — the wave's records back to back —
+// goes out with 16-byte stores, consecutive lanes on consecutive addresses.
 // ------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_evict(TableView t, uint64_t n_live, uint64_t seq_limit,
-                                               void* __restrict__ out) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_live; i += stride) {
-        const uint32_t idx = t.live_list[i];
-        SlotHot* H = &t.hot[idx];
-        SlotCold* C = &t.cold[idx];
-        const SlotHot hv = *H;
-        const SlotCold cv = *C;
-        const uint32_t first_inv = (uint32_t)(hv.id0 >> 32);
-        // A slot claimed by the careful path for a key that first appears at or
-        // after the split point is not part of this epoch: drop it.
-        const bool emit = first_inv != 0 && (uint64_t)(~first_inv) < seq_limit;
-        if (emit) {
-            uint32_t d[kRecordDwords];
+constexpr int kEvictWaves = 2;                        // waves per workgroup
+// Rows are padded to an odd number of 16-byte chunks (9 and 5): lane l reading chunk c of ITS row touches banks
+// (36 l + 4 c) mod 32 resp. (20 l + 4 c) mod 32 — eight consecutive lanes cover all 32 banks, a 16-byte read per lane runs
+// at the LDS's full rate. (Unpadded 128-byte rows put all 64 lanes on the same four banks.)
+struct EvictWaveLds {
+    uint4 hot[64][9];                                 // 9 KiB; reused as the output window: 64 records x 144 B
+    uint4 cold[64][5];                                // 5 KiB
+};
+static_assert(sizeof(uint4) * 9 == kRecordBytes, "a padded hot row is exactly one output record");
+
+// FILTER = false (no split pending: every claimed slot is a flow of this epoch): slot i of the live list goes to out[i],
+// no counter at all — 16 k returning atomics on the one n_out word, one per wave, were what bounded this kernel
+// (0.22 ms for 1 M flows whatever the traffic). FILTER = true: slots claimed for keys that first appear at or after the
+// split point are dropped (careful path, nfagg_api.hip), positions come from n_out.
+template <bool FILTER>
+__global__ __launch_bounds__(64 * kEvictWaves) void k_evict(TableView t, uint64_t n_live, uint64_t seq_limit,
+                                                            void* __restrict__ out) {
+    __shared__ EvictWaveLds lds[kEvictWaves];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    EvictWaveLds& W = lds[wv];
+    const uint64_t wave_id = (uint64_t)blockIdx.x * kEvictWaves + wv, n_waves = (uint64_t)gridDim.x * kEvictWaves;
+    for (uint64_t base = wave_id * 64; base < n_live; base += n_waves * 64) {
+        const uint64_t cnt = n_live - base < 64 ? n_live - base : 64;
+        const uint32_t my_idx = (uint64_t)lane < cnt ? t.live_list[base + lane] : 0u;
+        // ---- cooperative fetch: pass p covers slots 8p..8p+7 (hot), 16p..16p+15 (cold)
 #pragma unroll
-            for (int k = 0; k < 5; k++) { d[2 * k] = (uint32_t)hv.key[k]; d[2 * k + 1] = (uint32_t)(hv.key[k] >> 32); }
-            const uint64_t start = hv.start_inv ? ~hv.start_inv : 0ull;
+        for (int p = 0; p < 8; p++) {
+            const int s = 8 * p + (lane >> 3);
+            const uint32_t idx = __shfl(my_idx, s);
+            if ((uint64_t)s < cnt) W.hot[s][lane & 7] = reinterpret_cast<const uint4*>(&t.hot[idx])[lane & 7];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int s = 16 * p + (lane >> 2);
+            const uint32_t idx = __shfl(my_idx, s);
+            if ((uint64_t)s < cnt) W.cold[s][lane & 3] = reinterpret_cast<const uint4*>(&t.cold[idx])[lane & 3];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- one lane per slot: rebuild the record in registers
+        uint32_t d[kRecordDwords];
+        bool emit = false;
+        if ((uint64_t)lane < cnt) {
+            uint64_t hq[16], cq[2];
+            uint32_t ci[12];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint4 v = W.hot[lane][k];
+                hq[2 * k] = (uint64_t)v.x | ((uint64_t)v.y << 32); hq[2 * k + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+            }
+            {
+                const uint4 v0 = W.cold[lane][0], v1 = W.cold[lane][1], v2 = W.cold[lane][2], v3 = W.cold[lane][3];
+                cq[0] = (uint64_t)v0.x | ((uint64_t)v0.y << 32); cq[1] = (uint64_t)v0.z | ((uint64_t)v0.w << 32);
+                ci[0] = v1.x; ci[1] = v1.y; ci[2] = v1.z; ci[3] = v1.w; ci[4] = v2.x; ci[5] = v2.y; ci[6] = v2.z; ci[7] = v2.w;
+                ci[8] = v3.x; ci[9] = v3.y; ci[10] = v3.z; ci[11] = v3.w;
+            }
+            const uint64_t id0 = hq[13];
+            const uint32_t first_inv = (uint32_t)(id0 >> 32);
+            // A slot claimed by the careful path for a key that first appears at or after the split point is not part of
+            // this epoch: drop it.
+            emit = first_inv != 0 && (uint64_t)(~first_inv) < seq_limit;
+            if (!FILTER && !emit) { atomicExch(&t.ctr->error, 6u); emit = true; }   // cannot happen: every claimer merges its record
+#pragma unroll
+            for (int k = 0; k < 5; k++) { d[2 * k] = (uint32_t)hq[1 + k]; d[2 * k + 1] = (uint32_t)(hq[1 + k] >> 32); }
+            const uint64_t bytes = hq[6], end = hq[7], start_inv = hq[8], pf = hq[9], eth_tag = hq[10], dscp_tag = hq[11],
+                           samp_tag = hq[12], smac_lo = hq[14], dmac_lo = hq[15];
+            const uint64_t start = start_inv ? ~start_inv : 0ull;
             d[10] = (uint32_t)start; d[11] = (uint32_t)(start >> 32);
-            d[12] = (uint32_t)hv.end; d[13] = (uint32_t)(hv.end >> 32);
-            d[14] = (uint32_t)hv.bytes; d[15] = (uint32_t)(hv.bytes >> 32);
-            d[16] = hv.packets;
-            d[17] = (uint32_t)(hv.eth_tag & 0xffffu) | ((hv.flags & 0xffffu) << 16);
-            const uint64_t smac = (uint64_t)(uint32_t)hv.smac_lo | ((uint64_t)(cv.smac_hi & 0xffffu) << 32);
-            const uint64_t dmac = (uint64_t)(uint32_t)hv.dmac_lo | ((uint64_t)(cv.dmac_hi & 0xffffu) << 32);
+            d[12] = (uint32_t)end; d[13] = (uint32_t)(end >> 32);
+            d[14] = (uint32_t)bytes; d[15] = (uint32_t)(bytes >> 32);
+            d[16] = (uint32_t)pf;                                               // packets
+            d[17] = (uint32_t)(eth_tag & 0xffffu) | (((uint32_t)(pf >> 32) & 0xffffu) << 16);   // eth (last non-zero) | flags
+            const uint64_t smac = (uint64_t)(uint32_t)smac_lo | ((uint64_t)(cq[0] & 0xffffu) << 32);
+            const uint64_t dmac = (uint64_t)(uint32_t)dmac_lo | ((uint64_t)(cq[1] & 0xffffu) << 32);
             d[18] = (uint32_t)smac;
             d[19] = (uint32_t)((smac >> 32) & 0xffffu) | (uint32_t)((dmac & 0xffffu) << 16);
             d[20] = (uint32_t)(dmac >> 16);
-            d[21] = (uint32_t)hv.id0;
+            d[21] = (uint32_t)id0;
+            d[22] = ci[0];
+            d[23] = (uint32_t)samp_tag;                                         // sampling: last non-zero
 #pragma unroll
-            for (int k = 0; k < 14; k++) d[22 + k] = (uint32_t)cv.id[k];
-            d[23] = (uint32_t)hv.samp_tag;                                   // sampling: last non-zero
-            d[24] = (d[24] & 0xff00ffffu) | ((uint32_t)(hv.dscp_tag & 0xffu) << 16);  // dscp: last non-zero
-            const unsigned long long pos = aadd(&t.ctr->n_out, 1ull);
-            uint4* o = reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + pos * kRecordBytes);
-#pragma unroll
-            for (int k = 0; k < 9; k++) o[k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+            for (int k = 1; k < 12; k++) d[23 + k] = ci[k];
+            d[24] = (d[24] & 0xff00ffffu) | ((uint32_t)(dscp_tag & 0xffu) << 16);   // dscp: last non-zero
+            d[35] = 0;
         }
-        uint4* hz = reinterpret_cast<uint4*>(H);
-        uint4* cz = reinterpret_cast<uint4*>(C);
+        // ---- compaction: rank among the emitting lanes, one atomic per wave
+        const unsigned long long mask = __ballot(emit);
+        const uint32_t n_emit = (uint32_t)__popcll(mask);
+        unsigned long long pos0 = base;
+        if (FILTER) {
+            if (lane == 0 && n_emit) pos0 = aadd(&t.ctr->n_out, (unsigned long long)n_emit);
+            pos0 = __shfl(pos0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();                                        // every lane has read its LDS rows
+        if (emit) {
+            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            uint4* w = &W.hot[rank][0];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { hz[k] = make_uint4(0, 0, 0, 0); cz[k] = make_uint4(0, 0, 0, 0); }
+            for (int k = 0; k < 9; k++) w[k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint4* o = reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + pos0 * kRecordBytes);
+        const uint4* w = &W.hot[0][0];
+        for (uint32_t c = lane; c < n_emit * 9; c += 64) o[c] = w[c];
+        __builtin_amdgcn_wave_barrier();                                        // window free for the next 64 slots
     }
 }
 
-__global__ void k_reset_after_evict(DevCounters* c) {
+// ------------------------------------------------------------------
+// Finalize: the last launch of every ingest call. For each slot claimed since the previous finalize, the tag of id0 is
+// the sequence number of the flow's first record (account.go:95 stores it whole): copy that record's dwords 21..34
+// from the batch into the slot — plain stores, this lane is the only writer, every fold kernel of the call is done.
+// ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(TableView t, const void* __restrict__ recs, uint64_t n, uint32_t seq_base32) {
+    const uint64_t from = t.ctr->n_finalized, to = t.ctr->n_live;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < to; i += stride) {
+        const uint32_t idx = t.live_list[i];
+        SlotHot* H = &t.hot[idx];
+        const uint64_t id0 = H->id0;
+        const uint64_t ri = (uint64_t)(uint32_t)(~(uint32_t)(id0 >> 32) - seq_base32);
+        if ((uint32_t)(id0 >> 32) == 0 || ri >= n) continue;   // claimed, but no record of this batch's folded range is its first
+        const uint4* rp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + ri * kRecordBytes);
+        const uint4 c5 = rp[5], c6 = rp[6], c7 = rp[7], c8 = rp[8];     // record dwords 20..35
+        uint4* cw = reinterpret_cast<uint4*>(&t.cold[idx]);
+        cw[1] = make_uint4(c5.z, c6.x, c6.y, c6.z & 0x0000ffffu);       // dwords 22, 24, 25, 26 (pad2 cleared)
+        cw[2] = make_uint4(c6.w, c7.x, c7.y, c7.z);                     // 27..30
+        cw[3] = make_uint4(c7.w, c8.x, c8.y, c8.z);                     // 31..34
+        reinterpret_cast<uint32_t*>(&H->id0)[0] = c5.y;                 // dword 21: if_index_first_seen
+    }
+}
+
+__global__ void k_finalize_done(DevCounters* c) { c->n_finalized = c->n_live; }
+
+__global__ void k_reset_after_evict(DevCounters* c, int n_out_is_n_live) {
+    if (n_out_is_n_live) c->n_out = c->n_live;
     c->n_live = 0;
+    c->n_finalized = 0;
     c->aborted = 0;
     c->max_probe = 0;
 }
@@ -138,29 +231,24 @@ __global__ void k_reset_after_evict(DevCounters* c) {
 // ------------------------------------------------------------------
 template <bool RESTORE>
 __global__ __launch_bounds__(256) void k_snapshot(TableView t, uint64_t n, uint4* __restrict__ snap) {
-    const int per = t.aux ? 32 : 16;                       // 16-byte chunks per slot: hot 8 + cold 8 (+ aux 16)
+    const int per = t.aux ? 28 : 12;                       // 16-byte chunks per slot: hot 8 + cold 4 (+ aux 16)
     const uint64_t total = n * (uint64_t)per, stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
         const uint64_t i = g / per; const int c = (int)(g % per);
         const uint32_t idx = t.live_list[i];
         uint4* p; uint4* q;
         if (c < 8) { p = reinterpret_cast<uint4*>(&t.hot[idx]) + c; q = snap + i * 8 + c; }
-        else if (c < 16) { p = reinterpret_cast<uint4*>(&t.cold[idx]) + (c - 8); q = snap + n * 8 + i * 8 + (c - 8); }
-        else { p = reinterpret_cast<uint4*>(&t.aux[idx]) + (c - 16); q = snap + n * 16 + i * 16 + (c - 16); }
+        else if (c < 12) { p = reinterpret_cast<uint4*>(&t.cold[idx]) + (c - 8); q = snap + n * 8 + i * 4 + (c - 8); }
+        else { p = reinterpret_cast<uint4*>(&t.aux[idx]) + (c - 12); q = snap + n * 12 + i * 16 + (c - 12); }
         if (RESTORE) *p = *q; else *q = *p;
     }
 }
 
+// Give the slots live_list[from..to) back: an empty tag is all it takes (whoever claims a slot re-initialises it).
 __global__ __launch_bounds__(256) void k_discard(TableView t, uint64_t from, uint64_t to) {
-    const int per = t.aux ? 32 : 16;
-    const uint64_t total = (to - from) * (uint64_t)per, stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        const uint64_t i = from + g / per; const int c = (int)(g % per);
-        const uint32_t idx = t.live_list[i];
-        uint4* p = c < 8 ? reinterpret_cast<uint4*>(&t.hot[idx]) + c
-                 : c < 16 ? reinterpret_cast<uint4*>(&t.cold[idx]) + (c - 8) : reinterpret_cast<uint4*>(&t.aux[idx]) + (c - 16);
-        *p = make_uint4(0, 0, 0, 0);
-    }
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < to; i += stride)
+        t.hot[t.live_list[i]].tag = 0;
 }
 
 // out[i - from] = epoch-relative sequence number of the first record of the flow in slot live_list[i]
@@ -248,11 +336,11 @@ hipError_t launch_sort_slots(const uint32_t* d_in, uint32_t* d_out, uint64_t n, 
     return hipcub::DeviceRadixSort::SortKeys(d_temp, *temp_bytes, d_in, d_out, (int)n, 0, end_bit, s);
 }
 
-size_t snapshot_bytes(const TableView& t, uint64_t n) { return (size_t)n * (t.aux ? 512 : 256); }
+size_t snapshot_bytes(const TableView& t, uint64_t n) { return (size_t)n * (t.aux ? 448 : 192); }
 
 hipError_t launch_snapshot(const TableView& t, uint64_t n, void* d_snap, bool restore, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    const int grid = grid_for(n * (t.aux ? 32 : 16), 256, 256 * 16);
+    const int grid = grid_for(n * (t.aux ? 28 : 12), 256, 256 * 16);
     (void)hipGetLastError();
     if (restore) hipLaunchKernelGGL(k_snapshot<true>, dim3(grid), dim3(256), 0, s, t, n, (uint4*)d_snap);
     else hipLaunchKernelGGL(k_snapshot<false>, dim3(grid), dim3(256), 0, s, t, n, (uint4*)d_snap);
@@ -262,7 +350,7 @@ hipError_t launch_snapshot(const TableView& t, uint64_t n, void* d_snap, bool re
 hipError_t launch_discard(const TableView& t, uint64_t from, uint64_t to, hipStream_t s) {
     if (to <= from) return hipSuccess;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_discard, dim3(grid_for((to - from) * (t.aux ? 32 : 16), 256, 256 * 16)), dim3(256), 0, s, t, from, to);
+    hipLaunchKernelGGL(k_discard, dim3(grid_for(to - from, 256, 256 * 8)), dim3(256), 0, s, t, from, to);
     return hipGetLastError();
 }
 
@@ -273,6 +361,17 @@ hipError_t launch_first_seqs(const TableView& t, uint64_t from, uint64_t to, uin
     return hipGetLastError();
 }
 
+hipError_t launch_finalize(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s) {
+    (void)hipGetLastError();
+    // the number of new slots is only known on the device: a fixed grid strides over [n_finalized, n_live)
+    const int grid = n >= (1u << 20) ? 1024 : (n >= (1u << 14) ? 64 : 4);
+    hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, t, d_records, n, (uint32_t)seq_base);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_finalize_done, dim3(1), dim3(1), 0, s, t.ctr);
+    return hipGetLastError();
+}
+
 hipError_t launch_sort_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, void* d_temp, size_t* temp_bytes, hipStream_t s) {
     return hipcub::DeviceRadixSort::SortKeys(d_temp, *temp_bytes, d_in, d_out, (int)n, 0, 32, s);
 }
@@ -280,11 +379,14 @@ hipError_t launch_sort_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, vo
 hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s) {
     if (t.aux) return launch_evict_dedup(t, n_live, seq_limit, d_out, s);
     if (n_live) {
-        (void)hipGetLastError(); hipLaunchKernelGGL(k_evict, dim3(grid_for(n_live, 256, 256 * 8)), dim3(256), 0, s, t, n_live, seq_limit, d_out);
+        (void)hipGetLastError();
+        const dim3 grid(grid_for(n_live, 64 * kEvictWaves, 256 * 16)), block(64 * kEvictWaves);
+        if (seq_limit == ~0ull) hipLaunchKernelGGL(k_evict<false>, grid, block, 0, s, t, n_live, seq_limit, d_out);
+        else hipLaunchKernelGGL(k_evict<true>, grid, block, 0, s, t, n_live, seq_limit, d_out);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    (void)hipGetLastError(); hipLaunchKernelGGL(k_reset_after_evict, dim3(1), dim3(1), 0, s, t.ctr);
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_reset_after_evict, dim3(1), dim3(1), 0, s, t.ctr, seq_limit == ~0ull ? 1 : 0);
     return hipGetLastError();
 }
 

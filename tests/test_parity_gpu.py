@@ -343,3 +343,18 @@ def test_large_table_evicts_in_slot_order(nf, O, mode):
             got = nf.sort_by_key(tab.evict(nf.REASON_TIMEOUT))
             assert_records_equal(got, want, mode)
             assert len(tab) == 0
+
+
+def test_epoch_tags_wrap_after_65535_evictions(nf, O):
+    """Eviction does not clear the table: slots carry their epoch in 16 tag bits, and the tags are cleared once when the
+    epoch counter wraps. Flows left in the table by epoch e must not reappear in epoch e + 65 535."""
+    a = O.gen_stream(3000, seed=71, n_keys=200, variant=1)
+    b = O.gen_stream(3000, seed=72, n_keys=200, variant=1)
+    with nf.FlowTable(max_entries=1000) as tab:
+        assert tab.ingest(a.view(nf.FLOW_RECORD)) == (nf.OK, len(a))
+        assert_records_equal(nf.sort_by_key(tab.evict(nf.REASON_CLOSING)), O.run_accounter(a, 1000)[0][1])
+        for _ in range(65534):
+            assert len(tab.evict(nf.REASON_CLOSING, cap=1)) == 0          # closing evicts (and starts an epoch) even when empty
+        for part in (b, a, b):                                             # epoch numbers 1 (again), 2, 3
+            assert tab.ingest(part.view(nf.FLOW_RECORD)) == (nf.OK, len(part))
+            assert_records_equal(nf.sort_by_key(tab.evict(nf.REASON_CLOSING)), O.run_accounter(part, 1000)[0][1])

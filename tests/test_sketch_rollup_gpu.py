@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 1, 2, 3, 7, 10])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 3, 7, 10])
 def test_count_min_and_hll_match_scalar_oracle(nf, O, ingest_variant):
     th = O.zipf_thresholds(20000, 1.1)
     recs = O.gen_stream(200000, seed=3, n_keys=20000, thresholds=th, variant=1)
