@@ -152,7 +152,11 @@ NF_DEV uint32_t probe_home(const TableView& t, const uint64_t w[5], uint64_t h, 
 // trip in which its CAS succeeded. The empty asm keeps `done` opaque so the
 // compiler cannot move the publishing code out of the loop (where it would run
 // only after every wave-mate had left the loop: SIMT deadlock).
-NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t h) {
+// DEFER (pass 2 of the two-pass fold, which owns its partition's flows): a successful claim only takes the slot
+// (tag = claimed) and reports `fresh`; the caller writes key and values itself, publishes the tag and registers the slot
+// in the live list through its workgroup (one n_live atomic per workgroup instead of one per wave).
+template <bool DEFER = false>
+NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t h, bool* fresh = nullptr) {
     const uint64_t ready = tag_ready(t, h), locked = tag_locked(t, h);
     uint64_t idx = h & t.mask;
     uint64_t probes = 0;
@@ -172,7 +176,8 @@ NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t 
             // got there. A refused claim drops this lane's contribution and raises `aborted`: the API rolls the whole
             // batch back and folds a shorter prefix, so what the table holds meanwhile is moot.
             const uint64_t old = acas(&s->tag, tag, locked);
-            if (old == tag) {
+            if (DEFER && old == tag) { *fresh = true; result = (uint32_t)idx; done = 1; }
+            else if (old == tag) {
                 const unsigned long long pos = aadd(&t.ctr->n_live, 1ull);
                 if (pos >= t.claim_limit) {
                     ast(&s->tag, (uint64_t)0);
@@ -273,6 +278,61 @@ NF_DEV void merge_partial(const TableView& t, uint32_t idx, const Partial& p, co
     if (p.dmac_inv) {
         const uint64_t lo = tagged(p.dmac_inv, (uint32_t)p.dmac);
         if (x.dmac_lo <= lo) { amax(&H->dmac_lo, lo); amax(&C->dmac_hi, tagged(p.dmac_inv, (uint32_t)(p.dmac >> 32))); }
+    }
+}
+
+// merge_partial for a lane that OWNS the flow for the duration of the kernel: pass 2 of the two-pass fold, where a
+// flow's records all went to the queue of its partition and one workgroup folds that queue, each flow in one cache
+// entry — no other lane of the chip touches the value words of this slot before the kernel ends (other workgroups only
+// probe its tag and key; pass 1 and pass 3 are other kernels). So the ~12 atomics of merge_partial become a plain
+// read-modify-write of the line: five 16-byte loads, the operators of flow_content.go:28-61 in registers, 16-byte stores.
+// fresh: the slot was claimed (tag = claimed) by this lane just now and holds stale data: nothing is loaded, the
+// partial IS the value; key (write-through, other workgroups compare it), values, then the tag is published.
+NF_DEV void merge_partial_exclusive(const TableView& t, uint32_t idx, const Partial& p, bool fresh, const uint64_t w[5], uint64_t h) {
+    uint4* HL = reinterpret_cast<uint4*>(&t.hot[idx]);
+    SlotCold* C = &t.cold[idx];
+    uint64_t bytes = 0, end = 0, start_inv = 0, eth_tag = 0, dscp_tag = 0, samp_tag = 0, id0 = 0, smac_lo = 0, dmac_lo = 0;
+    uint32_t packets = 0, flags = 0;
+    if (!fresh) {
+        const uint4 l3 = HL[3], l4 = HL[4], l5 = HL[5], l6 = HL[6], l7 = HL[7];
+        bytes = (uint64_t)l3.x | ((uint64_t)l3.y << 32); end = (uint64_t)l3.z | ((uint64_t)l3.w << 32);
+        start_inv = (uint64_t)l4.x | ((uint64_t)l4.y << 32); packets = l4.z; flags = l4.w;
+        eth_tag = (uint64_t)l5.x | ((uint64_t)l5.y << 32); dscp_tag = (uint64_t)l5.z | ((uint64_t)l5.w << 32);
+        samp_tag = (uint64_t)l6.x | ((uint64_t)l6.y << 32); id0 = (uint64_t)l6.z | ((uint64_t)l6.w << 32);
+        smac_lo = (uint64_t)l7.x | ((uint64_t)l7.y << 32); dmac_lo = (uint64_t)l7.z | ((uint64_t)l7.w << 32);
+    }
+    bytes += p.bytes; packets += p.packets; flags |= p.flags;
+    if (p.end > end) end = p.end;
+    if (p.start_inv > start_inv) start_inv = p.start_inv;
+    if (p.eth_tag > eth_tag) eth_tag = p.eth_tag;
+    if (p.dscp_tag > dscp_tag) dscp_tag = p.dscp_tag;
+    if (p.samp_tag > samp_tag) samp_tag = p.samp_tag;
+    const uint64_t my0 = tagged(p.first_inv, p.ident0);
+    if (my0 > id0) id0 = my0;
+    // the high MAC halves live in the cold half line: written when they change, and always for a fresh slot (stale data)
+    bool st_s = fresh, st_d = fresh;
+    uint64_t smac_hi = 0, dmac_hi = 0;
+    if (p.smac_inv) {
+        const uint64_t lo = tagged(p.smac_inv, (uint32_t)p.smac);
+        if (lo >= smac_lo) { smac_lo = lo; smac_hi = tagged(p.smac_inv, (uint32_t)(p.smac >> 32)); st_s = true; }
+    }
+    if (p.dmac_inv) {
+        const uint64_t lo = tagged(p.dmac_inv, (uint32_t)p.dmac);
+        if (lo >= dmac_lo) { dmac_lo = lo; dmac_hi = tagged(p.dmac_inv, (uint32_t)(p.dmac >> 32)); st_d = true; }
+    }
+    if (st_s) C->smac_hi = smac_hi;
+    if (st_d) C->dmac_hi = dmac_hi;
+    HL[3] = make_uint4((uint32_t)bytes, (uint32_t)(bytes >> 32), (uint32_t)end, (uint32_t)(end >> 32));
+    HL[4] = make_uint4((uint32_t)start_inv, (uint32_t)(start_inv >> 32), packets, flags);
+    HL[5] = make_uint4((uint32_t)eth_tag, (uint32_t)(eth_tag >> 32), (uint32_t)dscp_tag, (uint32_t)(dscp_tag >> 32));
+    HL[6] = make_uint4((uint32_t)samp_tag, (uint32_t)(samp_tag >> 32), (uint32_t)id0, (uint32_t)(id0 >> 32));
+    HL[7] = make_uint4((uint32_t)smac_lo, (uint32_t)(smac_lo >> 32), (uint32_t)dmac_lo, (uint32_t)(dmac_lo >> 32));
+    if (fresh) {
+        SlotHot* H = &t.hot[idx];
+#pragma unroll
+        for (int k = 0; k < 5; k++) ast(&H->key[k], w[k]);
+        drain_stores();
+        ast(&H->tag, tag_ready(t, h));
     }
 }
 

@@ -148,19 +148,24 @@ NF_DEV uint4 rec_chunk(const void* recs, uint64_t i, int k) {
 
 // Merge cache entry e into the table: one partial per entry. The entry's earliest non-zero MACs are
 // gathered from the batch; the first record's identity dwords are left to k_finalize.
-template <bool SKETCH>
-NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L, int e, const void* recs, uint32_t seq_base32) {
+// EXCL (pass 2): this workgroup owns the flow — plain read-modify-write instead of atomics (merge_partial_exclusive),
+// slots it claims are collected in new_list[] and registered in the live list once per workgroup.
+template <bool SKETCH, bool EXCL>
+NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L, int e, const void* recs, uint32_t seq_base32,
+                              uint32_t* new_list, uint32_t* new_cnt) {
     if (L.h64[e] == 0 || L.first_seq[e] == 0xffffffffu) return;   // free, or claimed but never folded into
     uint64_t w[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
     const uint64_t h = key_hash(w);
     Hints x;
+    bool fresh = false;
     uint32_t idx = probe_home(t, w, h, x);
     if (idx == kNoSlot) {
-        idx = find_or_claim(t, w, h);
+        idx = EXCL ? find_or_claim<true>(t, w, h, &fresh) : find_or_claim(t, w, h);
         if (idx == kNoSlot) return;
-        load_hints(&t.hot[idx], x);
+        if (fresh) { x.end = 0; x.start_inv = 0; x.id0 = 0; x.smac_lo = 0; x.dmac_lo = 0; x.flags = 0; new_list[atomicAdd(new_cnt, 1u)] = idx; }
+        else load_hints(&t.hot[idx], x);
     }
     Partial p;
     p.bytes = L.bytes[e]; p.end = L.end[e]; p.start_inv = L.start_inv[e];
@@ -184,7 +189,8 @@ NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L
         p.dmac = (uint64_t)(c4.w >> 16) | ((uint64_t)c5.x << 16);
         p.dmac_inv = ~ds;
     }
-    merge_partial(t, idx, p, x);
+    if (EXCL) merge_partial_exclusive(t, idx, p, fresh, w, h);
+    else merge_partial(t, idx, p, x);
     if (SKETCH) sketch_add(sk, w, p.bytes);
 }
 
@@ -197,6 +203,8 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
     Cache& L = *reinterpret_cast<Cache*>(lds_raw);
     Stage& S = *reinterpret_cast<Stage*>(lds_raw + sizeof(Cache));   // pass 1 only
     uint32_t* door = reinterpret_cast<Door*>(lds_raw + sizeof(Cache) + sizeof(Stage))->bits;   // pass 1 with DOOR only
+    uint32_t* new_list = reinterpret_cast<uint32_t*>(lds_raw + sizeof(Cache));                 // pass 2 only: slots claimed by the flush
+    uint32_t* new_cnt = new_list + kEntries;                                                    // [0] count, [1..2] base of the reserved range
     const int tid = threadIdx.x;
     const uint32_t seq_base32 = (uint32_t)seq_base;
     uint64_t count = n;
@@ -208,6 +216,7 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
         my_queue = q.queue + (uint64_t)blockIdx.x * q.qcap;
     }
     cache_init(L, tid);
+    if (QUEUE && tid == 0) new_cnt[0] = 0;
     if (!QUEUE) for (int p = tid; p < kSpillParts; p += kBlock) S.cnt[p] = 0;
     if (DOOR) for (int p = tid; p < kDoorBits / 32; p += kBlock) door[p] = 0;
     __syncthreads();
@@ -353,7 +362,30 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
             }
         }
     }
-    for (int e = tid; e < kEntries; e += kBlock) cache_flush_entry<SKETCH>(t, sk, L, e, recs, seq_base32);
+    for (int e = tid; e < kEntries; e += kBlock) cache_flush_entry<SKETCH, QUEUE>(t, sk, L, e, recs, seq_base32, new_list, new_cnt);
+    if (QUEUE) {
+        // the slots this workgroup claimed: one range of the live list, reserved with one atomic. Positions at or beyond
+        // claim_limit are given back (find_or_claim's rule, applied to the range): slot emptied, n_live restored, `aborted`.
+        __syncthreads();
+        const uint32_t cnt = new_cnt[0];
+        if (cnt) {
+            if (tid == 0) {
+                const unsigned long long base = aadd(&t.ctr->n_live, (unsigned long long)cnt);
+                new_cnt[1] = (uint32_t)base; new_cnt[2] = (uint32_t)(base >> 32);
+                if (base + cnt > t.claim_limit) {
+                    const unsigned long long keep = base < t.claim_limit ? t.claim_limit - base : 0ull;
+                    aadd(&t.ctr->n_live, ~(unsigned long long)(cnt - keep) + 1ull);
+                    atomicExch(&t.ctr->aborted, 1u);
+                }
+            }
+            __syncthreads();
+            const unsigned long long base = (unsigned long long)new_cnt[1] | ((unsigned long long)new_cnt[2] << 32);
+            for (uint32_t i = tid; i < cnt; i += kBlock) {
+                if (base + i < t.claim_limit) t.live_list[base + i] = new_list[i];
+                else ast(&t.hot[new_list[i]].tag, (uint64_t)0);
+            }
+        }
+    }
     if (TIMING) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         NF_TICK(6);
@@ -388,7 +420,7 @@ __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView 
 template <bool SKETCH, bool T1 = false, bool T2 = false, bool DOOR = true>
 static hipError_t run(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                       uint64_t seq_base, hipStream_t s) {
-    const size_t lds1 = sizeof(Cache) + sizeof(Stage) + (DOOR ? sizeof(Door) : 0), lds2 = sizeof(Cache);
+    const size_t lds1 = sizeof(Cache) + sizeof(Stage) + (DOOR ? sizeof(Door) : 0), lds2 = sizeof(Cache) + (kEntries + 4) * sizeof(uint32_t);
     static_assert(sizeof(Cache) + sizeof(Stage) + sizeof(Door) <= 160 * 1024, "pass 1 needs the whole LDS of a CU");
     static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
     int dev_ = 0;
