@@ -179,6 +179,8 @@ def main():
                                 "+CM(d=4,w=2^20)+HLL(p=14)" if args.sketches else " only",
                                 ", kernel-dedup merge on" if args.dedup else "")),
                 "records_per_gpu_per_step": n, "unique_flows_per_gpu": keys, "hot_permille": args.hot_permille,
+                "stream_variant": 2 if args.dedup else 0, "mode": "kernel_dedup" if args.dedup else "accounter",
+                "max_entries": max_entries, "table_bytes": int(st.table_bytes), "chunk": chunk,
                 "parallelism": "key-hash shards x%d" % world + ("" if args.backend == "nccl" and not args.same_device
                                                                         else " (REHEARSAL: backend %s, same_device %s)" % (args.backend, args.same_device)), "ingest_variant": args.variant,
                 "evictions_per_step": 1, "evicted_flows_per_step": flows_total,
@@ -187,10 +189,15 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("k_dedup_claim + k_dedup_fold (one ingest call)" if args.dedup else
-                           "part::k_fold pass 1 + pass 2 (+ k_merge_overflow) = one hash-insert/fold call" if args.variant == 0 else
+                           "part::k_fold pass 1 + pass 2 (+ k_merge_overflow + k_finalize) = one hash-insert/fold call" if args.variant == 0 else
                            "ingest variant %d" % args.variant),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                # honest yardsticks next to SURVEY §8(d)'s algorithmic figure (which charges a slot read + write per record that
+                # the LDS flow cache never performs): frac_stream_floor = the 144-byte records alone, read once, against the
+                # peak; frac_traffic = HBM bytes the counters saw (roofline.traffic), against the peak
+                "frac_stream_floor": round(144 * recs_per_launch / (ingest_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ingest_ms > 0 else None,
+                "frac_traffic": None,
                 "alg_bytes_per_record": alg_bytes, "records_per_launch": int(recs_per_launch),
                 "launch_ms": round(ingest_ms, 4), "launches": int(st.ingest_launches),
                 "lds_cache_hit_rate": round(1.0 - st.records_bypassed / max(1, n * (args.steps + args.warmup)), 4),
@@ -199,6 +206,12 @@ def main():
                 "sketch_launch_ms": round(st.sketch_kernel_ms / max(st.sketch_launches, 1), 4) if st.sketch_launches else None,
             },
         }
+        ev_ms = st.evict_kernel_ms / max(st.evict_launches, 1)
+        if ev_ms > 0 and not args.dedup:
+            ev_ach = ALG_BYTES_EVICT * (flows_total / world) / (ev_ms * 1e-3) / 1e9
+            out["roofline_evict"] = {"bound": "hbm", "kernel": "k_evict", "achieved": round(ev_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(ev_ach / HBM_PEAK_GBS, 4), "alg_bytes_per_flow": ALG_BYTES_EVICT,
+                                     "flows_per_launch": int(flows_total / world), "launch_ms": round(ev_ms, 4), "traffic": None}
         # ---- HBM traffic of one ingest call, from rocprofv3 PMC passes of this same command line
         # (tools/profile_bench.sh + tools/summarize_prof.py -> profiles/<tag>_traffic.json; FETCH_SIZE/WRITE_SIZE
         # calibrated on known byte counts in the same session). Reported only for the workload it was measured on.
@@ -208,11 +221,15 @@ def main():
                 tj = json.load(open(tf))
             except Exception:
                 continue
-            if tj.get("workload") == out["config"]["workload"] and tj.get("records_per_call") == int(recs_per_launch) \
-                    and args.variant == 0 and ingest_ms > 0:
+            same = all(tj.get(k) == out["config"].get(k) for k in ("workload", "hot_permille", "stream_variant", "mode", "max_entries"))
+            if same and tj.get("records_per_call") == int(recs_per_launch) and args.variant == 0 and ingest_ms > 0:
                 out["roofline"]["traffic"] = round(tj["traffic_bytes_per_call"] / (ingest_ms * 1e-3) / 1e9, 1)
+                out["roofline"]["frac_traffic"] = round(out["roofline"]["traffic"] / HBM_PEAK_GBS, 4)
                 out["roofline"]["traffic_bytes_per_launch"] = int(tj["traffic_bytes_per_call"])
                 out["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
+                if "roofline_evict" in out and tj.get("evict_traffic_bytes_per_call") and tj.get("evicted_flows") == out["roofline_evict"]["flows_per_launch"]:
+                    out["roofline_evict"]["traffic"] = round(tj["evict_traffic_bytes_per_call"] / (ev_ms * 1e-3) / 1e9, 1)
+                    out["roofline_evict"]["traffic_bytes_per_flow"] = round(tj["evict_traffic_bytes_per_call"] / tj["evicted_flows"], 1)
                 break
         # ---- CPU baseline: the oracle (C restatement of pkg/flow.Accounter), 1 core, bounded sample
         if args.cpu_sample > 0 and world == 1:     # rank 0 at N=1 only
@@ -228,7 +245,7 @@ def main():
             acc.close()
             assert consumed == m
             out["cpu_baseline"] = {
-                "value": round(m / cpu_dt / 1e6, 3), "unit": "Mrecords/s", "cores": 1, "kind": "port",
+                "value": round(m / cpu_dt / 1e6, 3), "unit": "Mrecords/s", "cores": 1, "kind": "port", "what": "C restatement of pkg/flow.Accounter (oracle/nfagg_oracle.c); the Go reference cannot be built here",
                 "sample": "first %d records of rank 0's stream (%d flows), oracle Accounter ingest+evict, %.1f s" % (m, len(ev), cpu_dt),
                 "host_cores_available": os.cpu_count(),
             }

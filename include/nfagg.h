@@ -615,6 +615,48 @@ int nfagg_stats_reset_profile(nfagg_handle* h);
 int nfagg_sync(nfagg_handle* h);
 /* The hipStream_t the handle launches on (as void*), for event timing by the caller. */
 void* nfagg_stream(nfagg_handle* h);
+/* ------------------------------------------------------------------ */
+/* Multi-GPU group — N devices behind ONE process.                      */
+/* The agent is one process with one pipeline (pkg/agent/agent.go:387-442;  */
+/* the Accounter is built at agent.go:208-212), so its N GPUs are driven   */
+/* from that process: flows shard by key hash (nfagg_shard_of), member i    */
+/* is an ordinary handle owning shard i. A batch enters on one member's     */
+/* device, is partitioned there in arrival order (stable device partition)  */
+/* and the buckets go to their owners over xGMI; every owner folds its      */
+/* bucket. Flow state needs no collective; the Count-Min / HyperLogLog      */
+/* arrays are all-reduced with RCCL at the eviction tick (librccl is        */
+/* loaded on demand; a single-GPU process never loads it).                  */
+/* ------------------------------------------------------------------ */
+typedef struct nfagg_group nfagg_group;
+
+/* cfg as for nfagg_create, except: device / n_shards / shard_id / ext_sketch are set per member, and max_entries is
+ * CACHE_MAX_FLOWS for the whole group — every shard holds at most ceil(max_entries / n_devices) flows.
+ * devices: HIP ordinals, one per member; all distinct (production), or all equal (several members on ONE GPU: lets a
+ * single-GPU box exercise partition, routing and the stop-on-full logic; the sketch merge then runs as local kernels). */
+int nfagg_group_create(const nfagg_config* cfg, const int32_t* devices, uint32_t n_devices, nfagg_group** out);
+void nfagg_group_destroy(nfagg_group* g);
+const char* nfagg_group_last_error(const nfagg_group* g);   /* NULL: last create error */
+uint32_t nfagg_group_size(const nfagg_group* g);
+/* Member i (shard i): sketch queries, stats, device-side export (nfagg_encode_pb_device ...) go through its handle.
+ * Do not ingest into or evict a member directly. */
+nfagg_handle* nfagg_group_member(nfagg_group* g, uint32_t i);
+
+/* The record arm of Accounter.Account (account.go:81-96) for the group: records in HOST memory, in arrival order.
+ * Chunks go up the members' PCIe links in turn (pinned staging ring of the member), are partitioned on that device
+ * and routed. Returns NFAGG_FULL with *consumed = the leading records folded when the next record's NEW key finds
+ * its shard full (account.go:85): evict the group with NFAGG_REASON_FULL, then resubmit the rest. */
+int nfagg_group_ingest(nfagg_group* g, const void* records, size_t n, size_t* consumed);
+/* Same, records already in DEVICE memory of member `src_member`'s device (16-byte aligned, < 2^31 records). */
+int nfagg_group_ingest_device(nfagg_group* g, uint32_t src_member, const void* d_records, size_t n, size_t* consumed);
+/* len(c.entries) over all shards. */
+int nfagg_group_len(nfagg_group* g, uint64_t* entries);
+/* The per-tick collective: ncclAllReduce(sum, uint64) over each Count-Min array and ncclAllReduce(max, uint32) over each
+ * HLL register array, in place on every member, on the members' streams. Afterwards every member answers
+ * nfagg_hll_estimate / nfagg_cm_query / nfagg_cm_topk for the whole node. */
+int nfagg_group_merge_sketches(nfagg_group* g);
+/* Accounter.evict (account.go:102-124) for every shard: the members' flows back to back in `out` (HOST memory). */
+int nfagg_group_evict(nfagg_group* g, int reason, void* out, size_t cap, size_t* n_out);
+
 /* Testing aid: account for `records` more records in the current eviction epoch without folding any (their sequence
  * numbers are skipped), so that the 2^32-16 records-per-epoch boundary can be reached without feeding 600 GB. */
 int nfagg_debug_skip_sequence(nfagg_handle* h, uint64_t records);

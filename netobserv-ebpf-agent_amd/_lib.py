@@ -137,6 +137,16 @@ SIGNATURES = {
     "nfagg_sync": (C.c_int, [_vp]),
     "nfagg_stream": (_vp, [_vp]),
     "nfagg_debug_skip_sequence": (C.c_int, [_vp, C.c_uint64]),
+    "nfagg_group_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(_vp)]),
+    "nfagg_group_destroy": (None, [_vp]),
+    "nfagg_group_last_error": (C.c_char_p, [_vp]),
+    "nfagg_group_size": (C.c_uint32, [_vp]),
+    "nfagg_group_member": (_vp, [_vp, C.c_uint32]),
+    "nfagg_group_ingest": (C.c_int, [_vp, _vp, _sz, _psz]),
+    "nfagg_group_ingest_device": (C.c_int, [_vp, C.c_uint32, _vp, _sz, _psz]),
+    "nfagg_group_len": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "nfagg_group_merge_sketches": (C.c_int, [_vp]),
+    "nfagg_group_evict": (C.c_int, [_vp, C.c_int, _vp, _sz, _psz]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

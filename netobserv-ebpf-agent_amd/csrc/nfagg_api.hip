@@ -227,65 +227,109 @@ int snapshot_sketches(nfagg_handle* h, bool restore) {
     return NFAGG_OK;
 }
 
-// Fold d[0..chunk) optimistically (h->live exact on entry). On return: *folded = records folded for good,
-// *full = the record after them found the table full (account.go:85), *retry = nothing folded, try a shorter chunk.
-int fold_optimistic(nfagg_handle* h, const void* d, uint64_t chunk, uint64_t* folded, bool* full, bool* retry) {
-    const uint64_t maxe = h->cfg.max_entries, old_live = h->live, seq0 = h->epoch_seq;
-    const uint64_t room = maxe > old_live ? maxe - old_live : 0;
-    *folded = 0; *full = false; *retry = false;
+// The pieces of an optimistic fold (also driven member by member by the multi-GPU group, nfagg_group.inc):
+//   opt_begin    raw copy of the live slots and of the sketches (h->live exact on entry: the caller refreshed the counters)
+//   opt_fold     the fold itself, asynchronous, sequence numbers from h->epoch_seq
+//   opt_result   waits; did the chunk cross max_entries / was it aborted; if it crossed: the index (relative to the
+//                chunk) of the record whose new key found the table full — the (room+1)-th smallest first sequence
+//                number among the slots the chunk claimed
+//   opt_commit   the fold stands: account for it
+//   opt_rollback table, sketches and counters as opt_begin found them
+struct OptState {
+    uint64_t old_live = 0, seq0 = 0, room = 0, n_after = 0;
+    DevCounters before{};
+    bool was_unclustered = false;
+};
+
+int opt_begin(nfagg_handle* h, OptState& st) {
+    const uint64_t maxe = h->cfg.max_entries;
+    st.old_live = h->live; st.seq0 = h->epoch_seq;
+    st.room = maxe > st.old_live ? maxe - st.old_live : 0;
+    st.before = *h->h_ctr;
+    st.was_unclustered = h->epoch_unclustered;
     int rc;
-    const DevCounters before = *h->h_ctr;                     // refreshed by the caller
-    if (old_live) {
-        if ((rc = ensure_bytes(h, &h->d_opt[0], &h->d_opt_cap[0], snapshot_bytes(h->tv, old_live))) != NFAGG_OK) return rc;
-        hipError_t e = launch_snapshot(h->tv, old_live, h->d_opt[0], false, h->stream);
+    if (st.old_live) {
+        if ((rc = ensure_bytes(h, &h->d_opt[0], &h->d_opt_cap[0], snapshot_bytes(h->tv, st.old_live))) != NFAGG_OK) return rc;
+        hipError_t e = launch_snapshot(h->tv, st.old_live, h->d_opt[0], false, h->stream);
         if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "snapshot launch failed: %s", hipGetErrorString(e));
     }
-    if ((rc = snapshot_sketches(h, false)) != NFAGG_OK) return rc;
-    const bool was_unclustered = h->epoch_unclustered;
-    if ((rc = launch_ingest_profiled(h, d, chunk, seq0)) != NFAGG_OK) return rc;
-    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;
-    const uint64_t n_after = h->h_ctr->n_live;
-    const bool aborted = h->h_ctr->aborted != 0;
+    return snapshot_sketches(h, false);
+}
+
+int opt_fold(nfagg_handle* h, const OptState& st, const void* d, uint64_t chunk) {
+    return chunk ? launch_ingest_profiled(h, d, chunk, st.seq0) : NFAGG_OK;
+}
+
+int opt_result(nfagg_handle* h, OptState& st, uint64_t chunk, bool* crossed, bool* aborted, uint64_t* split) {
+    int rc = refresh_counters(h);
+    if (rc != NFAGG_OK) return rc;
+    const uint64_t maxe = h->cfg.max_entries;
+    st.n_after = h->h_ctr->n_live;
+    *aborted = h->h_ctr->aborted != 0;
+    *crossed = *aborted || st.n_after > maxe;
+    *split = 0;
     h->stats.optimistic_folds++;
-    if (!aborted && n_after <= maxe) {                         // no record of the chunk found the table full
-        h->live = h->live_ub = n_after;
-        *folded = chunk;
-        return NFAGG_OK;
-    }
-    // ---- the chunk crossed max_entries: find the split (unless aborted), roll back
+    if (!*crossed || *aborted) return NFAGG_OK;
+    const uint64_t m = st.n_after - st.old_live;               // slots claimed by the chunk; m > room
+    size_t temp_bytes = 0;
+    hipError_t e = launch_sort_u32(nullptr, nullptr, m, nullptr, &temp_bytes, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "sort size query failed: %s", hipGetErrorString(e));
+    if ((rc = ensure_bytes(h, &h->d_opt[2], &h->d_opt_cap[2], 2 * m * sizeof(uint32_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_opt[3], &h->d_opt_cap[3], temp_bytes + 16)) != NFAGG_OK) return rc;
+    uint32_t* seqs = (uint32_t*)h->d_opt[2];
+    e = launch_first_seqs(h->tv, st.old_live, st.n_after, seqs, h->stream);
+    if (e == hipSuccess) e = launch_sort_u32(seqs, seqs + m, m, h->d_opt[3], &temp_bytes, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "split search failed: %s", hipGetErrorString(e));
+    uint32_t split_seq = 0;
+    HIP_TRY(h, hipMemcpyAsync(&split_seq, seqs + m + st.room, sizeof split_seq, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if ((uint64_t)split_seq < st.seq0 || (uint64_t)split_seq - st.seq0 >= chunk)
+        return fail(h, NFAGG_EDEVICE, "optimistic fold: split sequence %u outside the batch [%llu, %llu)", split_seq,
+                    (unsigned long long)st.seq0, (unsigned long long)(st.seq0 + chunk));
+    *split = (uint64_t)split_seq - st.seq0;
+    return NFAGG_OK;
+}
+
+void opt_commit(nfagg_handle* h, const OptState& st, uint64_t chunk) {
+    h->live = h->live_ub = h->h_ctr->n_live;
+    h->epoch_seq = st.seq0 + chunk;
+    h->stats.records_ingested += chunk;
+}
+
+int opt_rollback(nfagg_handle* h, const OptState& st) {
     h->stats.optimistic_rollbacks++;
-    uint64_t split = 0;
-    if (!aborted) {
-        const uint64_t m = n_after - old_live;                 // slots claimed by the chunk; m > room
-        size_t temp_bytes = 0;
-        hipError_t e = launch_sort_u32(nullptr, nullptr, m, nullptr, &temp_bytes, h->stream);
-        if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "sort size query failed: %s", hipGetErrorString(e));
-        if ((rc = ensure_bytes(h, &h->d_opt[2], &h->d_opt_cap[2], 2 * m * sizeof(uint32_t))) != NFAGG_OK) return rc;
-        if ((rc = ensure_bytes(h, &h->d_opt[3], &h->d_opt_cap[3], temp_bytes + 16)) != NFAGG_OK) return rc;
-        uint32_t* seqs = (uint32_t*)h->d_opt[2];
-        e = launch_first_seqs(h->tv, old_live, n_after, seqs, h->stream);
-        if (e == hipSuccess) e = launch_sort_u32(seqs, seqs + m, m, h->d_opt[3], &temp_bytes, h->stream);
-        if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "split search failed: %s", hipGetErrorString(e));
-        uint32_t split_seq = 0;
-        HIP_TRY(h, hipMemcpyAsync(&split_seq, seqs + m + room, sizeof split_seq, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if ((uint64_t)split_seq < seq0 || (uint64_t)split_seq - seq0 >= chunk)
-            return fail(h, NFAGG_EDEVICE, "optimistic fold: split sequence %u outside the batch [%llu, %llu)", split_seq,
-                        (unsigned long long)seq0, (unsigned long long)(seq0 + chunk));
-        split = (uint64_t)split_seq - seq0;
-    }
-    hipError_t e = launch_discard(h->tv, old_live, n_after, h->stream);
-    if (e == hipSuccess && old_live) e = launch_snapshot(h->tv, old_live, h->d_opt[0], true, h->stream);
+    hipError_t e = launch_discard(h->tv, st.old_live, st.n_after, h->stream);
+    if (e == hipSuccess && st.old_live) e = launch_snapshot(h->tv, st.old_live, h->d_opt[0], true, h->stream);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "rollback launch failed: %s", hipGetErrorString(e));
-    if ((rc = snapshot_sketches(h, true)) != NFAGG_OK) return rc;
-    *h->h_ctr = before;                                        // n_live, n_reserved, the diagnostic counters: as before the chunk
+    int rc = snapshot_sketches(h, true);
+    if (rc != NFAGG_OK) return rc;
+    *h->h_ctr = st.before;                                     // n_live, n_finalized, the diagnostic counters: as before the chunk
     HIP_TRY(h, hipMemcpyAsync(h->tv.ctr, h->h_ctr, sizeof(DevCounters), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));               // h_ctr is reused by the next refresh
-    h->epoch_unclustered = was_unclustered;
-    h->live_ub = old_live;
+    h->epoch_unclustered = st.was_unclustered;
+    h->live = h->live_ub = st.old_live;
+    return NFAGG_OK;
+}
+
+// Fold d[0..chunk) optimistically (h->live exact on entry). On return: *folded = records folded for good (the epoch's
+// sequence and record counters advanced by them), *full = the record after them found the table full (account.go:85),
+// *retry = nothing folded, try a shorter chunk.
+int fold_optimistic(nfagg_handle* h, const void* d, uint64_t chunk, uint64_t* folded, bool* full, bool* retry) {
+    *folded = 0; *full = false; *retry = false;
+    OptState st;
+    int rc;
+    if ((rc = opt_begin(h, st)) != NFAGG_OK) return rc;
+    if ((rc = opt_fold(h, st, d, chunk)) != NFAGG_OK) return rc;
+    bool crossed = false, aborted = false;
+    uint64_t split = 0;
+    if ((rc = opt_result(h, st, chunk, &crossed, &aborted, &split)) != NFAGG_OK) return rc;
+    if (!crossed) { opt_commit(h, st, chunk); *folded = chunk; return NFAGG_OK; }   // no record of the chunk found the table full
+    if ((rc = opt_rollback(h, st)) != NFAGG_OK) return rc;
     if (aborted) { *retry = true; return NFAGG_OK; }
-    if (split > 0 && (rc = launch_ingest_profiled(h, d, split, seq0)) != NFAGG_OK) return rc;
-    h->live = h->live_ub = maxe;                               // exactly `room` new keys in the prefix: len(entries) == maxEntries
+    if (split > 0 && (rc = launch_ingest_profiled(h, d, split, st.seq0)) != NFAGG_OK) return rc;
+    h->live = h->live_ub = h->cfg.max_entries;                 // exactly `room` new keys in the prefix: len(entries) == maxEntries
+    h->epoch_seq = st.seq0 + split;
+    h->stats.records_ingested += split;
     *folded = split; *full = true;
     return NFAGG_OK;
 }
@@ -337,8 +381,7 @@ int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t*
                 h->opt_hint = chunk / 4 > safe ? chunk / 4 : safe;
                 continue;
             }
-            h->epoch_seq += folded; consumed += folded;
-            h->stats.records_ingested += folded;
+            consumed += folded;                                   // epoch_seq and the record counter advanced inside
             if (full) {
                 // epochs of this stream are about `folded` records long: do not fold (and throw away) far more than that next time
                 h->opt_hint = folded * 2 > (1ull << 16) ? folded * 2 : (1ull << 16);
@@ -1280,3 +1323,5 @@ int nfagg_stats_reset_profile(nfagg_handle* h) {
 }
 
 }  // extern "C"
+
+#include "nfagg_group.inc"

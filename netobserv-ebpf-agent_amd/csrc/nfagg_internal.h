@@ -173,6 +173,14 @@ hipError_t launch_first_seqs(const TableView& t, uint64_t from, uint64_t to, uin
 // Last launch of an ingest call: identity dwords of the slots claimed since the previous finalize, from records[0..n).
 hipError_t launch_finalize(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
 hipError_t launch_sort_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, void* d_temp, size_t* temp_bytes, hipStream_t s);
+// Stable partition of a batch by key-hash shard (nfagg_partition.hip): buckets back to back in shard order in d_out, the
+// original index of every record in d_orig, bucket sizes in d_count[0..n_shards). Scratch: partition_scratch_bytes(n, n_shards).
+size_t partition_scratch_bytes(uint64_t n, uint32_t n_shards);
+hipError_t launch_partition(const void* d_records, uint64_t n, uint32_t n_shards, void* d_out, uint32_t* d_orig,
+                            uint64_t* d_count, void* d_scratch, hipStream_t s);
+// d_cnt[s] = entries of bucket s with original index < m
+hipError_t launch_partition_prefix_counts(const uint32_t* d_orig, const uint64_t* d_count, uint32_t n_shards, uint64_t m,
+                                          uint64_t* d_cnt, hipStream_t s);
 // Sketch update over a batch (nfagg_sketch.hip).
 hipError_t launch_sketch_update(const SketchView& sk, const TableView& t, const void* d_records, uint64_t n, hipStream_t s);
 hipError_t launch_cm_estimate(const uint64_t* d_cm, uint32_t depth, uint32_t log2w, int side, const void* d_records, uint64_t n,

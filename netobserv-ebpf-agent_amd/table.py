@@ -338,6 +338,98 @@ class FlowTable:
         return L.lib.nfagg_stream(self._h) or 0
 
 
+class _Member(FlowTable):
+    """A group member's handle, borrowed: queries only (sketches, stats, export); the group owns and destroys it."""
+
+    def __init__(self, handle, max_entries):
+        self._h = C.c_void_p(handle)
+        self.max_entries = max_entries
+
+    def close(self):
+        self._h = None
+
+
+class FlowGroup:
+    """nfagg_group (include/nfagg.h): N GPUs behind one process; flows shard by key hash, member i owns shard i."""
+
+    def __init__(self, devices, max_entries=5000, mode=L.MODE_ACCOUNTER, sketches=0, cm_depth=0, cm_log2_width=0, hll_p=0,
+                 staging_records=0, profile=False, ingest_variant=0):
+        cfg = L.Config()
+        cfg.struct_size = C.sizeof(L.Config)
+        cfg.max_entries = max_entries
+        cfg.mode = mode
+        cfg.sketch_flags = sketches
+        cfg.cm_depth, cfg.cm_log2_width, cfg.hll_p = cm_depth, cm_log2_width, hll_p
+        cfg.staging_records = staging_records
+        cfg.profile = 1 if profile else 0
+        cfg.ingest_variant = ingest_variant
+        devs = (C.c_int32 * len(devices))(*devices)
+        self._g = C.c_void_p()
+        rc = L.lib.nfagg_group_create(C.byref(cfg), devs, len(devices), C.byref(self._g))
+        if rc != L.OK:
+            msg = L.lib.nfagg_group_last_error(None)
+            self._g = None
+            raise NfaggError(rc, msg.decode() if msg else "nfagg_group_create failed")
+        self.n = len(devices)
+        self.max_entries = max_entries
+        share = (max_entries + self.n - 1) // self.n
+        self.members = [_Member(L.lib.nfagg_group_member(self._g, i), share) for i in range(self.n)]
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for m in self.members:
+                m.close()
+            L.lib.nfagg_group_destroy(self._g)
+            self._g = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, ok=(L.OK,)):
+        if rc not in ok:
+            msg = L.lib.nfagg_group_last_error(self._g)
+            raise NfaggError(rc, msg.decode() if msg else "")
+        return rc
+
+    def ingest(self, records: np.ndarray):
+        records = np.ascontiguousarray(records)
+        n = records.nbytes // 144
+        consumed = C.c_size_t(0)
+        rc = L.lib.nfagg_group_ingest(self._g, records.ctypes.data_as(C.c_void_p), n, C.byref(consumed))
+        self._check(rc, (L.OK, L.FULL))
+        return rc, consumed.value
+
+    def ingest_device(self, src_member: int, d_ptr: int, n: int):
+        consumed = C.c_size_t(0)
+        rc = L.lib.nfagg_group_ingest_device(self._g, src_member, C.c_void_p(d_ptr), n, C.byref(consumed))
+        self._check(rc, (L.OK, L.FULL))
+        return rc, consumed.value
+
+    def __len__(self):
+        v = C.c_uint64(0)
+        self._check(L.lib.nfagg_group_len(self._g, C.byref(v)))
+        return v.value
+
+    def merge_sketches(self):
+        self._check(L.lib.nfagg_group_merge_sketches(self._g))
+
+    def evict(self, reason=L.REASON_TIMEOUT) -> np.ndarray:
+        cap = max(len(self), 1)
+        out = np.zeros(cap, dtype=FLOW_RECORD)
+        n = C.c_size_t(0)
+        self._check(L.lib.nfagg_group_evict(self._g, reason, out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[: n.value]
+
+
 def key_hash(flow_id_bytes: bytes) -> int:
     buf = (C.c_uint8 * 40).from_buffer_copy(bytes(flow_id_bytes)[:40])
     return L.lib.nfagg_key_hash(buf)

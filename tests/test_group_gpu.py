@@ -1,0 +1,151 @@
+"""The multi-GPU group (include/nfagg.h nfagg_group_*, csrc/nfagg_group.inc) on ONE GPU: several members on device 0
+exercise the stable device partition, the routing, per-shard folds, the stop-on-full logic and the sketch merge (local
+kernels instead of RCCL when members share a device); a one-member group on a distinct device goes through the RCCL
+calls themselves (ncclCommInitAll / ncclAllReduce at N = 1), from Python and from plain C."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import assert_records_equal
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "netobserv-ebpf-agent_amd", "lib")
+
+
+def _zipf(O, n, keys, seed):
+    return O.gen_stream(n, seed=seed, n_keys=keys, thresholds=O.zipf_thresholds(keys, 1.1), variant=1)
+
+
+def reference_group(nf, O, recs, n_shards, max_entries):
+    """The group's contract restated with the oracle: shard j = nfagg_shard_of(key); one sequential Accounter per shard
+    with ceil(max_entries / N) entries; the first record (in arrival order) whose new key finds its shard full stops the
+    group, everything is evicted, the stream goes on."""
+    share = (max_entries + n_shards - 1) // n_shards
+    ids = np.ascontiguousarray(recs["id"])
+    base, fn = ids.ctypes.data, O.lib().orc_shard_of
+    shard = np.fromiter((fn(base + 40 * i, n_shards) for i in range(len(ids))), dtype=np.int64, count=len(ids))
+    out, off = [], 0
+    while True:
+        accs = [O.Accounter(share) for _ in range(n_shards)]
+        stop = len(recs)
+        for j in range(n_shards):
+            mine = np.nonzero(shard[off:] == j)[0] + off
+            c = accs[j].ingest(recs[mine])
+            if c < len(mine):
+                stop = min(stop, int(mine[c]))
+        if stop == len(recs):
+            ev = np.concatenate([a.evict() for a in accs])
+            out.append(("closing", nf.sort_by_key(ev.view(nf.FLOW_RECORD))))
+            return out
+        for a in accs:
+            a.close()
+        accs = [O.Accounter(share) for _ in range(n_shards)]          # redo the epoch up to the stop
+        for j in range(n_shards):
+            mine = np.nonzero(shard[off:stop] == j)[0] + off
+            assert accs[j].ingest(recs[mine]) == len(mine)
+        ev = np.concatenate([a.evict() for a in accs])
+        out.append(("full", nf.sort_by_key(ev.view(nf.FLOW_RECORD))))
+        off = stop
+
+
+def drive_group(nf, grp, recs, batch):
+    out, off, n = [], 0, len(recs)
+    while off < n:
+        hi = min(n, off + batch)
+        while off < hi:
+            rc, c = grp.ingest(recs[off:hi])
+            off += c
+            if rc == nf.FULL:
+                out.append(("full", nf.sort_by_key(grp.evict(nf.REASON_FULL))))
+    out.append(("closing", nf.sort_by_key(grp.evict(nf.REASON_CLOSING))))
+    return out
+
+
+@pytest.mark.parametrize("n_members", [1, 3, 8])
+def test_group_equals_one_accounter_when_nothing_fills(nf, O, n_members):
+    """Sharding is invisible in the result: the members' evictions together = the oracle's single Accounter; the merged
+    sketches = the oracle's sketches of the whole stream, on every member."""
+    recs = _zipf(O, 400_000, 30_000, seed=31)
+    with nf.FlowGroup([0] * n_members, max_entries=1 << 20, sketches=nf.SKETCH_CM | nf.SKETCH_HLL, cm_log2_width=14, hll_p=10,
+                      staging_records=150_000) as grp:
+        assert grp.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
+        want = O.run_accounter(recs, 1 << 20)[0][1]
+        assert len(grp) == len(want)
+        grp.merge_sketches()
+        cs, cd, hs, hd = O.sketches(recs, 4, 14, 10)
+        for m in grp.members:
+            assert np.array_equal(m.sketch_snapshot(nf.CM_SRC), cs) and np.array_equal(m.sketch_snapshot(nf.CM_DST), cd)
+            assert np.array_equal(m.sketch_snapshot(nf.HLL_SRC), hs) and np.array_equal(m.sketch_snapshot(nf.HLL_DST), hd)
+        per_member = [int(m.stats().records_ingested) for m in grp.members]
+        assert sum(per_member) == len(recs) and (n_members == 1 or min(per_member) > 0)
+        got = nf.sort_by_key(grp.evict(nf.REASON_CLOSING))
+    assert_records_equal(got, want)
+
+
+@pytest.mark.parametrize("n_members,max_entries,batch", [(3, 9_000, 1 << 30), (4, 2_000, 50_000), (2, 16_000, 120_000)])
+def test_group_stops_exactly_where_a_shard_fills(nf, O, n_members, max_entries, batch):
+    recs = _zipf(O, 300_000, 40_000, seed=32)
+    want = reference_group(nf, O, recs, n_members, max_entries)
+    assert sum(1 for r, _ in want if r == "full") >= 2
+    with nf.FlowGroup([0] * n_members, max_entries=max_entries, staging_records=100_000) as grp:
+        got = drive_group(nf, grp, recs.view(nf.FLOW_RECORD), batch)
+    assert [(r, len(b)) for r, b in got] == [(r, len(b)) for r, b in want]
+    for k, ((_, g), (_, w)) in enumerate(zip(got, want)):
+        assert_records_equal(g, w, f"group eviction #{k}")
+
+
+def test_group_device_resident_input(nf, O):
+    import torch
+    recs = _zipf(O, 500_000, 50_000, seed=33)
+    d = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()).cuda()
+    with nf.FlowGroup([0, 0, 0, 0], max_entries=1 << 20) as grp:
+        for src, (a, b) in enumerate(((0, 200_000), (200_000, 500_000))):
+            assert grp.ingest_device(src, d.data_ptr() + a * 144, b - a) == (nf.OK, b - a)
+        got = nf.sort_by_key(grp.evict(nf.REASON_CLOSING))
+    assert_records_equal(got, O.run_accounter(recs, 1 << 20)[0][1])
+
+
+def test_one_member_group_goes_through_rccl(nf, O):
+    """Distinct devices -> the RCCL path (communicator + all-reduce), here with the one GPU the box has."""
+    recs = _zipf(O, 100_000, 5_000, seed=34)
+    with nf.FlowGroup([0], max_entries=1 << 16, sketches=nf.SKETCH_CM | nf.SKETCH_HLL, cm_log2_width=12, hll_p=10) as grp:
+        assert grp.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
+        grp.merge_sketches()
+        cs, _, hs, _ = O.sketches(recs, 4, 12, 10)
+        assert np.array_equal(grp.members[0].sketch_snapshot(nf.CM_SRC), cs)
+        assert np.array_equal(grp.members[0].sketch_snapshot(nf.HLL_SRC), hs)
+        assert_records_equal(nf.sort_by_key(grp.evict(nf.REASON_CLOSING)), O.run_accounter(recs, 1 << 16)[0][1])
+
+
+@pytest.fixture(scope="module")
+def group_driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("gdriver") / "nfagg_group_cdriver")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "c", "nfagg_group_cdriver.c"), "-o", exe, "-L", LIBDIR, "-lnfagg", "-Wl,-rpath," + LIBDIR])
+    return exe
+
+
+@pytest.mark.parametrize("devices,max_entries", [("0", 1 << 16), ("0,0,0", 3_000)])
+def test_group_from_plain_c(nf, O, group_driver, tmp_path, devices, max_entries):
+    """No Python, no torch in the process: what the cgo shim of the one-process agent sees. "0" = the RCCL
+    path at N = 1 (librccl loaded by the library itself)."""
+    recs = _zipf(O, 150_000, 4_000, seed=35)
+    src = tmp_path / "records.bin"
+    recs.tofile(src)
+    out = subprocess.check_output([group_driver, str(src), str(tmp_path / "out"), str(max_entries), "60000", devices], text=True).split("\n")
+    n_members = len(devices.split(","))
+    want = reference_group(nf, O, recs, n_members, max_entries)
+    lines = [l.split() for l in out if l.startswith(("full ", "closing "))]        # RCCL prints its version banner on stdout too
+    assert [(r, len(b)) for r, b in want] == [(l[0], int(l[1])) for l in lines]
+    got = np.fromfile(tmp_path / "out.records", dtype=O.FLOW_RECORD)
+    pos = 0
+    for reason, b in want:
+        assert_records_equal(nf.sort_by_key(got[pos:pos + len(b)].view(nf.FLOW_RECORD)), b, reason)
+        pos += len(b)
+    if not any(r == "full" for r, _ in want):                      # sketches see every record of the last epoch... all of them here
+        est = float([l for l in out if l.startswith("hll_src")][0].split()[1])
+        _, _, hs, _ = O.sketches(recs, 4, 20, 14)
+        assert abs(est - O.hll_estimate(hs, 14)) <= np.spacing(est)

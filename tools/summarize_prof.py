@@ -73,7 +73,11 @@ if f_read and f_write:
         bench = json.load(open(f"{src}/pmc_FETCH_SIZE_bench.json"))
     except Exception:
         bench = None
-    ingest = [k for k in per_kernel if any(s in k for s in ("k_fold", "k_merge_overflow", "k_ingest", "k_dedup_claim", "k_dedup_fold"))]
+    ingest = [k for k in per_kernel if any(s in k for s in ("k_fold", "k_merge_overflow", "k_ingest", "k_dedup_claim", "k_dedup_fold", "k_finalize"))]
+    evict = [k for k in per_kernel if "k_evict" in k]
+    ev_calls = max((per_kernel[k].get("FETCH_SIZE", (1, 0))[0] for k in evict), default=1)
+    ev_traffic = (sum(per_kernel[k].get("FETCH_SIZE", (0, 0))[1] for k in evict) * f_read +
+                  sum(per_kernel[k].get("WRITE_SIZE", (0, 0))[1] for k in evict) * f_write) * 1024.0 / max(1, ev_calls)
     calls = max(1, bench["roofline"]["launches"]) if bench else 1
     fetch_kib = sum(per_kernel[k].get("FETCH_SIZE", (0, 0))[1] for k in ingest)
     write_kib = sum(per_kernel[k].get("WRITE_SIZE", (0, 0))[1] for k in ingest)
@@ -84,6 +88,12 @@ if f_read and f_write:
         "factor_read": f_read, "factor_write": f_write,
         "traffic_bytes_per_call": traffic,
         "workload": bench["config"]["workload"] if bench else None,
+        "hot_permille": bench["config"].get("hot_permille") if bench else None,
+        "stream_variant": bench["config"].get("stream_variant") if bench else None,
+        "mode": bench["config"].get("mode") if bench else None,
+        "max_entries": bench["config"].get("max_entries") if bench else None,
+        "evict_traffic_bytes_per_call": ev_traffic if evict else None,
+        "evicted_flows": bench["config"].get("evicted_flows_per_step") if bench else None,
         "records_per_call": bench["roofline"]["records_per_launch"] if bench else None,
         "note": "FETCH_SIZE/WRITE_SIZE summed over the ingest kernels of one nfagg_ingest_device call, each multiplied by the "
                 "factor measured on tools/pmc_calib (lane-strided 144-byte record reads / 144-byte record writes).",
