@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1: nccl (= RCCL, the product path) or gloo "
                     "(rehearsal of the N>1 code path on a 1-GPU box together with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--group-devices", default="", help="ONE process driving several GPUs through nfagg_group_* (how the one-process Go agent "
+                    "runs): comma-separated HIP ordinals, e.g. 0,1,2,3,4,5,6,7 — or 0,0,0,0 to rehearse four members on one GPU. One COMMON "
+                    "stream (slice i arrives on member i's device), partitioned on the device and routed by key hash; not the torchrun contract path")
     args = ap.parse_args()
     if os.environ.get("NFAGG_BENCH_WATCHDOG"):
         import faulthandler
@@ -59,6 +62,8 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.group_devices:
+        return group_main(args, torch)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -289,6 +294,80 @@ def main():
     tab.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def group_main(args, torch):
+    """--group-devices: one process, D members, ONE common stream of D x --records records over D x --flows flows. Slice i of the
+    stream (arrival order: slice 0 first) is resident on member i's device — as if it had come up that member's PCIe link — and
+    enters through nfagg_group_ingest_device(i, ...): stable device partition by key-hash shard, buckets to their owners
+    (hipMemcpyPeerAsync over xGMI between distinct devices), per-member folds; per step one sketch merge (RCCL all-reduce when
+    the devices are distinct) and one eviction of every shard."""
+    import __graft_entry__
+    __graft_entry__.ensure_built()
+    import netobserv_ebpf_agent_amd as nf
+    from netobserv_ebpf_agent_amd import synth
+    devs = [int(x) for x in args.group_devices.split(",")]
+    D, n, keys = len(devs), args.records, args.flows * len(devs)
+    th = synth.zipf_thresholds(keys, args.zipf)
+    slices, outs = [], []
+    for i, d in enumerate(devs):
+        torch.cuda.set_device(d)
+        d_th = torch.from_numpy(th.view(np.int64)).cuda()
+        buf = torch.empty(n * 144, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        synth.stream_device(buf.data_ptr(), n, j0=i * n, seed=2, n_keys=keys, d_thresholds=d_th.data_ptr(), hot_permille=args.hot_permille, variant=0)
+        torch.cuda.synchronize()
+        slices.append(buf)
+        outs.append(torch.empty((2 * args.flows + 4096) * 144, dtype=torch.uint8, device="cuda"))
+    sk_flags = (nf.SKETCH_CM | nf.SKETCH_HLL) if args.sketches else 0
+    max_entries = (args.max_entries or DEFAULT_MAX_ENTRIES) * D
+    grp = nf.FlowGroup(devs, max_entries=max_entries, sketches=sk_flags, profile=True)
+
+    def step():
+        for i in range(D):
+            rc, c = grp.ingest_device(i, slices[i].data_ptr(), n)
+            assert rc == nf.OK and c == n, (rc, c)
+        if args.sketches:
+            grp.merge_sketches()
+        got = grp.evict_device([o.data_ptr() for o in outs], [2 * args.flows + 4096] * D, nf.REASON_TIMEOUT)
+        if args.sketches:
+            for m in grp.members:
+                m.sketch_reset()
+        return sum(got)
+
+    def sync_all():
+        for d in set(devs):
+            torch.cuda.synchronize(d)
+
+    flows = 0
+    for _ in range(args.warmup):
+        flows = step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        flows = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    steps = max(args.steps, 1)
+    sts = [m.stats() for m in grp.members]
+    fold_ms = [st.ingest_kernel_ms / max(st.ingest_launches, 1) for st in sts]
+    out = {
+        "metric": "flow-records/s ingested + evictions/s, 1/2/4/8 GPU; % HBM roofline",
+        "value": round(n * D * steps / dt / 1e6, 3), "unit": "Mrecords/s", "n_gpus": len(set(devs)), "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": "configs[3] shape through nfagg_group_*: ONE common %dM-record Zipf(%.1f) stream over %dk flows, %d members on devices %s, "
+                        "device partition + routing by key hash%s, device-resident input" % (n * D // 1_000_000, args.zipf, keys // 1000, D, devs,
+                                                                                               ", CM+HLL merged per step" if args.sketches else ""),
+            "members": D, "devices": devs, "records_per_member_slice": n, "unique_flows_total": keys, "max_entries_total": max_entries,
+            "evicted_flows_per_step": flows, "parallelism": "one process, group of %d members (distinct devices: %s)" % (D, len(set(devs)) == D),
+            "member_fold_ms_per_launch": [round(x, 3) for x in fold_ms],
+            "member_records_ingested": [int(st.records_ingested) for st in sts],
+        },
+    }
+    print(json.dumps(out), flush=True)
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -656,6 +656,10 @@ int nfagg_group_len(nfagg_group* g, uint64_t* entries);
 int nfagg_group_merge_sketches(nfagg_group* g);
 /* Accounter.evict (account.go:102-124) for every shard: the members' flows back to back in `out` (HOST memory). */
 int nfagg_group_evict(nfagg_group* g, int reason, void* out, size_t cap, size_t* n_out);
+/* Same, shard i's flows into d_out[i] (DEVICE memory of member i's device, cap[i] records, 16-byte aligned), n_out[i] of
+ * them: the input of nfagg_encode_pb_device on member i. NFAGG_TRUNCATED (nothing evicted, n_out = sizes needed) when a
+ * buffer is too small. */
+int nfagg_group_evict_device(nfagg_group* g, int reason, void* const* d_out, const size_t* cap, size_t* n_out);
 
 /* Testing aid: account for `records` more records in the current eviction epoch without folding any (their sequence
  * numbers are skipped), so that the 2^32-16 records-per-epoch boundary can be reached without feeding 600 GB. */

@@ -147,6 +147,7 @@ SIGNATURES = {
     "nfagg_group_len": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "nfagg_group_merge_sketches": (C.c_int, [_vp]),
     "nfagg_group_evict": (C.c_int, [_vp, C.c_int, _vp, _sz, _psz]),
+    "nfagg_group_evict_device": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _psz, _psz]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

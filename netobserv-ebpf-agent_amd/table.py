@@ -429,6 +429,14 @@ class FlowGroup:
         self._check(L.lib.nfagg_group_evict(self._g, reason, out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
         return out[: n.value]
 
+    def evict_device(self, d_ptrs, caps, reason=L.REASON_TIMEOUT):
+        """Shard i's flows into device buffer d_ptrs[i] (on member i's device). Returns the per-member counts."""
+        p = (C.c_void_p * self.n)(*d_ptrs)
+        c = (C.c_size_t * self.n)(*caps)
+        n = (C.c_size_t * self.n)()
+        self._check(L.lib.nfagg_group_evict_device(self._g, reason, p, c, n))
+        return [int(x) for x in n]
+
 
 def key_hash(flow_id_bytes: bytes) -> int:
     buf = (C.c_uint8 * 40).from_buffer_copy(bytes(flow_id_bytes)[:40])
