@@ -51,6 +51,8 @@ struct nfagg_handle {
     void* pinned[2] = {nullptr, nullptr};
     void* d_stage[2] = {nullptr, nullptr};
     hipEvent_t stage_free[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;   // H2D copies of the staging ring: chunk k+1 goes up while chunk k is folded on `stream`
+    hipEvent_t stage_up[2] = {nullptr, nullptr};
     int stage_next = 0;
     bool stage_acquired = false;
     // careful-path scratch
@@ -538,6 +540,8 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
     CREATE_TRY(hipMalloc((void**)&h->d_flags, h->careful_chunk));
     CREATE_TRY(hipMalloc((void**)&h->d_block_counts, ((h->careful_chunk + kFlagBlock - 1) / kFlagBlock) * sizeof(uint32_t)));
     for (int b = 0; b < 2; b++) CREATE_TRY(hipEventCreateWithFlags(&h->stage_free[b], hipEventDisableTiming));
+    for (int b = 0; b < 2; b++) CREATE_TRY(hipEventCreateWithFlags(&h->stage_up[b], hipEventDisableTiming));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     // sketches
     h->sk.cm_depth = cfg.cm_depth; h->sk.cm_log2w = cfg.cm_log2_width; h->sk.hll_p = cfg.hll_p;
     h->sk.flags = cfg.sketch_flags & (NFAGG_SKETCH_CM | NFAGG_SKETCH_HLL);
@@ -586,7 +590,9 @@ void nfagg_destroy(nfagg_handle* h) {
         if (h->pinned[b]) hipHostFree(h->pinned[b]);
         if (h->d_stage[b]) hipFree(h->d_stage[b]);
         if (h->stage_free[b]) hipEventDestroy(h->stage_free[b]);
+        if (h->stage_up[b]) hipEventDestroy(h->stage_up[b]);
     }
+    if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     for (int k = 0; k < 2; k++) {
         if (h->own_sketch[k] && h->sk.cm[k]) hipFree(h->sk.cm[k]);
         if (h->own_sketch[2 + k] && h->sk.hll[k]) hipFree(h->sk.hll[k]);
@@ -666,7 +672,10 @@ int nfagg_ingest(nfagg_handle* h, const void* records, size_t n, size_t* consume
         const int b = h->stage_next;
         HIP_TRY(h, hipEventSynchronize(h->stage_free[b]));
         staged_copy(h->pinned[b], src + consumed * kRecordBytes, m * kRecordBytes, h->cfg.copy_threads);
-        HIP_TRY(h, hipMemcpyAsync(h->d_stage[b], h->pinned[b], m * kRecordBytes, hipMemcpyHostToDevice, h->stream));
+        // the copy runs on its own stream: the fold of the previous chunk (other buffer) is still busy on h->stream
+        HIP_TRY(h, hipMemcpyAsync(h->d_stage[b], h->pinned[b], m * kRecordBytes, hipMemcpyHostToDevice, h->copy_stream));
+        HIP_TRY(h, hipEventRecord(h->stage_up[b], h->copy_stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->stage_up[b], 0));
         size_t c = 0;
         rc = ingest_device_core(h, h->d_stage[b], m, &c);
         HIP_TRY(h, hipEventRecord(h->stage_free[b], h->stream));
@@ -699,7 +708,9 @@ int nfagg_staging_commit(nfagg_handle* h, size_t n, size_t* consumed) {
     HIP_TRY(h, hipSetDevice(h->device));
     const int b = h->stage_next;
     h->stage_acquired = false;
-    HIP_TRY(h, hipMemcpyAsync(h->d_stage[b], h->pinned[b], n * kRecordBytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_stage[b], h->pinned[b], n * kRecordBytes, hipMemcpyHostToDevice, h->copy_stream));
+    HIP_TRY(h, hipEventRecord(h->stage_up[b], h->copy_stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->stage_up[b], 0));
     int rc = ingest_device_core(h, h->d_stage[b], n, consumed);
     HIP_TRY(h, hipEventRecord(h->stage_free[b], h->stream));
     h->stage_next ^= 1;
