@@ -152,7 +152,7 @@ NF_DEV uint4 rec_chunk(const void* recs, uint64_t i, int k) {
 // slots it claims are collected in new_list[] and registered in the live list once per workgroup.
 template <bool SKETCH, bool EXCL>
 NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L, int e, const void* recs, uint32_t seq_base32,
-                              uint32_t* new_list, uint32_t* new_cnt) {
+                              uint32_t* new_list, uint32_t* new_cnt, bool defer) {
     if (L.h64[e] == 0 || L.first_seq[e] == 0xffffffffu) return;   // free, or claimed but never folded into
     uint64_t w[5];
 #pragma unroll
@@ -162,7 +162,7 @@ NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L
     bool fresh = false;
     uint32_t idx = probe_home(t, w, h, x);
     if (idx == kNoSlot) {
-        idx = EXCL ? find_or_claim<true>(t, w, h, &fresh) : find_or_claim(t, w, h);
+        idx = (EXCL && defer) ? find_or_claim<true>(t, w, h, &fresh) : find_or_claim(t, w, h);
         if (idx == kNoSlot) return;
         if (fresh) { x.end = 0; x.start_inv = 0; x.id0 = 0; x.smac_lo = 0; x.dmac_lo = 0; x.flags = 0; new_list[atomicAdd(new_cnt, 1u)] = idx; }
         else load_hints(&t.hot[idx], x);
@@ -362,7 +362,15 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
             }
         }
     }
-    for (int e = tid; e < kEntries; e += kBlock) cache_flush_entry<SKETCH, QUEUE>(t, sk, L, e, recs, seq_base32, new_list, new_cnt);
+    // Deferred claims (collected per workgroup, counted once) only while the claims that the resident workgroups may hold
+    // uncounted — 256 x 1024 — cannot carry the table past its claim limit; otherwise every claim is counted on the spot.
+    bool defer = false;
+    if (QUEUE) {
+        if (tid == 0) new_cnt[3] = (t.defer_claims && ald(&t.ctr->n_live) + 256ull * kEntries <= t.claim_limit) ? 1u : 0u;
+        __syncthreads();
+        defer = new_cnt[3] != 0;
+    }
+    for (int e = tid; e < kEntries; e += kBlock) cache_flush_entry<SKETCH, QUEUE>(t, sk, L, e, recs, seq_base32, new_list, new_cnt, defer);
     if (QUEUE) {
         // the slots this workgroup claimed: one range of the live list, reserved with one atomic. Positions at or beyond
         // claim_limit are given back (find_or_claim's rule, applied to the range): slot emptied, n_live restored, `aborted`.

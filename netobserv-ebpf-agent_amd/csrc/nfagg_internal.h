@@ -125,6 +125,7 @@ struct TableView {
     uint64_t claim_limit;          // hard bound on claimed slots per epoch (3/4 of the table): claims beyond it are refused
     uint64_t epoch_bits;           // current eviction epoch (1..65535) << 48: the tags of this epoch's slots carry it
     uint32_t n_shards, shard_id;
+    uint32_t defer_claims;         // 1: tables of 2^21 slots or more (see nfagg_create)
     SpillView spill;               // set by the API for the two-pass fold
 };
 

@@ -269,14 +269,15 @@ static inline int grid_for(uint64_t n, int block, int max_blocks) {
 hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                                 int variant, hipStream_t s);  // nfagg_ingest_cached.hip
 
-// Default kernel by batch size, measured on configs[1]'s stream (profiles/r01e_batch_size_crossover.txt):
-//   below 6 144 records the direct kernel (one record per lane, HBM atomics; no LDS cache to set up and flush): 14 / 24 us
-//     per 1 024 / 4 096 records against 34 / 35 us for the cached kernel;
-//   below 3 Mi records the single-pass LDS-cached kernel: 0.046 ms per 65 536 records against 0.098 ms for the three
-//     launches of the two-pass fold, 0.46 against 0.51 ms at 2 Mi;
-//   from there the two-pass partitioned fold: 0.74 against 0.79 ms at 4 Mi, 5.5 against 12.5 ms at 100 M.
+// Default kernel by batch size, measured on configs[1]'s stream, per call (round 2: gpurun_out/r02_sweep -> profiles/r02_batch_size_sweep.txt;
+// round 1: profiles/r01e_batch_size_crossover.txt):
+//   below 6 144 records the direct kernel (one record per lane, HBM atomics; no LDS cache to set up and flush);
+//   below 768 Ki records the single-pass LDS-cached kernel: 0.050 ms per 65 536 records against 0.096 ms for the launches
+//     of the two-pass fold, 0.13 against 0.17 ms at 256 Ki;
+//   from there the two-pass partitioned fold: 0.28 against 0.40 ms at 1 Mi, 0.62 against 1.29 ms at 4 Mi (since pass 2 flushes
+//     with plain read-modify-writes the crossover lies at ~0.5 Mi; it was 3 Mi in round 1).
 constexpr uint64_t kDirectMaxBatch = 6144;
-constexpr uint64_t kPartMinBatch = 3u << 20;
+constexpr uint64_t kPartMinBatch = 3u << 18;   // 768 Ki
 constexpr uint64_t kDedupCachedMinBatch = 1u << 16;
 static bool takes_two_pass(int variant, uint64_t n) { return (variant >= 8 && variant <= 11) || (variant == 0 && n >= kPartMinBatch); }
 // Shipping variants: 0 (by batch size), 1 direct, 3/4/5/7 geometries of the single-pass cached kernel, 10/11 two-pass

@@ -102,3 +102,32 @@ def test_epoch_sequence_space_ends_in_an_eviction_not_an_error(nf, O):
         assert tab.stats().seq_space_evictions == 1
         assert tab.ingest(recs[35_000:].view(nf.FLOW_RECORD)) == (nf.OK, 15_000)
         assert_records_equal(nf.sort_by_key(tab.evict()), O.run_accounter(recs[35_000:], 1 << 16)[0][1])
+
+
+def test_two_pass_fold_with_more_new_keys_than_the_table_has_slots(nf, O):
+    """A call large enough for the two-pass fold (>= 768 Ki records) of all-distinct keys into a 65 536-slot table: pass 2 must
+    count its claims on the spot here (deferred, per-workgroup counting could fill a table this small), claims beyond the
+    limit are refused, the call is rolled back and retried shorter until the split is found."""
+    n = 1_500_000
+    recs = O.gen_stream(n, seed=41, n_keys=n, variant=0)
+    recs["id"]["src_port"] = np.arange(n) & 0xffff
+    recs["id"]["dst_port"] = np.arange(n) >> 16
+    with nf.FlowTable(max_entries=5000) as tab:
+        rc, c = tab.ingest(recs.view(nf.FLOW_RECORD))
+        assert (rc, c) == (nf.FULL, 5000)
+        assert_records_equal(nf.sort_by_key(tab.evict(nf.REASON_FULL)), O.run_accounter(recs[:5000], 1 << 20)[0][1])
+
+
+def test_stream_that_keeps_stopping_on_full_uses_its_epoch_length(nf, O):
+    """After the first stop the library sizes its chunks by the length of the last epoch: most folds fit, one short chunk per
+    epoch crosses max_entries and is rolled back."""
+    recs = _zipf(O, 3_000_000, 400_000, seed=42)
+    with nf.FlowTable(max_entries=50_000) as tab:
+        got = drive_product(tab, recs.view(nf.FLOW_RECORD), 1 << 30)
+        st = tab.stats()
+    want = O.run_accounter(recs, 50_000)
+    assert [(r, len(b)) for r, b in got] == [(r, len(b)) for r, b in want]
+    for k, ((_, g), (_, w)) in enumerate(zip(got, want)):
+        assert_records_equal(g, w, f"eviction #{k}")
+    n_full = sum(1 for r, _ in want if r == "full")
+    assert n_full >= 5 and st.optimistic_rollbacks <= n_full + 2 and st.optimistic_folds >= 2 * n_full - 2
