@@ -405,6 +405,193 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
     if (direct) aadd(&t.ctr->n_direct, direct);
 }
 
+// ---- pass 2 ------------------------------------------------------------------------------------------------------
+// Workgroup b folds the records whose indices pass 1 queued for partition b, in its LDS cache, and owns the partition's
+// flows while it runs (plain read-modify-write flush, nfagg_device.h merge_partial_exclusive).
+//
+// More flows in a partition than the cache has entries (beyond ~2 M flows per GPU and epoch): a record whose flow finds the
+// probe window full is not merged into HBM on its own (4-5 atomics per record: 14 ms of a 19 ms call at 10 M flows) but RETRIED:
+// its index, tagged with three more bits of the key hash (the sub-partition), goes back into the front of the workgroup's own
+// queue region — in place: the write position never passes the read position. After the queue: flush, then the retry list is
+// sorted by sub-partition into the free tail of the region (counting sort, counts kept during the first round) and every
+// sub-partition gets a round of its own with a fresh cache: an eighth of the missed flows each. What misses even then is
+// merged on its own, as before. A stream whose partitions fit (configs[1]: ~490 flows each) never enters a second round.
+constexpr int kSubBits = 3, kSubs = 1 << kSubBits;
+constexpr uint32_t kIdxBits = 32 - kSubBits, kIdxMask = (1u << kIdxBits) - 1u;
+
+struct Pass2Lds {                 // after the Cache
+    uint32_t new_list[kEntries];  // slots claimed by the current flush
+    uint32_t new_cnt[4];          // [0] count, [1..2] base of the reserved live-list range, [3] deferred claims allowed
+    uint32_t retry_cnt;           // indices written back for a second round
+    uint32_t sub_cnt[kSubs];      // ... per sub-partition
+    uint32_t sub_off[kSubs + 1];  // counting sort: start of every sub-partition's segment
+    uint32_t sub_fill[kSubs];
+};
+
+// Fold the `count` queue entries at `queue` (0xffffffff = padding). RETRY: misses go back to retry_to[] (tagged with their
+// sub-partition) instead of being merged on their own; COHERENT: the entries were written by this workgroup (read past L1).
+template <bool SKETCH, bool TIMING, bool RETRY, bool COHERENT>
+NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass2Lds& P, const uint32_t* queue, uint32_t count,
+                        uint32_t* retry_to, const void* recs, uint64_t seq_base, uint32_t sub_shift, unsigned long long& direct,
+                        unsigned long long* ph, unsigned long long& tp) {
+#define NF_TICK2(k) do { if (TIMING) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
+    const int tid = threadIdx.x;
+    const uint32_t seq_base32 = (uint32_t)seq_base;
+    auto qload = [&](uint32_t pos) -> uint32_t { return COHERENT ? ald(&queue[pos]) : queue[pos]; };
+    const uint32_t n_tiles = (count + kBlock - 1) / kBlock;
+    // Software pipeline: queue entries two tiles ahead, records one tile ahead; loads are unconditional on a clamped index.
+    bool valid; uint32_t i; Rec r;
+    uint32_t qi_next = 0xffffffffu;
+    {
+        const uint32_t pos = (uint32_t)tid;
+        const uint32_t qi = pos < count ? qload(pos) : 0xffffffffu;
+        valid = qi != 0xffffffffu; i = valid ? (qi & kIdxMask) : 0;
+        if (pos + kBlock < count) qi_next = qload(pos + kBlock);
+        load_record_head(recs, i, r);
+    }
+    for (uint32_t tile = 0; tile < n_tiles; tile++) {
+        bool valid_n; uint32_t i_n; Rec r_n; uint32_t qi_nn = 0xffffffffu;
+        {
+            valid_n = qi_next != 0xffffffffu; i_n = valid_n ? (qi_next & kIdxMask) : 0;
+            const uint64_t p2 = (uint64_t)(tile + 2) * kBlock + tid;
+            if (p2 < count) qi_nn = qload((uint32_t)p2);
+            load_record_head(recs, i_n, r_n);
+        }
+        uint64_t w[5];
+        uint64_t h = 0;
+        if (valid) { r.canonicalize(); r.key_words(w); h = key_hash(w); }
+        const uint32_t seq32 = seq_base32 + i;
+        if (TIMING) { asm volatile("" :: "v"(h)); NF_TICK2(0); }
+        int ent = valid ? cache_claim<false>(L, nullptr, h, w) : -1;
+        NF_TICK2(1);
+        __syncthreads();
+        NF_TICK2(2);
+        if (valid && ent >= 0) ent = cache_fold(L, ent, r, w, seq32);
+        NF_TICK2(3);
+        if (valid && ent < 0) {
+            if (RETRY) {
+                // writes land below (tile + 1) * kBlock; the entries of the next two tiles are in registers already
+                const uint32_t sub = (uint32_t)(h >> sub_shift) & (kSubs - 1);
+                const uint32_t at = atomicAdd(&P.retry_cnt, 1u);
+                atomicAdd(&P.sub_cnt[sub], 1u);
+                retry_to[at] = i | (sub << kIdxBits);
+            } else {
+                // no cache entry even now: merge the record itself (all 144 bytes needed)
+                direct++;
+                Rec full;
+                load_record(recs, i, full);
+                full.canonicalize();
+                Partial p;
+                partial_from_record(full, seq_base + i, p);
+                upsert_partial(t, w, h, p);
+                if (SKETCH) sketch_add(sk, w, full.bytes());
+            }
+        }
+        NF_TICK2(5);
+        valid = valid_n; i = i_n; qi_next = qi_nn;
+#pragma unroll
+        for (int k = 0; k < 28; k++) r.d[k] = r_n.d[k];
+    }
+    __syncthreads();
+#undef NF_TICK2
+}
+
+// Flush the cache into the table (exclusive) and register the slots it claimed: one range of the live list per flush.
+template <bool SKETCH>
+NF_DEV void pass2_flush(const TableView& t, const SketchView& sk, Cache& L, Pass2Lds& P, const void* recs, uint32_t seq_base32) {
+    const int tid = threadIdx.x;
+    // Deferred claims (collected per workgroup, counted once) only while the claims that the resident workgroups may hold
+    // uncounted — 256 x 1024 — cannot carry the table past its claim limit; otherwise every claim is counted on the spot.
+    if (tid == 0) {
+        P.new_cnt[0] = 0;
+        P.new_cnt[3] = (t.defer_claims && ald(&t.ctr->n_live) + 256ull * kEntries <= t.claim_limit) ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool defer = P.new_cnt[3] != 0;
+    for (int e = tid; e < kEntries; e += kBlock) cache_flush_entry<SKETCH, true>(t, sk, L, e, recs, seq_base32, P.new_list, P.new_cnt, defer);
+    // the slots this workgroup claimed: one range of the live list, reserved with one atomic. Positions at or beyond
+    // claim_limit are given back (find_or_claim's rule, applied to the range): slot emptied, n_live restored, `aborted`.
+    __syncthreads();
+    const uint32_t cnt = P.new_cnt[0];
+    if (cnt) {
+        if (tid == 0) {
+            const unsigned long long base = aadd(&t.ctr->n_live, (unsigned long long)cnt);
+            P.new_cnt[1] = (uint32_t)base; P.new_cnt[2] = (uint32_t)(base >> 32);
+            if (base + cnt > t.claim_limit) {
+                const unsigned long long keep = base < t.claim_limit ? t.claim_limit - base : 0ull;
+                aadd(&t.ctr->n_live, ~(unsigned long long)(cnt - keep) + 1ull);
+                atomicExch(&t.ctr->aborted, 1u);
+            }
+        }
+        __syncthreads();
+        const unsigned long long base = (unsigned long long)P.new_cnt[1] | ((unsigned long long)P.new_cnt[2] << 32);
+        for (uint32_t k = tid; k < cnt; k += kBlock) {
+            if (base + k < t.claim_limit) t.live_list[base + k] = P.new_list[k];
+            else ast(&t.hot[P.new_list[k]].tag, (uint64_t)0);
+        }
+    }
+    __syncthreads();
+}
+
+template <bool SKETCH, bool TIMING>
+__global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
+                                                  uint64_t n, uint64_t seq_base) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    Cache& L = *reinterpret_cast<Cache*>(lds_raw);
+    Pass2Lds& P = *reinterpret_cast<Pass2Lds*>(lds_raw + sizeof(Cache));
+    const int tid = threadIdx.x;
+    const uint32_t seq_base32 = (uint32_t)seq_base;
+    const uint32_t tail = q.qtail[blockIdx.x];                        // written by pass 1 (previous kernel)
+    const uint32_t count = tail < q.qcap ? tail : q.qcap;
+    if (count == 0) return;
+    uint32_t* my_queue = q.queue + (uint64_t)blockIdx.x * q.qcap;
+    cache_init(L, tid);
+    if (tid == 0) P.retry_cnt = 0;
+    if (tid < kSubs) { P.sub_cnt[tid] = 0; P.sub_fill[tid] = 0; }
+    __syncthreads();
+    if (tid == 0) q.qtail[blockIdx.x] = 0;                            // every lane has read it: ready for the next batch
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, tp = 0, direct = 0;
+    if (TIMING) tp = __builtin_readcyclecounter();
+    // sub-partition = the three hash bits below the partition's (slot-index bits, nfagg_create); retries need 29-bit indices
+    // and room for the sorted list behind the queue
+    const uint32_t sub_shift = q.part_shift >= (uint32_t)kSubBits ? q.part_shift - kSubBits : 0;
+    const uint32_t sorted_at = (count + 3u) & ~3u;
+    const bool retry_ok = n <= (uint64_t)kIdxMask && (uint64_t)sorted_at + count <= q.qcap;
+    if (retry_ok) pass2_round<SKETCH, TIMING, true, false>(t, sk, L, P, my_queue, count, my_queue, recs, seq_base, sub_shift, direct, ph, tp);
+    else pass2_round<SKETCH, TIMING, false, false>(t, sk, L, P, my_queue, count, nullptr, recs, seq_base, sub_shift, direct, ph, tp);
+    pass2_flush<SKETCH>(t, sk, L, P, recs, seq_base32);
+    const uint32_t m = P.retry_cnt;
+    if (m) {
+        // ---- counting sort of the retry list by sub-partition, into the free tail of this workgroup's region
+        drain_stores();
+        __syncthreads();
+        if (tid == 0) { uint32_t o = 0; for (int s = 0; s < kSubs; s++) { P.sub_off[s] = o; o += P.sub_cnt[s]; } P.sub_off[kSubs] = o; }
+        __syncthreads();
+        uint32_t* sorted = my_queue + sorted_at;
+        for (uint32_t k = tid; k < m; k += kBlock) {
+            const uint32_t e = ald(&my_queue[k]);
+            const uint32_t s = e >> kIdxBits;
+            sorted[P.sub_off[s] + atomicAdd(&P.sub_fill[s], 1u)] = e;
+        }
+        drain_stores();
+        __syncthreads();
+        for (int s = 0; s < kSubs; s++) {
+            const uint32_t c = P.sub_cnt[s];
+            if (c == 0) continue;
+            cache_init(L, tid);
+            __syncthreads();
+            pass2_round<SKETCH, TIMING, false, true>(t, sk, L, P, sorted + P.sub_off[s], c, nullptr, recs, seq_base, sub_shift, direct, ph, tp);
+            pass2_flush<SKETCH>(t, sk, L, P, recs, seq_base32);
+        }
+    }
+    if (TIMING) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[6] += tn_ - tp; }
+        if ((tid & 63) == 0) for (int k = 0; k < 7; k++) aadd(&t.ctr->phase[k], ph[k]);
+    }
+    if (direct) aadd(&t.ctr->n_direct, direct);
+}
+
 // pass 3: the (normally empty) overflow list, one record per lane, merged directly.
 template <bool SKETCH>
 __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs, uint64_t seq_base) {
@@ -428,7 +615,7 @@ __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView 
 template <bool SKETCH, bool T1 = false, bool T2 = false, bool DOOR = true>
 static hipError_t run(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                       uint64_t seq_base, hipStream_t s) {
-    const size_t lds1 = sizeof(Cache) + sizeof(Stage) + (DOOR ? sizeof(Door) : 0), lds2 = sizeof(Cache) + (kEntries + 4) * sizeof(uint32_t);
+    const size_t lds1 = sizeof(Cache) + sizeof(Stage) + (DOOR ? sizeof(Door) : 0), lds2 = sizeof(Cache) + sizeof(Pass2Lds);
     static_assert(sizeof(Cache) + sizeof(Stage) + sizeof(Door) <= 160 * 1024, "pass 1 needs the whole LDS of a CU");
     static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
     int dev_ = 0;
@@ -438,7 +625,7 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold<SKETCH, false, T1, DOOR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold<SKETCH, true, T2>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<SKETCH, T2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -450,7 +637,7 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     hipLaunchKernelGGL((k_fold<SKETCH, false, T1, DOOR>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_fold<SKETCH, true, T2>), dim3(kSpillParts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
+    hipLaunchKernelGGL((k_pass2<SKETCH, T2>), dim3(kSpillParts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_merge_overflow<SKETCH>), dim3(256), dim3(256), 0, s, t, sk, q, d_records, seq_base);

@@ -119,3 +119,28 @@ def test_full_size_properties_100m_records(nf, torch):
         a = nf.sort_by_key(out.cpu().numpy().view(nf.FLOW_RECORD))
         b = nf.sort_by_key(out2.cpu().numpy().view(nf.FLOW_RECORD))
         assert_records_equal(b, a)
+
+
+@pytest.mark.parametrize("sketches", [False, True])
+def test_partitions_with_more_flows_than_cache_entries_take_retry_rounds(nf, O, torch, sketches):
+    """6 M flows in one two-pass call: ~2 900 flows per partition against 1 024 cache entries per pass-2 workgroup. The misses
+    are retried by sub-partition (three more hash bits) instead of being merged one by one; exact against the oracle, every
+    order-dependent field scrambled; then a second call into the same epoch (flows already in the table)."""
+    n, keys = 12_000_000, 6_000_000
+    d = dev_stream(torch, nf.synth, n, seed=51, n_keys=keys, variant=1)          # uniform over the population: every flow ~2 records
+    host = d.cpu().numpy().view(O.FLOW_RECORD)
+    sk = (nf.SKETCH_CM | nf.SKETCH_HLL) if sketches else 0
+    with nf.FlowTable(max_entries=1 << 23, sketches=sk, cm_log2_width=16, hll_p=12) as tab:
+        assert tab.ingest_device(d.data_ptr(), n) == (nf.OK, n)
+        st = tab.stats()
+        assert st.records_bypassed > n // 2                                       # nearly everything spills (no hot head) ...
+        half = n // 2
+        assert tab.ingest_device(d.data_ptr(), half) == (nf.OK, half)             # ... and a second batch meets the flows again
+        want = O.run_accounter(np.concatenate([host, host[:half]]), 1 << 23)[0][1]
+        out = torch.empty(len(want) * 144 + 16, dtype=torch.uint8, device="cuda")
+        assert tab.evict_device(out.data_ptr(), len(want)) == len(want)
+        got = out[: len(want) * 144].cpu().numpy().view(nf.FLOW_RECORD)
+        assert_records_equal(nf.sort_by_key(got), want)
+        if sketches:
+            cm_s, _, hs, _ = O.sketches(np.concatenate([host, host[:half]]), 4, 16, 12)
+            assert np.array_equal(tab.sketch_snapshot(nf.CM_SRC), cm_s) and np.array_equal(tab.sketch_snapshot(nf.HLL_SRC), hs)
