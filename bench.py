@@ -194,7 +194,7 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("k_dedup_claim + k_dedup_fold (one ingest call)" if args.dedup else
-                           "part::k_fold pass 1 + pass 2 (+ k_merge_overflow + k_finalize) = one hash-insert/fold call" if args.variant == 0 else
+                           "part::k_pass1 + part::k_pass2 (+ k_merge_overflow + k_finalize) = one hash-insert/fold call" if args.variant == 0 else
                            "ingest variant %d" % args.variant),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

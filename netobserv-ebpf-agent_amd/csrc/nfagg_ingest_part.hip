@@ -6,12 +6,12 @@
 // ~24 G random atomics/s (profiles/r01_ubench_atomics.txt) — that, not HBM
 // bandwidth, bounds the kernel. Here the tail is not merged record by record:
 //
-//   pass 1  k_fold<.., false>  streams the batch once. Hot flows are folded in the
+//   pass 1  k_pass1            streams the batch once. Hot flows are folded in the
 //           workgroup's LDS flow cache exactly as before; a record whose flow gets no
 //           cache entry is SPILLED: its 32-bit index is appended to the queue of its
 //           partition (2048 partitions = the top bits of its home slot index), staged four at a time in LDS so a
 //           spill costs one 16-byte store and a quarter of an atomic.
-//   pass 2  k_fold<.., true>   one workgroup per partition gathers the spilled
+//   pass 2  k_pass2            one workgroup per partition gathers the spilled
 //           records by index and folds them in ITS LDS cache. A partition holds
 //           ~1/2048 of the flows, so (almost) every flow of it gets an entry.
 //   Both passes end by merging each cache entry into the table ONCE.
@@ -194,42 +194,31 @@ NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L
     if (SKETCH) sketch_add(sk, w, p.bytes);
 }
 
-// QUEUE == false: pass 1 over records[0..n). QUEUE == true: pass 2, workgroup b folds
-// the records whose indices pass 1 queued for partition b.
-template <bool SKETCH, bool QUEUE, bool TIMING, bool DOOR = false>
-__global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
-                                                 uint64_t n, uint64_t seq_base) {
+// ---- pass 1 ------------------------------------------------------------------------------------------------------
+// 256 workgroups stream records[0..n), tiles of 1024 consecutive records, one per lane. Hot flows fold in the workgroup's
+// persistent LDS cache; a record whose flow has no entry is spilled: its index goes to the queue of its flow's partition,
+// staged four at a time in LDS so that a spill costs one 16-byte store and a quarter of an atomic.
+template <bool SKETCH, bool TIMING, bool DOOR>
+__global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
+                                                  uint64_t n, uint64_t seq_base) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     Cache& L = *reinterpret_cast<Cache*>(lds_raw);
-    Stage& S = *reinterpret_cast<Stage*>(lds_raw + sizeof(Cache));   // pass 1 only
-    uint32_t* door = reinterpret_cast<Door*>(lds_raw + sizeof(Cache) + sizeof(Stage))->bits;   // pass 1 with DOOR only
-    uint32_t* new_list = reinterpret_cast<uint32_t*>(lds_raw + sizeof(Cache));                 // pass 2 only: slots claimed by the flush
-    uint32_t* new_cnt = new_list + kEntries;                                                    // [0] count, [1..2] base of the reserved range
+    Stage& S = *reinterpret_cast<Stage*>(lds_raw + sizeof(Cache));
+    uint32_t* door = reinterpret_cast<Door*>(lds_raw + sizeof(Cache) + sizeof(Stage))->bits;   // with DOOR only
     const int tid = threadIdx.x;
     const uint32_t seq_base32 = (uint32_t)seq_base;
-    uint64_t count = n;
-    const uint32_t* my_queue = nullptr;
-    if (QUEUE) {
-        const uint32_t tail = q.qtail[blockIdx.x];                    // written by pass 1 (previous kernel)
-        count = tail < q.qcap ? tail : q.qcap;
-        if (count == 0) return;
-        my_queue = q.queue + (uint64_t)blockIdx.x * q.qcap;
-    }
     cache_init(L, tid);
-    if (QUEUE && tid == 0) new_cnt[0] = 0;
-    if (!QUEUE) for (int p = tid; p < kSpillParts; p += kBlock) S.cnt[p] = 0;
+    for (int p = tid; p < kSpillParts; p += kBlock) S.cnt[p] = 0;
     if (DOOR) for (int p = tid; p < kDoorBits / 32; p += kBlock) door[p] = 0;
     __syncthreads();
-    if (QUEUE && tid == 0) q.qtail[blockIdx.x] = 0;                    // every lane has read it: ready for the next batch
 
     unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, tp = 0;          // TIMING: load+hash, A, barrier, B, barrier, C, flush
 #define NF_TICK(k) do { if (TIMING) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
     if (TIMING) tp = __builtin_readcyclecounter();
-    const uint64_t n_tiles = (count + kBlock - 1) / kBlock;
-    const uint64_t tile0 = QUEUE ? 0 : blockIdx.x, tile_step = QUEUE ? 1 : gridDim.x;
-    unsigned long long skipped = 0, spilled = 0, direct = 0;
-    // pass 1 drain state: this lane serves partitions tid and tid + kBlock. A drained group is stored one tile
-    // later, when the reservation (a returning atomic) has long arrived: no HBM round trip inside a tile.
+    const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
+    unsigned long long skipped = 0, spilled = 0;
+    // drain state: this lane serves partitions tid and tid + kBlock. A drained group is stored one tile later, when the
+    // reservation (a returning atomic) has long arrived: no HBM round trip inside a tile.
     constexpr int kMine = kSpillParts / kBlock;
     uint4 pend_v[kMine];
     uint32_t pend_at[kMine];
@@ -237,33 +226,19 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
 #pragma unroll
     for (int k = 0; k < kMine; k++) { pend[k] = false; pend_at[k] = 0; pend_v[k] = make_uint4(0, 0, 0, 0); }
     uint32_t carry = 0xffffffffu, carry_p = 0;                         // a spill that found its group full: retried next tile
-    // Software pipeline: the records of tile k+1 are requested before tile k is folded (and in pass 2 the
-    // queue entries of tile k+2 before that), so no HBM latency is exposed inside a tile. Loads are
-    // unconditional on a clamped index; `valid` only gates the fold.
+    // Software pipeline: the records of tile k+1 are requested before tile k is folded, so no HBM latency is exposed inside
+    // a tile. Loads are unconditional on a clamped index; `valid` only gates the fold.
     bool valid; uint64_t i; Rec r;
-    uint32_t qi_next = 0xffffffffu;
     {
-        const uint64_t pos = tile0 * kBlock + tid;
-        valid = pos < count; i = valid ? pos : 0;
-        if (QUEUE) {
-            const uint32_t qi = valid ? my_queue[pos] : 0xffffffffu;
-            valid = qi != 0xffffffffu; i = valid ? qi : 0;            // 0xffffffff = padding of a partial group
-            const uint64_t p1 = pos + kBlock;
-            if (p1 < count) qi_next = my_queue[p1];
-        }
+        const uint64_t pos = (uint64_t)blockIdx.x * kBlock + tid;
+        valid = pos < n; i = valid ? pos : 0;
         load_record_head(recs, i, r);
     }
-    for (uint64_t tile = tile0; tile < n_tiles; tile += tile_step) {
-        bool valid_n = false; uint64_t i_n = 0; Rec r_n; uint32_t qi_nn = 0xffffffffu;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        bool valid_n; uint64_t i_n; Rec r_n;
         {
-            const uint64_t pos = (tile + tile_step) * kBlock + tid;
-            if (QUEUE) {
-                valid_n = qi_next != 0xffffffffu; i_n = valid_n ? qi_next : 0;
-                const uint64_t p2 = pos + kBlock;
-                if (p2 < count) qi_nn = my_queue[p2];
-            } else {
-                valid_n = pos < count; i_n = valid_n ? pos : 0;
-            }
+            const uint64_t pos = (tile + gridDim.x) * kBlock + tid;
+            valid_n = pos < n; i_n = valid_n ? pos : 0;
             load_record_head(recs, i_n, r_n);
         }
         uint64_t w[5];
@@ -272,128 +247,81 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
             r.canonicalize();
             r.key_words(w);
             h = key_hash(w);
-            if (!QUEUE && t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id) { valid = false; skipped++; }
+            if (t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id) { valid = false; skipped++; }
         }
         const uint32_t seq32 = seq_base32 + (uint32_t)i;
         if (TIMING) { asm volatile("" :: "v"(h)); NF_TICK(0); }
-        int ent = valid ? cache_claim<DOOR && !QUEUE>(L, door, h, w) : -1;
+        int ent = valid ? cache_claim<DOOR>(L, door, h, w) : -1;
         NF_TICK(1);
         __syncthreads();
         NF_TICK(2);
         if (valid && ent >= 0) ent = cache_fold(L, ent, r, w, seq32);
-        if (!QUEUE) {
 #pragma unroll
-            for (int k = 0; k < kMine; k++) {
-                const int p = tid + k * kBlock;
-                if (pend[k]) {
-                    if (pend_at[k] + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)p * q.qcap + pend_at[k]) = pend_v[k];
-                    else overflow_push(q, pend_v[k]);                 // partition queue full (adversarial skew)
-                    pend[k] = false;
-                }
-                if (S.cnt[p] >= (uint32_t)kStage) {
-                    pend_v[k] = *reinterpret_cast<const uint4*>(S.buf[p]);
-                    S.cnt[p] = 0;
-                    pend_at[k] = aadd(&q.qtail[p], (uint32_t)kStage);
-                    pend[k] = true;
-                }
+        for (int k = 0; k < kMine; k++) {
+            const int p = tid + k * kBlock;
+            if (pend[k]) {
+                if (pend_at[k] + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)p * q.qcap + pend_at[k]) = pend_v[k];
+                else overflow_push(q, pend_v[k]);                     // partition queue full (adversarial skew)
+                pend[k] = false;
+            }
+            if (S.cnt[p] >= (uint32_t)kStage) {
+                pend_v[k] = *reinterpret_cast<const uint4*>(S.buf[p]);
+                S.cnt[p] = 0;
+                pend_at[k] = aadd(&q.qtail[p], (uint32_t)kStage);
+                pend[k] = true;
             }
         }
         NF_TICK(3);
         __syncthreads();
         NF_TICK(4);
-        if (!QUEUE) {
-            if (carry != 0xffffffffu) {
-                const uint32_t at = atomicAdd(&S.cnt[carry_p], 1u);
-                if (at < (uint32_t)kStage) S.buf[carry_p][at] = carry;
-                else overflow_push(q, make_uint4(carry, 0xffffffffu, 0xffffffffu, 0xffffffffu));   // full twice in a row: very rare
-                carry = 0xffffffffu;
-            }
-            if (valid && ent < 0) {
-                const uint32_t p = part_of(h, q.part_shift);
-                const uint32_t at = atomicAdd(&S.cnt[p], 1u);
-                spilled++;
-                if (at < (uint32_t)kStage) S.buf[p][at] = (uint32_t)i;
-                else { carry = (uint32_t)i; carry_p = p; }
-            }
-        } else if (valid && ent < 0) {
-            // no cache entry even here (probe window full): merge the record itself (all 144 bytes needed)
-            direct++;
-            Rec full;
-            load_record(recs, i, full);
-            full.canonicalize();
-            Partial p;
-            partial_from_record(full, seq_base + i, p);
-            upsert_partial(t, w, h, p);
-            if (SKETCH) sketch_add(sk, w, full.bytes());
+        if (carry != 0xffffffffu) {
+            const uint32_t at = atomicAdd(&S.cnt[carry_p], 1u);
+            if (at < (uint32_t)kStage) S.buf[carry_p][at] = carry;
+            else overflow_push(q, make_uint4(carry, 0xffffffffu, 0xffffffffu, 0xffffffffu));   // full twice in a row: very rare
+            carry = 0xffffffffu;
+        }
+        if (valid && ent < 0) {
+            const uint32_t p = part_of(h, q.part_shift);
+            const uint32_t at = atomicAdd(&S.cnt[p], 1u);
+            spilled++;
+            if (at < (uint32_t)kStage) S.buf[p][at] = (uint32_t)i;
+            else { carry = (uint32_t)i; carry_p = p; }
         }
         if (TIMING) NF_TICK(5);
-        valid = valid_n; i = i_n; qi_next = qi_nn;
+        valid = valid_n; i = i_n;
 #pragma unroll
         for (int k = 0; k < 28; k++) r.d[k] = r_n.d[k];
         // next tile: phase A touches only h64/key of NEW entries, the barrier after it orders phase B/C as before;
         // staging appends of this tile are drained after the next tile's first barrier
     }
     __syncthreads();
-    if (!QUEUE) {
-        if (carry != 0xffffffffu) {
-            const uint32_t at = atomicAdd(&S.cnt[carry_p], 1u);
-            if (at < (uint32_t)kStage) S.buf[carry_p][at] = carry;
-            else overflow_push(q, make_uint4(carry, 0xffffffffu, 0xffffffffu, 0xffffffffu));
-        }
-        __syncthreads();
-        // pending groups, then whatever is staged (padded with invalid indices)
+    if (carry != 0xffffffffu) {
+        const uint32_t at = atomicAdd(&S.cnt[carry_p], 1u);
+        if (at < (uint32_t)kStage) S.buf[carry_p][at] = carry;
+        else overflow_push(q, make_uint4(carry, 0xffffffffu, 0xffffffffu, 0xffffffffu));
+    }
+    __syncthreads();
+    // pending groups, then whatever is staged (padded with invalid indices)
 #pragma unroll
-        for (int k = 0; k < kMine; k++) {
-            const int p = tid + k * kBlock;
-            if (pend[k]) {
-                if (pend_at[k] + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)p * q.qcap + pend_at[k]) = pend_v[k];
-                else overflow_push(q, pend_v[k]);
-            }
-            uint32_t c = S.cnt[p];
-            if (c > (uint32_t)kStage) c = kStage;
-            if (c) {
-                const uint32_t at = aadd(&q.qtail[p], (uint32_t)kStage);
-                uint4 v = *reinterpret_cast<const uint4*>(S.buf[p]);
-                if (c < 2) v.y = 0xffffffffu;
-                if (c < 3) v.z = 0xffffffffu;
-                if (c < 4) v.w = 0xffffffffu;
-                if (at + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)p * q.qcap + at) = v;
-                else overflow_push(q, v);
-            }
+    for (int k = 0; k < kMine; k++) {
+        const int p = tid + k * kBlock;
+        if (pend[k]) {
+            if (pend_at[k] + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)p * q.qcap + pend_at[k]) = pend_v[k];
+            else overflow_push(q, pend_v[k]);
+        }
+        uint32_t c = S.cnt[p];
+        if (c > (uint32_t)kStage) c = kStage;
+        if (c) {
+            const uint32_t at = aadd(&q.qtail[p], (uint32_t)kStage);
+            uint4 v = *reinterpret_cast<const uint4*>(S.buf[p]);
+            if (c < 2) v.y = 0xffffffffu;
+            if (c < 3) v.z = 0xffffffffu;
+            if (c < 4) v.w = 0xffffffffu;
+            if (at + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)p * q.qcap + at) = v;
+            else overflow_push(q, v);
         }
     }
-    // Deferred claims (collected per workgroup, counted once) only while the claims that the resident workgroups may hold
-    // uncounted — 256 x 1024 — cannot carry the table past its claim limit; otherwise every claim is counted on the spot.
-    bool defer = false;
-    if (QUEUE) {
-        if (tid == 0) new_cnt[3] = (t.defer_claims && ald(&t.ctr->n_live) + 256ull * kEntries <= t.claim_limit) ? 1u : 0u;
-        __syncthreads();
-        defer = new_cnt[3] != 0;
-    }
-    for (int e = tid; e < kEntries; e += kBlock) cache_flush_entry<SKETCH, QUEUE>(t, sk, L, e, recs, seq_base32, new_list, new_cnt, defer);
-    if (QUEUE) {
-        // the slots this workgroup claimed: one range of the live list, reserved with one atomic. Positions at or beyond
-        // claim_limit are given back (find_or_claim's rule, applied to the range): slot emptied, n_live restored, `aborted`.
-        __syncthreads();
-        const uint32_t cnt = new_cnt[0];
-        if (cnt) {
-            if (tid == 0) {
-                const unsigned long long base = aadd(&t.ctr->n_live, (unsigned long long)cnt);
-                new_cnt[1] = (uint32_t)base; new_cnt[2] = (uint32_t)(base >> 32);
-                if (base + cnt > t.claim_limit) {
-                    const unsigned long long keep = base < t.claim_limit ? t.claim_limit - base : 0ull;
-                    aadd(&t.ctr->n_live, ~(unsigned long long)(cnt - keep) + 1ull);
-                    atomicExch(&t.ctr->aborted, 1u);
-                }
-            }
-            __syncthreads();
-            const unsigned long long base = (unsigned long long)new_cnt[1] | ((unsigned long long)new_cnt[2] << 32);
-            for (uint32_t i = tid; i < cnt; i += kBlock) {
-                if (base + i < t.claim_limit) t.live_list[base + i] = new_list[i];
-                else ast(&t.hot[new_list[i]].tag, (uint64_t)0);
-            }
-        }
-    }
+    for (int e = tid; e < kEntries; e += kBlock) cache_flush_entry<SKETCH, false>(t, sk, L, e, recs, seq_base32, nullptr, nullptr, false);
     if (TIMING) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         NF_TICK(6);
@@ -402,7 +330,6 @@ __global__ __launch_bounds__(kBlock) void k_fold(TableView t, SketchView sk, Spi
 #undef NF_TICK
     if (skipped) aadd(&t.ctr->n_skipped, skipped);
     if (spilled) aadd(&t.ctr->n_bypassed, spilled);
-    if (direct) aadd(&t.ctr->n_direct, direct);
 }
 
 // ---- pass 2 ------------------------------------------------------------------------------------------------------
@@ -622,7 +549,7 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold<SKETCH, false, T1, DOOR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<SKETCH, T1, DOOR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<SKETCH, T2>),
@@ -634,7 +561,7 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     uint64_t grid = 256;
     if (grid > tiles) grid = tiles;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_fold<SKETCH, false, T1, DOOR>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
+    hipLaunchKernelGGL((k_pass1<SKETCH, T1, DOOR>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_pass2<SKETCH, T2>), dim3(kSpillParts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
