@@ -13,16 +13,16 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 rounds = recs_total = 0
 while time.time() < t_end:
-    n = int(rng.choice([50_000, 400_000, 1_500_000, 3_500_000, 5_000_000]))
-    keys = int(rng.choice([1, 50, 3_000, 100_000, 700_000]))
+    n = int(rng.choice([50_000, 400_000, 1_500_000, 3_500_000, 5_000_000, 9_000_000]))
+    keys = int(rng.choice([1, 50, 3_000, 100_000, 700_000, 3_000_000]))      # 3 M: pass-2 partitions overflow their caches (retry rounds)
     s = float(rng.choice([0.0, 0.8, 1.1, 1.6]))
     hot = int(rng.choice([0, 0, 500, 900, 999]))
     dedup = bool(rng.integers(0, 4) == 0)
     variant = int(rng.choice([1, 2] if dedup else [1, 1, 1, 0]))       # stream variant: scrambled fields (2: interfaces for dedup)
     ingest_variant = int(rng.choice([0, 0, 0, 7, 10, 11, 1])) if not dedup else int(rng.choice([0, 0, 1, 10]))
     max_entries = int(rng.choice([1 << 20, 1 << 23, max(2, keys // 3), keys + 5]))
-    if max_entries < keys:
-        n = min(n, 50_000)          # evict-on-full every few records: thousands of eviction round trips, keep the round short
+    if max_entries < keys:          # evict-on-full: bound the number of eviction round trips of a round
+        n = min(n, 50_000 if max_entries < 1000 else 2_000_000)
     sketches = (nf.SKETCH_CM | nf.SKETCH_HLL) if (not dedup and rng.integers(0, 3) == 0) else 0
     n_shards = int(rng.choice([1, 1, 2, 8]))
     shard_id = int(rng.integers(0, n_shards))
@@ -35,7 +35,8 @@ while time.time() < t_end:
     bounds = [0, *cuts.tolist(), n]
     got = []
     with nf.FlowTable(max_entries=max_entries, mode=nf.MODE_KERNEL_DEDUP if dedup else nf.MODE_ACCOUNTER, sketches=sketches,
-                      cm_log2_width=14, hll_p=10, ingest_variant=ingest_variant, n_shards=n_shards, shard_id=shard_id) as tab:
+                      cm_log2_width=14, hll_p=10, ingest_variant=ingest_variant, n_shards=n_shards, shard_id=shard_id,
+                      staging_records=int(rng.choice([0, 1 << 16, 1 << 22, 1 << 23]))) as tab:
         view = recs.view(nf.FLOW_RECORD)
         for a, b in zip(bounds[:-1], bounds[1:]):
             off = a
