@@ -370,7 +370,10 @@ int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t*
         if ((rc = refresh_counters(h)) != NFAGG_OK) break;
         const uint64_t room = maxe > h->live ? maxe - h->live : 0;
         if (room >= rem) continue;
-        if (rem > kCarefulMaxBatch) {
+        // epochs shorter than a claim + flag chunk (tiny CACHE_MAX_FLOWS, the reference's default of 5000 among them): that path
+        // finds the split with two small launches and one round trip, an optimistic fold would be rolled back every time
+        const bool tiny_epochs = h->epoch_len_hint != 0 && h->epoch_len_hint <= kCarefulMaxBatch;
+        if (rem > kCarefulMaxBatch && !tiny_epochs) {
             // ---- optimistic path (see fold_optimistic). How much to try: everything, unless this stream has been stopping on
             // full. Then an epoch is about epoch_len_hint records long: stay clearly inside it while far from its end (the chunk
             // fits, nothing is thrown away), and go for the split with a short chunk when close — a chunk that crosses
