@@ -336,26 +336,26 @@ NF_DEV void merge_partial_exclusive(const TableView& t, uint32_t idx, const Part
     }
 }
 
-// Sketch contribution of one (src IP, dst IP, byte count): Count-Min is linear, so
-// a pre-folded run of records contributes its byte SUM once; HyperLogLog is
-// idempotent. Spec: nfagg_sketch.hip / DESIGN.md §6.
-NF_DEV void sketch_add(const SketchView& sk, const uint64_t w[5], uint64_t bytes) {
-#pragma unroll
-    for (int side = 0; side < 2; side++) {
-        const uint64_t lo = w[2 * side], hi = w[2 * side + 1];
-        if ((sk.flags & 1u) && bytes) {
-            const uint64_t ha = ip_hash(lo, hi, 0), hb = ip_hash(lo, hi, 1) | 1ull;
-            for (uint32_t r = 0; r < sk.cm_depth; r++)
-                aadd(&sk.cm[side][((uint64_t)r << sk.cm_log2w) + cm_index(ha, hb, r, sk.cm_log2w)], bytes);
-        }
-        if (sk.flags & 2u) {
-            const uint64_t h = ip_hash(lo, hi, 2);
-            const uint64_t idx = h >> (64 - sk.hll_p);
-            const uint32_t rho = (uint32_t)__clzll((long long)((h << sk.hll_p) | (1ull << (sk.hll_p - 1)))) + 1u;
-            // registers only grow: a stale smaller value merely costs one atomic
-            if (sk.hll[side][idx] < rho) amax(&sk.hll[side][idx], rho);
-        }
+// Sketch contribution of one (IP, byte count) on one side (0 = src, 1 = dst): Count-Min is linear, so a pre-folded run of
+// records contributes its byte SUM once; HyperLogLog is idempotent. Spec: nfagg_sketch.hip / DESIGN.md §6.
+NF_DEV void sketch_add_side(const SketchView& sk, int side, uint64_t lo, uint64_t hi, uint64_t bytes) {
+    if ((sk.flags & 1u) && bytes) {
+        const uint64_t ha = ip_hash(lo, hi, 0), hb = ip_hash(lo, hi, 1) | 1ull;
+        for (uint32_t r = 0; r < sk.cm_depth; r++)
+            aadd(&sk.cm[side][((uint64_t)r << sk.cm_log2w) + cm_index(ha, hb, r, sk.cm_log2w)], bytes);
     }
+    if (sk.flags & 2u) {
+        const uint64_t h = ip_hash(lo, hi, 2);
+        const uint64_t idx = h >> (64 - sk.hll_p);
+        const uint32_t rho = (uint32_t)__clzll((long long)((h << sk.hll_p) | (1ull << (sk.hll_p - 1)))) + 1u;
+        // registers only grow: a stale smaller value merely costs one atomic
+        if (sk.hll[side][idx] < rho) amax(&sk.hll[side][idx], rho);
+    }
+}
+
+NF_DEV void sketch_add(const SketchView& sk, const uint64_t w[5], uint64_t bytes) {
+    sketch_add_side(sk, 0, w[0], w[1], bytes);
+    sketch_add_side(sk, 1, w[2], w[3], bytes);
 }
 
 // lookup-or-insert + merge of one partial: home-slot fast path, coherent loop otherwise

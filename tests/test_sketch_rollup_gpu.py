@@ -128,3 +128,19 @@ def test_heavy_hitters_match_scalar_oracle(nf, O, k, log2w):
         d_ev = torch.from_numpy(ev.view(np.uint8).reshape(-1).copy()).cuda()
         assert tab.cm_topk(nf.CM_SRC, None, k, device_ptr=d_ev.data_ptr(), n=len(ev)).tobytes() == O.cm_topk(cm_s, 3, log2w, ev.view(O.FLOW_RECORD), 0, k).tobytes()
         assert len(tab.cm_topk(nf.CM_SRC, ev[:0], k)) == 0 and len(tab.cm_topk(nf.CM_SRC, ev, 0)) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hot,n", [(900, 200_000), (999, 70_001), (500, 65), (0, 100_000)])
+def test_wave_combined_sketch_updates_on_hot_endpoints(nf, O, hot, n):
+    """k_sketch_update (the sketch kernel of the direct and the dedup paths) sums the byte counts of the lanes that carry the
+    same address across the wave (DPP reduction) before touching the Count-Min counters: hot endpoints, ragged tails, waves
+    with one, two or many distinct addresses — counters and registers still exactly the scalar oracle's."""
+    th = O.zipf_thresholds(3000, 1.1)
+    recs = O.gen_stream(n, seed=90 + hot, n_keys=3000, thresholds=th, hot_permille=hot, variant=1)
+    cs, cd, hs, hd = O.sketches(recs, 4, 12, 10)
+    for kw in (dict(ingest_variant=1), dict(mode=nf.MODE_KERNEL_DEDUP)):          # direct kernel + k_sketch_update; dedup mode + k_sketch_update
+        with nf.FlowTable(max_entries=1 << 16, sketches=nf.SKETCH_CM | nf.SKETCH_HLL, cm_log2_width=12, hll_p=10, **kw) as tab:
+            assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, n)
+            assert np.array_equal(tab.sketch_snapshot(nf.CM_SRC), cs) and np.array_equal(tab.sketch_snapshot(nf.CM_DST), cd)
+            assert np.array_equal(tab.sketch_snapshot(nf.HLL_SRC), hs) and np.array_equal(tab.sketch_snapshot(nf.HLL_DST), hd)
