@@ -239,7 +239,7 @@ typedef struct nfagg_config {
     uint32_t shard_id;
     uint32_t profile;            /* 1 -> bracket kernels with HIP events (stats) */
     uint32_t ingest_variant;     /* 0 -> default kernels by batch size (direct kernel below 6144 records,
-                                    single-pass LDS-cached kernel below 3 Mi, two-pass partitioned fold from
+                                    single-pass LDS-cached kernel below 768 Ki, two-pass partitioned fold from
                                     there); others are A/B and diagnostic builds, see DESIGN.md §4.1b */
     /* Optional caller-owned DEVICE buffers for the sketches (so that another
      * library, e.g. RCCL via torch.distributed, can all-reduce them in place).
