@@ -149,3 +149,25 @@ def test_group_from_plain_c(nf, O, group_driver, tmp_path, devices, max_entries)
         est = float([l for l in out if l.startswith("hll_src")][0].split()[1])
         _, _, hs, _ = O.sketches(recs, 4, 20, 14)
         assert abs(est - O.hll_estimate(hs, 14)) <= np.spacing(est)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_group_randomised_against_the_contract(nf, O, seed):
+    """Random member counts, capacities (down to a handful of flows per shard: several shards fill inside one call, claims get
+    refused in the smallest tables), batch cuts and staging sizes; every eviction compared with the per-shard-oracle contract."""
+    rng = np.random.default_rng(seed)
+    n_members = int(rng.choice([1, 2, 3, 5, 8]))
+    keys = int(rng.choice([40, 2_000, 30_000]))
+    n = int(rng.choice([30_000, 120_000, 250_000]))
+    max_entries = int(rng.choice([n_members * 3, max(n_members, keys // 4), keys // 2 + 7, 1 << 20]))
+    if max_entries < keys // 8:
+        n = min(n, 40_000)                                            # bounded number of eviction round trips
+    s = float(rng.choice([0.0, 1.1]))
+    th = O.zipf_thresholds(keys, s) if s > 0 else None
+    recs = O.gen_stream(n, seed=int(rng.integers(1, 1 << 30)), n_keys=keys, thresholds=th, hot_permille=int(rng.choice([0, 900])), variant=1)
+    want = reference_group(nf, O, recs, n_members, max_entries)
+    with nf.FlowGroup([0] * n_members, max_entries=max_entries, staging_records=int(rng.choice([0, 1 << 14, 1 << 16]))) as grp:
+        got = drive_group(nf, grp, recs.view(nf.FLOW_RECORD), int(rng.choice([1 << 30, 50_000, 7_777])))
+    assert [(r, len(b)) for r, b in got] == [(r, len(b)) for r, b in want], dict(seed=seed, n_members=n_members, keys=keys, n=n, max_entries=max_entries)
+    for k, ((_, g), (_, w)) in enumerate(zip(got, want)):
+        assert_records_equal(g, w, f"seed {seed}, eviction #{k}")
