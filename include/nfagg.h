@@ -299,7 +299,11 @@ const char* nfagg_last_error(const nfagg_handle* h);
  * leading records folded; returns NFAGG_FULL when it stopped early. */
 int nfagg_ingest(nfagg_handle* h, const void* records, size_t n, size_t* consumed);
 
-/* Same, records already in DEVICE memory of cfg.device (16-byte aligned). */
+/* Same, records already in DEVICE memory of cfg.device (16-byte aligned). ASYNCHRONOUS when the batch cannot fill the table
+ * (live + n <= max_entries): the kernels run on the handle's stream after the call returned and read d_records (the fold,
+ * and k_finalize's copy of the new flows' first records), so the buffer must stay valid and unmodified until the handle
+ * synchronises — nfagg_sync, nfagg_len, nfagg_evict*, nfagg_stats_get, or work ordered after nfagg_stream(h). (The host
+ * variants copy into the library's own staging ring and have no such requirement.) */
 int nfagg_ingest_device(nfagg_handle* h, const void* d_records, size_t n, size_t* consumed);
 
 /* Zero-copy producer path: borrow the next pinned staging buffer
