@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1: nccl (= RCCL, the product path) or gloo "
                     "(rehearsal of the N>1 code path on a 1-GPU box together with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--group-local-fold", action="store_true", help="with --group-devices: NFAGG_GROUP_LOCAL_FOLD (no routing; every member "
+                    "folds its own slice, the members' slots are merged into their owners at the eviction)")
     ap.add_argument("--group-devices", default="", help="ONE process driving several GPUs through nfagg_group_* (how the one-process Go agent "
                     "runs): comma-separated HIP ordinals, e.g. 0,1,2,3,4,5,6,7 — or 0,0,0,0 to rehearse four members on one GPU. One COMMON "
                     "stream (slice i arrives on member i's device), partitioned on the device and routed by key hash; not the torchrun contract path")
@@ -321,7 +323,11 @@ def group_main(args, torch):
         outs.append(torch.empty((2 * args.flows + 4096) * 144, dtype=torch.uint8, device="cuda"))
     sk_flags = (nf.SKETCH_CM | nf.SKETCH_HLL) if args.sketches else 0
     max_entries = (args.max_entries or DEFAULT_MAX_ENTRIES) * D
-    grp = nf.FlowGroup(devs, max_entries=max_entries, sketches=sk_flags, profile=True)
+    if args.group_local_fold:
+        # max_entries stays D x the single-GPU table: it bounds every member undivided, and each member may see every flow
+        outs = [torch.empty((2 * keys // D + 4096) * 144, dtype=torch.uint8, device="cuda:%d" % d) for d in devs]
+    grp = nf.FlowGroup(devs, max_entries=max_entries, sketches=sk_flags, profile=True, local_fold=args.group_local_fold)
+    out_cap = [o.numel() // 144 for o in outs]
 
     def step():
         for i in range(D):
@@ -329,7 +335,7 @@ def group_main(args, torch):
             assert rc == nf.OK and c == n, (rc, c)
         if args.sketches:
             grp.merge_sketches()
-        got = grp.evict_device([o.data_ptr() for o in outs], [2 * args.flows + 4096] * D, nf.REASON_TIMEOUT)
+        got = grp.evict_device([o.data_ptr() for o in outs], out_cap, nf.REASON_TIMEOUT)
         if args.sketches:
             for m in grp.members:
                 m.sketch_reset()
@@ -358,8 +364,11 @@ def group_main(args, torch):
         "dtype": "u64", "data": "synthetic",
         "config": {
             "workload": "configs[3] shape through nfagg_group_*: ONE common %dM-record Zipf(%.1f) stream over %dk flows, %d members on devices %s, "
-                        "device partition + routing by key hash%s, device-resident input" % (n * D // 1_000_000, args.zipf, keys // 1000, D, devs,
-                                                                                               ", CM+HLL merged per step" if args.sketches else ""),
+                        "%s%s, device-resident input" % (n * D // 1_000_000, args.zipf, keys // 1000, D, devs,
+                                                         "local fold, raw slots merged into their owners at the eviction" if args.group_local_fold
+                                                         else "device partition + routing by key hash",
+                                                         ", CM+HLL merged per step" if args.sketches else ""),
+            "group_mode": "local_fold" if args.group_local_fold else "routed",
             "members": D, "devices": devs, "records_per_member_slice": n, "unique_flows_total": keys, "max_entries_total": max_entries,
             "evicted_flows_per_step": flows, "parallelism": "one process, group of %d members (distinct devices: %s)" % (D, len(set(devs)) == D),
             "member_fold_ms_per_launch": [round(x, 3) for x in fold_ms],

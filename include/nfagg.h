@@ -248,8 +248,25 @@ typedef struct nfagg_config {
     void*    ext_sketch[4];
     uint32_t copy_threads;       /* host threads that copy a caller buffer into the pinned staging ring in
                                     nfagg_ingest (one core moves ~28 GB/s, PCIe Gen5 x16 takes ~50); 0 -> 4, 1 -> inline */
-    uint32_t reserved_;
+    uint32_t group_flags;        /* nfagg_group_create only: NFAGG_GROUP_* */
 } nfagg_config;
+
+enum {
+    /* Local-fold ("combiner") mode of a group: no per-record routing. Every member folds the chunks that arrive on ITS
+     * device, whatever their keys, with sequence numbers global to the group; a flow may live on several members at once. At
+     * the eviction the members' raw slots — mergeable partials, sequence tags included — travel to the member that owns the
+     * flow (nfagg_shard_of), are merged there exactly (sums, ORs, maxima, earliest-tag-wins words) and the owner evicts the
+     * flow. xGMI carries 192 bytes per (flow, member) instead of 144 bytes per record, and one hot flow (BASELINE configs[4])
+     * is folded by all GPUs instead of by the one that owns it. Every eviction is bit-identical to one Accounter that saw
+     * the same records between the same two evictions. Differences to the routed mode: max_entries bounds every member's
+     * table, undivided — NFAGG_FULL is returned when ONE member holds max_entries flows and meets a new one, which is never
+     * earlier and can be later than one Accounter over the whole stream would (an eviction may deliver up to
+     * N x max_entries flows); use it where evictions are timeout-driven (CACHE_ACTIVE_TIMEOUT) and max_entries is the
+     * safety net. nfagg_group_len is an upper bound (a flow counts once per member that saw it). After an eviction call
+     * that returned NFAGG_TRUNCATED the group only accepts the repeated eviction (ingest returns NFAGG_FULL): the members'
+     * slots have been merged already. NFAGG_MODE_ACCOUNTER only. */
+    NFAGG_GROUP_LOCAL_FOLD = 1u,
+};
 
 typedef struct nfagg_stats {
     uint64_t records_ingested;   /* accepted into the table (this shard) */
@@ -650,7 +667,9 @@ nfagg_handle* nfagg_group_member(nfagg_group* g, uint32_t i);
  * and routed. Returns NFAGG_FULL with *consumed = the leading records folded when the next record's NEW key finds
  * its shard full (account.go:85): evict the group with NFAGG_REASON_FULL, then resubmit the rest. */
 int nfagg_group_ingest(nfagg_group* g, const void* records, size_t n, size_t* consumed);
-/* Same, records already in DEVICE memory of member `src_member`'s device (16-byte aligned, < 2^31 records). */
+/* Same, records already in DEVICE memory of member `src_member`'s device (16-byte aligned, < 2^31 records). In local-fold
+ * mode the chunk is folded by that member, asynchronously: the buffer must stay valid until the group synchronises
+ * (nfagg_group_len, nfagg_group_evict*), as for nfagg_ingest_device. */
 int nfagg_group_ingest_device(nfagg_group* g, uint32_t src_member, const void* d_records, size_t n, size_t* consumed);
 /* len(c.entries) over all shards. */
 int nfagg_group_len(nfagg_group* g, uint64_t* entries);

@@ -29,6 +29,7 @@ EINVAL, ENODEV, ENOMEM, EDEVICE, ESTATE, ERANGE = -1, -2, -3, -4, -5, -6
 REASON_TIMEOUT, REASON_FULL, REASON_CLOSING = 0, 1, 2
 REASON_NAMES = {0: "timeout", 1: "full", 2: "closing"}
 MODE_ACCOUNTER, MODE_KERNEL_DEDUP = 0, 1
+GROUP_LOCAL_FOLD = 1
 SKETCH_CM, SKETCH_HLL = 1, 2
 CM_SRC, CM_DST, HLL_SRC, HLL_DST = 0, 1, 2, 3
 
@@ -40,7 +41,7 @@ class Config(C.Structure):
         ("cm_depth", C.c_uint32), ("cm_log2_width", C.c_uint32), ("hll_p", C.c_uint32),
         ("staging_records", C.c_uint64), ("n_shards", C.c_uint32), ("shard_id", C.c_uint32),
         ("profile", C.c_uint32), ("ingest_variant", C.c_uint32), ("ext_sketch", C.c_void_p * 4),
-        ("copy_threads", C.c_uint32), ("reserved_", C.c_uint32),
+        ("copy_threads", C.c_uint32), ("group_flags", C.c_uint32),
     ]
 
 

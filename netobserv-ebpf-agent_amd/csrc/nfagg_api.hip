@@ -750,6 +750,23 @@ int nfagg_len(nfagg_handle* h, uint64_t* entries) {
     return NFAGG_OK;
 }
 
+// The bookkeeping that ends an eviction epoch (the kernels have been launched; the device counters are reset by them).
+static int finish_epoch(nfagg_handle* h, int reason, uint64_t flows) {
+    h->stats.evictions[reason]++;
+    h->stats.evicted_flows[reason] += flows;
+    h->epoch_seq = 0; h->live = 0; h->live_ub = 0; h->must_evict = false; h->split_seq = 0;
+    h->epoch_unclustered = false;
+    // The table itself was not touched: the slots of the evicted flows simply belong to a past epoch now.
+    // Tags hold 16 bits of epoch; when they wrap (every 65 535 evictions) the tags are cleared once.
+    uint64_t next_epoch = (h->tv.epoch_bits >> 48) + 1;
+    if (next_epoch > 0xFFFFull) {
+        HIP_TRY(h, hipMemsetAsync(h->tv.hot, 0, h->slots * sizeof(SlotHot), h->stream));
+        next_epoch = 1;
+    }
+    h->tv.epoch_bits = next_epoch << 48;
+    return NFAGG_OK;
+}
+
 static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device, size_t cap, size_t* n_out) {
     if (!h || !n_out || reason < 0 || reason > 2) return fail(h, NFAGG_EINVAL, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -802,19 +819,7 @@ static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device
         return fail(h, NFAGG_EDEVICE, "evict wrote %llu records, expected %llu", (unsigned long long)h->h_ctr->n_out, (unsigned long long)legit);
     if (!out_is_device && legit)
         HIP_TRY(h, hipMemcpy(out, h->d_evict, (size_t)legit * kRecordBytes, hipMemcpyDeviceToHost));
-    h->stats.evictions[reason]++;
-    h->stats.evicted_flows[reason] += legit;
-    h->epoch_seq = 0; h->live = 0; h->live_ub = 0; h->must_evict = false; h->split_seq = 0;
-    h->epoch_unclustered = false;
-    // The table itself was not touched: the slots of the evicted flows simply belong to a past epoch now.
-    // Tags hold 16 bits of epoch; when they wrap (every 65 535 evictions) the tags are cleared once.
-    uint64_t next_epoch = (h->tv.epoch_bits >> 48) + 1;
-    if (next_epoch > 0xFFFFull) {
-        HIP_TRY(h, hipMemsetAsync(h->tv.hot, 0, h->slots * sizeof(SlotHot), h->stream));
-        next_epoch = 1;
-    }
-    h->tv.epoch_bits = next_epoch << 48;
-    return NFAGG_OK;
+    return finish_epoch(h, reason, legit);
 }
 
 int nfagg_evict(nfagg_handle* h, int reason, void* out, size_t cap, size_t* n_out) {

@@ -163,6 +163,7 @@ hipError_t launch_first_flags(const TableView& t, const uint32_t* d_slot_idx, ui
 // record (dense, order unspecified), reset n_live. The table is not touched: the caller bumps the epoch.
 hipError_t launch_sort_slots(const uint32_t* d_in, uint32_t* d_out, uint64_t n, int end_bit, void* d_temp, size_t* temp_bytes, hipStream_t s);
 hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);
+hipError_t launch_evict_filtered(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);
 // Optimistic fold support (nfagg_api.hip: a batch that MIGHT cross max_entries is folded whole and rolled back if it did).
 // Raw copies of the claimed slots live_list[0..n) (hot, cold and — dedup mode — aux lines) into / out of a scratch area laid
 // out as [n hot lines][n cold lines][n aux pairs]; zeroing of the slots live_list[from..to); the first sequence number of
@@ -182,6 +183,11 @@ hipError_t launch_partition(const void* d_records, uint64_t n, uint32_t n_shards
 // d_cnt[s] = entries of bucket s with original index < m
 hipError_t launch_partition_prefix_counts(const uint32_t* d_orig, const uint64_t* d_count, uint32_t n_shards, uint64_t m,
                                           uint64_t* d_cnt, hipStream_t s);
+// Group local-fold mode (nfagg_combine.hip): merge the raw slots at d_raw (k_snapshot's layout, n slots of another member's
+// table) that THIS shard owns (t.n_shards / t.shard_id) into t: phase 1 (identity_phase = false) everything that combines,
+// phase 2 the winner's plain identity dwords. launch_count_owned: owned flows of t itself.
+hipError_t launch_merge_raw(const TableView& t, const void* d_raw, uint64_t n, uint64_t seq_limit, bool identity_phase, hipStream_t s);
+hipError_t launch_count_owned(const TableView& t, uint64_t n_live, uint64_t seq_limit, unsigned long long* d_count, hipStream_t s);
 // Sketch update over a batch (nfagg_sketch.hip).
 hipError_t launch_sketch_update(const SketchView& sk, const TableView& t, const void* d_records, uint64_t n, hipStream_t s);
 hipError_t launch_cm_estimate(const uint64_t* d_cm, uint32_t depth, uint32_t log2w, int side, const void* d_records, uint64_t n,

@@ -145,6 +145,15 @@ __global__ __launch_bounds__(64 * kEvictWaves) void k_evict(TableView t, uint64_
             // this epoch: drop it.
             emit = first_inv != 0 && (uint64_t)(~first_inv) < seq_limit;
             if (!FILTER && !emit) { atomicExch(&t.ctr->error, 6u); emit = true; }   // cannot happen: every claimer merges its record
+            if (FILTER && emit && t.n_shards > 1) {
+                // group local-fold mode: a table also holds flows of other shards (folded where they arrived, merged into
+                // their owners at the tick); only the flows this shard owns leave through it. (A table that was fed through
+                // the shard filter holds nothing else and passes unchanged.)
+                uint64_t kw[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) kw[k] = hq[1 + k];
+                emit = shard_of_hash(key_hash(kw), t.n_shards) == t.shard_id;
+            }
 #pragma unroll
             for (int k = 0; k < 5; k++) { d[2 * k] = (uint32_t)hq[1 + k]; d[2 * k + 1] = (uint32_t)(hq[1 + k] >> 32); }
             const uint64_t bytes = hq[6], end = hq[7], start_inv = hq[8], pf = hq[9], eth_tag = hq[10], dscp_tag = hq[11],
@@ -375,6 +384,20 @@ hipError_t launch_finalize(const TableView& t, const void* d_records, uint64_t n
 
 hipError_t launch_sort_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, void* d_temp, size_t* temp_bytes, hipStream_t s) {
     return hipcub::DeviceRadixSort::SortKeys(d_temp, *temp_bytes, d_in, d_out, (int)n, 0, 32, s);
+}
+
+// force_filter: take the filtered kernel (positions from n_out) although no split is pending — the group's local-fold mode
+// evicts only the flows the shard owns
+hipError_t launch_evict_filtered(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s) {
+    if (n_live) {
+        (void)hipGetLastError();
+        const dim3 grid(grid_for(n_live, 64 * kEvictWaves, 256 * 16)), block(64 * kEvictWaves);
+        hipLaunchKernelGGL(k_evict<true>, grid, block, 0, s, t, n_live, seq_limit, d_out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_reset_after_evict, dim3(1), dim3(1), 0, s, t.ctr, 0);
+    return hipGetLastError();
 }
 
 hipError_t launch_evict(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s) {

@@ -350,10 +350,12 @@ class _Member(FlowTable):
 
 
 class FlowGroup:
-    """nfagg_group (include/nfagg.h): N GPUs behind one process; flows shard by key hash, member i owns shard i."""
+    """nfagg_group (include/nfagg.h): N GPUs behind one process; flows shard by key hash, member i owns shard i.
+    local_fold: NFAGG_GROUP_LOCAL_FOLD — chunks are folded where they arrive, the members' slots are merged into their
+    owners at the eviction."""
 
     def __init__(self, devices, max_entries=5000, mode=L.MODE_ACCOUNTER, sketches=0, cm_depth=0, cm_log2_width=0, hll_p=0,
-                 staging_records=0, profile=False, ingest_variant=0):
+                 staging_records=0, profile=False, ingest_variant=0, local_fold=False):
         cfg = L.Config()
         cfg.struct_size = C.sizeof(L.Config)
         cfg.max_entries = max_entries
@@ -363,6 +365,8 @@ class FlowGroup:
         cfg.staging_records = staging_records
         cfg.profile = 1 if profile else 0
         cfg.ingest_variant = ingest_variant
+        cfg.group_flags = L.GROUP_LOCAL_FOLD if local_fold else 0
+        self.local_fold = bool(local_fold)
         devs = (C.c_int32 * len(devices))(*devices)
         self._g = C.c_void_p()
         rc = L.lib.nfagg_group_create(C.byref(cfg), devs, len(devices), C.byref(self._g))
@@ -372,7 +376,7 @@ class FlowGroup:
             raise NfaggError(rc, msg.decode() if msg else "nfagg_group_create failed")
         self.n = len(devices)
         self.max_entries = max_entries
-        share = (max_entries + self.n - 1) // self.n
+        share = max_entries if local_fold else (max_entries + self.n - 1) // self.n
         self.members = [_Member(L.lib.nfagg_group_member(self._g, i), share) for i in range(self.n)]
 
     def close(self):
@@ -434,7 +438,10 @@ class FlowGroup:
         p = (C.c_void_p * self.n)(*d_ptrs)
         c = (C.c_size_t * self.n)(*caps)
         n = (C.c_size_t * self.n)()
-        self._check(L.lib.nfagg_group_evict_device(self._g, reason, p, c, n))
+        rc = L.lib.nfagg_group_evict_device(self._g, reason, p, c, n)
+        if rc == L.TRUNCATED:        # nothing was evicted; n holds what every member needs
+            raise NfaggError(rc, "device buffers too small, needed %s" % [int(x) for x in n])
+        self._check(rc)
         return [int(x) for x in n]
 
 
