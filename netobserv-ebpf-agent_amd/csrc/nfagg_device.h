@@ -103,6 +103,7 @@ NF_DEV bool tag_is_free(const TableView& t, uint64_t tag) { return (tag & kEpoch
 struct Hints {
     uint64_t end, start_inv, id0, smac_lo, dmac_lo;
     uint32_t flags;
+    uint64_t home_tag;     // probe_home only: the tag it saw in the home slot (find_or_claim's first look, saved a round trip)
 };
 
 NF_DEV void load_hints(const SlotHot* H, Hints& x) {
@@ -135,6 +136,7 @@ NF_DEV uint32_t probe_home(const TableView& t, const uint64_t w[5], uint64_t h, 
     x.id0 = (uint64_t)l6.z | ((uint64_t)l6.w << 32);
     x.smac_lo = (uint64_t)l7.x | ((uint64_t)l7.y << 32);
     x.dmac_lo = (uint64_t)l7.z | ((uint64_t)l7.w << 32);
+    x.home_tag = (uint64_t)a.x | ((uint64_t)a.y << 32);
     return eq ? (uint32_t)idx : kNoSlot;
 }
 
@@ -155,8 +157,12 @@ NF_DEV uint32_t probe_home(const TableView& t, const uint64_t w[5], uint64_t h, 
 // DEFER (pass 2 of the two-pass fold, which owns its partition's flows): a successful claim only takes the slot
 // (tag = claimed) and reports `fresh`; the caller writes key and values itself, publishes the tag and registers the slot
 // in the live list through its workgroup (one n_live atomic per workgroup instead of one per wave).
+// home_tag: what probe_home's plain load saw in the home slot, used as the first trip's look at it. A stale value is
+// harmless: "free" is verified by the CAS (which fails and leads to a real load), "another flow's" cannot go back to free
+// within a fold that stands (only the claim undo of an aborted — rolled back — fold empties a tag), anything else is looked
+// at again.
 template <bool DEFER = false>
-NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t h, bool* fresh = nullptr) {
+NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t h, bool* fresh = nullptr, const uint64_t* home_tag = nullptr) {
     const uint64_t ready = tag_ready(t, h), locked = tag_locked(t, h);
     uint64_t idx = h & t.mask;
     uint64_t probes = 0;
@@ -166,7 +172,7 @@ NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t 
     do {
         if (++trips > kSpinLimit) { atomicExch(&t.ctr->error, 2u); break; }
         SlotHot* s = &t.hot[idx];
-        uint64_t tag = ald(&s->tag);
+        uint64_t tag = (home_tag && trips == 1) ? *home_tag : ald(&s->tag);
         if (tag_is_free(t, tag)) {       // never used, or left over from an earlier epoch (eviction does not clear the table)
             // Claims are bounded: at most claim_limit slots are ever claimed in an epoch, however many new keys an
             // (optimistically folded, nfagg_api.hip) batch holds. The position handed out by the n_live increment decides
@@ -211,8 +217,10 @@ NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t 
             for (int k = 0; k < 5; k++) eq &= (ald(&s->key[k]) == w[k]);
             if (eq) { result = (uint32_t)idx; done = 1; }
             else { idx = (idx + 1) & t.mask; probes++; }
-        } else if (tag == locked) {
-            // same fingerprint, key (and zeroes) not yet published: look again next trip
+        } else if (tag == locked && !DEFER) {
+            // same fingerprint, key (and zeroes) not yet published: look again next trip. (DEFER — pass 2, where every flow
+            // has ONE claimer on the whole chip, this lane: a slot being claimed is another flow's whatever its fingerprint,
+            // and its claimer may be a lane of this workgroup that publishes only after the flush's barrier — move on.)
         } else {
             idx = (idx + 1) & t.mask; probes++;
         }
@@ -288,7 +296,10 @@ NF_DEV void merge_partial(const TableView& t, uint32_t idx, const Partial& p, co
 // read-modify-write of the line: five 16-byte loads, the operators of flow_content.go:28-61 in registers, 16-byte stores.
 // fresh: the slot was claimed (tag = claimed) by this lane just now and holds stale data: nothing is loaded, the
 // partial IS the value; key (write-through, other workgroups compare it), values, then the tag is published.
-NF_DEV void merge_partial_exclusive(const TableView& t, uint32_t idx, const Partial& p, bool fresh, const uint64_t w[5], uint64_t h) {
+// publish = false: the caller publishes the tag of a fresh slot itself, after drain_stores() (pass2_flush: one wait for the whole
+// workgroup, overlapped with the live-list reservation).
+NF_DEV void merge_partial_exclusive(const TableView& t, uint32_t idx, const Partial& p, bool fresh, const uint64_t w[5], uint64_t h,
+                                    bool publish = true) {
     uint4* HL = reinterpret_cast<uint4*>(&t.hot[idx]);
     SlotCold* C = &t.cold[idx];
     uint64_t bytes = 0, end = 0, start_inv = 0, eth_tag = 0, dscp_tag = 0, samp_tag = 0, id0 = 0, smac_lo = 0, dmac_lo = 0;
@@ -331,8 +342,10 @@ NF_DEV void merge_partial_exclusive(const TableView& t, uint32_t idx, const Part
         SlotHot* H = &t.hot[idx];
 #pragma unroll
         for (int k = 0; k < 5; k++) ast(&H->key[k], w[k]);
-        drain_stores();
-        ast(&H->tag, tag_ready(t, h));
+        if (publish) {
+            drain_stores();
+            ast(&H->tag, tag_ready(t, h));
+        }
     }
 }
 

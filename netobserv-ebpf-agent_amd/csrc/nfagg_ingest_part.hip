@@ -150,20 +150,28 @@ NF_DEV uint4 rec_chunk(const void* recs, uint64_t i, int k) {
 // gathered from the batch; the first record's identity dwords are left to k_finalize.
 // EXCL (pass 2): this workgroup owns the flow — plain read-modify-write instead of atomics (merge_partial_exclusive),
 // slots it claims are collected in new_list[] and registered in the live list once per workgroup.
+// The dependent round trips of an entry are kept few (a flush is latency-bound: one entry per lane, 16 waves per CU): the MAC
+// words are requested from the batch together with the home slot's line, before it is known whether they will be needed; the
+// claim takes its first look at the home slot from that line; EXCL: a fresh slot's tag is published by the caller (returns the
+// slot then, kNoSlot otherwise).
 template <bool SKETCH, bool EXCL>
-NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L, int e, const void* recs, uint32_t seq_base32,
-                              uint32_t* new_list, uint32_t* new_cnt, bool defer) {
-    if (L.h64[e] == 0 || L.first_seq[e] == 0xffffffffu) return;   // free, or claimed but never folded into
+NF_DEV uint32_t cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L, int e, const void* recs, uint32_t seq_base32,
+                                  uint32_t* new_list, uint32_t* new_cnt, bool defer, uint64_t* fresh_hash = nullptr) {
+    if (L.h64[e] == 0 || L.first_seq[e] == 0xffffffffu) return kNoSlot;   // free, or claimed but never folded into
     uint64_t w[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
     const uint64_t h = key_hash(w);
+    const uint32_t fs = L.first_seq[e], ss = L.smac_seq[e], ds = L.dmac_seq[e];
+    uint4 s4 = make_uint4(0, 0, 0, 0), d4 = s4, d5 = s4;
+    if (ss != 0xffffffffu) s4 = rec_chunk(recs, (uint64_t)(ss - seq_base32), 4);
+    if (ds != 0xffffffffu) { d4 = rec_chunk(recs, (uint64_t)(ds - seq_base32), 4); d5 = rec_chunk(recs, (uint64_t)(ds - seq_base32), 5); }
     Hints x;
     bool fresh = false;
     uint32_t idx = probe_home(t, w, h, x);
     if (idx == kNoSlot) {
-        idx = (EXCL && defer) ? find_or_claim<true>(t, w, h, &fresh) : find_or_claim(t, w, h);
-        if (idx == kNoSlot) return;
+        idx = (EXCL && defer) ? find_or_claim<true>(t, w, h, &fresh, &x.home_tag) : find_or_claim(t, w, h, nullptr, &x.home_tag);
+        if (idx == kNoSlot) return kNoSlot;
         if (fresh) { x.end = 0; x.start_inv = 0; x.id0 = 0; x.smac_lo = 0; x.dmac_lo = 0; x.flags = 0; new_list[atomicAdd(new_cnt, 1u)] = idx; }
         else load_hints(&t.hot[idx], x);
     }
@@ -171,28 +179,33 @@ NF_DEV void cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L
     p.bytes = L.bytes[e]; p.end = L.end[e]; p.start_inv = L.start_inv[e];
     p.packets = L.packets[e]; p.flags = L.flags[e];
     p.eth_tag = L.eth_tag[e]; p.dscp_tag = L.dscp_tag[e]; p.samp_tag = L.samp_tag[e];
-    const uint32_t fs = L.first_seq[e], ss = L.smac_seq[e], ds = L.dmac_seq[e];
     // The entry's earliest record may be the flow's first: only its sequence number goes into the slot (the tag of
     // id0); k_finalize copies that record's identity dwords from the batch after the last fold kernel of the call.
     p.first_inv = ((uint32_t)(x.id0 >> 32) <= ~fs) ? ~fs : 0u;   // tagged(0, 0) = 0 never wins
     p.ident0 = 0;
     p.smac_inv = 0; p.dmac_inv = 0; p.smac = 0; p.dmac = 0;
     if (ss != 0xffffffffu && (uint32_t)(x.smac_lo >> 32) <= ~ss) {
-        const uint64_t ri = (uint64_t)(ss - seq_base32);
-        const uint4 c4 = rec_chunk(recs, ri, 4);
-        p.smac = (uint64_t)c4.z | ((uint64_t)(c4.w & 0xffffu) << 32);
+        p.smac = (uint64_t)s4.z | ((uint64_t)(s4.w & 0xffffu) << 32);
         p.smac_inv = ~ss;
     }
     if (ds != 0xffffffffu && (uint32_t)(x.dmac_lo >> 32) <= ~ds) {
-        const uint64_t ri = (uint64_t)(ds - seq_base32);
-        const uint4 c4 = rec_chunk(recs, ri, 4), c5 = rec_chunk(recs, ri, 5);
-        p.dmac = (uint64_t)(c4.w >> 16) | ((uint64_t)c5.x << 16);
+        p.dmac = (uint64_t)(d4.w >> 16) | ((uint64_t)d5.x << 16);
         p.dmac_inv = ~ds;
     }
-    if (EXCL) merge_partial_exclusive(t, idx, p, fresh, w, h);
+    if (EXCL) merge_partial_exclusive(t, idx, p, fresh, w, h, false);
     else merge_partial(t, idx, p, x);
     if (SKETCH) sketch_add(sk, w, p.bytes);
+    if (EXCL && fresh) { *fresh_hash = h; return idx; }
+    return kNoSlot;
 }
+
+// A queue entry = the record's index in the batch, and above it (batches of up to 2^29 - 1 records: always, in practice) three
+// more bits of the key hash, the flow's SUB-PARTITION: pass 2 splits what a partition's cache could not take into eight by it.
+// (Tried and dropped: giving up the first round after a few probe tiles when most of them miss, and sorting the rest of the
+// queue by these bits without gathering a record — no gain even on a uniform 10 M-flow stream, 30.4 against 30.6 ms.)
+constexpr int kSubBits = 3, kSubs = 1 << kSubBits;
+constexpr uint32_t kIdxBits = 32 - kSubBits, kIdxMask = (1u << kIdxBits) - 1u;
+NF_DEV uint32_t sub_shift_of(const SpillView& q) { return q.part_shift >= (uint32_t)kSubBits ? q.part_shift - kSubBits : 0; }
 
 // ---- pass 1 ------------------------------------------------------------------------------------------------------
 // 256 workgroups stream records[0..n), tiles of 1024 consecutive records, one per lane. Hot flows fold in the workgroup's
@@ -217,6 +230,8 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
     if (TIMING) tp = __builtin_readcyclecounter();
     const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
     unsigned long long skipped = 0, spilled = 0;
+    const bool tag_on = n <= (uint64_t)kIdxMask;                       // the index leaves room for the sub-partition bits
+    const uint32_t sub_shift = sub_shift_of(q);
     // drain state: this lane serves partitions tid and tid + kBlock. A drained group is stored one tile later, when the
     // reservation (a returning atomic) has long arrived: no HBM round trip inside a tile.
     constexpr int kMine = kSpillParts / kBlock;
@@ -283,9 +298,10 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
         if (valid && ent < 0) {
             const uint32_t p = part_of(h, q.part_shift);
             const uint32_t at = atomicAdd(&S.cnt[p], 1u);
+            const uint32_t qi = (uint32_t)i | (tag_on ? ((uint32_t)(h >> sub_shift) & (uint32_t)(kSubs - 1)) << kIdxBits : 0u);
             spilled++;
-            if (at < (uint32_t)kStage) S.buf[p][at] = (uint32_t)i;
-            else { carry = (uint32_t)i; carry_p = p; }
+            if (at < (uint32_t)kStage) S.buf[p][at] = qi;
+            else { carry = qi; carry_p = p; }
         }
         if (TIMING) NF_TICK(5);
         valid = valid_n; i = i_n;
@@ -343,9 +359,6 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
 // sorted by sub-partition into the free tail of the region (counting sort, counts kept during the first round) and every
 // sub-partition gets a round of its own with a fresh cache: an eighth of the missed flows each. What misses even then is
 // merged on its own, as before. A stream whose partitions fit (configs[1]: ~490 flows each) never enters a second round.
-constexpr int kSubBits = 3, kSubs = 1 << kSubBits;
-constexpr uint32_t kIdxBits = 32 - kSubBits, kIdxMask = (1u << kIdxBits) - 1u;
-
 struct Pass2Lds {                 // after the Cache
     uint32_t new_list[kEntries];  // slots claimed by the current flush
     uint32_t new_cnt[4];          // [0] count, [1..2] base of the reserved live-list range, [3] deferred claims allowed
@@ -359,7 +372,7 @@ struct Pass2Lds {                 // after the Cache
 // sub-partition) instead of being merged on their own; COHERENT: the entries were written by this workgroup (read past L1).
 template <bool SKETCH, bool TIMING, bool RETRY, bool COHERENT>
 NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass2Lds& P, const uint32_t* queue, uint32_t count,
-                        uint32_t* retry_to, const void* recs, uint64_t seq_base, uint32_t sub_shift, unsigned long long& direct,
+                        uint32_t* retry_to, const void* recs, uint64_t seq_base, uint32_t idx_mask, unsigned long long& direct,
                         unsigned long long* ph, unsigned long long& tp) {
 #define NF_TICK2(k) do { if (TIMING) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
     const int tid = threadIdx.x;
@@ -368,18 +381,19 @@ NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass
     const uint32_t n_tiles = (count + kBlock - 1) / kBlock;
     // Software pipeline: queue entries two tiles ahead, records one tile ahead; loads are unconditional on a clamped index.
     bool valid; uint32_t i; Rec r;
-    uint32_t qi_next = 0xffffffffu;
+    uint32_t qi_next = 0xffffffffu, qi_cur = 0xffffffffu;
     {
         const uint32_t pos = (uint32_t)tid;
         const uint32_t qi = pos < count ? qload(pos) : 0xffffffffu;
-        valid = qi != 0xffffffffu; i = valid ? (qi & kIdxMask) : 0;
+        valid = qi != 0xffffffffu; i = valid ? (qi & idx_mask) : 0;
+        qi_cur = qi;
         if (pos + kBlock < count) qi_next = qload(pos + kBlock);
         load_record_head(recs, i, r);
     }
     for (uint32_t tile = 0; tile < n_tiles; tile++) {
         bool valid_n; uint32_t i_n; Rec r_n; uint32_t qi_nn = 0xffffffffu;
         {
-            valid_n = qi_next != 0xffffffffu; i_n = valid_n ? (qi_next & kIdxMask) : 0;
+            valid_n = qi_next != 0xffffffffu; i_n = valid_n ? (qi_next & idx_mask) : 0;
             const uint64_t p2 = (uint64_t)(tile + 2) * kBlock + tid;
             if (p2 < count) qi_nn = qload((uint32_t)p2);
             load_record_head(recs, i_n, r_n);
@@ -398,10 +412,9 @@ NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass
         if (valid && ent < 0) {
             if (RETRY) {
                 // writes land below (tile + 1) * kBlock; the entries of the next two tiles are in registers already
-                const uint32_t sub = (uint32_t)(h >> sub_shift) & (kSubs - 1);
                 const uint32_t at = atomicAdd(&P.retry_cnt, 1u);
-                atomicAdd(&P.sub_cnt[sub], 1u);
-                retry_to[at] = i | (sub << kIdxBits);
+                atomicAdd(&P.sub_cnt[qi_cur >> kIdxBits], 1u);
+                retry_to[at] = qi_cur;                            // index + sub-partition bits, as pass 1 queued it
             } else {
                 // no cache entry even now: merge the record itself (all 144 bytes needed)
                 direct++;
@@ -415,7 +428,7 @@ NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass
             }
         }
         NF_TICK2(5);
-        valid = valid_n; i = i_n; qi_next = qi_nn;
+        valid = valid_n; i = i_n; qi_cur = qi_next; qi_next = qi_nn;
 #pragma unroll
         for (int k = 0; k < 28; k++) r.d[k] = r_n.d[k];
     }
@@ -423,26 +436,36 @@ NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass
 #undef NF_TICK2
 }
 
+// Before a round (lane 0; the round's barriers publish it): may this flush collect its claims and count them once? Only while
+// the claims that workgroups may hold uncounted cannot carry the table past its claim limit — 256 resident workgroups x 1024,
+// and as much again for what is registered between this look at n_live and the flush it is used in (a round earlier).
+constexpr uint32_t kPackRecords = 768;
+NF_DEV void pass2_defer_ok(const TableView& t, Pass2Lds& P) {
+    P.new_cnt[0] = 0;
+    P.new_cnt[3] = (t.defer_claims && ald(&t.ctr->n_live) + 512ull * kEntries <= t.claim_limit) ? 1u : 0u;
+}
+
 // Flush the cache into the table (exclusive) and register the slots it claimed: one range of the live list per flush.
 template <bool SKETCH>
 NF_DEV void pass2_flush(const TableView& t, const SketchView& sk, Cache& L, Pass2Lds& P, const void* recs, uint32_t seq_base32) {
+    static_assert(kEntries == kBlock, "one cache entry per lane");
     const int tid = threadIdx.x;
-    // Deferred claims (collected per workgroup, counted once) only while the claims that the resident workgroups may hold
-    // uncounted — 256 x 1024 — cannot carry the table past its claim limit; otherwise every claim is counted on the spot.
-    if (tid == 0) {
-        P.new_cnt[0] = 0;
-        P.new_cnt[3] = (t.defer_claims && ald(&t.ctr->n_live) + 256ull * kEntries <= t.claim_limit) ? 1u : 0u;
-    }
-    __syncthreads();
+    // P.new_cnt[0] = 0 and P.new_cnt[3] (deferred claims allowed, pass2_defer_ok) were written before the round: barriers since.
     const bool defer = P.new_cnt[3] != 0;
-    for (int e = tid; e < kEntries; e += kBlock) cache_flush_entry<SKETCH, true>(t, sk, L, e, recs, seq_base32, P.new_list, P.new_cnt, defer);
+    uint64_t fresh_hash = 0;
+    const uint32_t fresh_idx = cache_flush_entry<SKETCH, true>(t, sk, L, tid, recs, seq_base32, P.new_list, P.new_cnt, defer, &fresh_hash);
     // the slots this workgroup claimed: one range of the live list, reserved with one atomic. Positions at or beyond
     // claim_limit are given back (find_or_claim's rule, applied to the range): slot emptied, n_live restored, `aborted`.
     __syncthreads();
     const uint32_t cnt = P.new_cnt[0];
+    unsigned long long base0 = 0;
+    if (cnt && tid == 0) base0 = aadd(&t.ctr->n_live, (unsigned long long)cnt);     // in flight while the stores drain
+    // key and value stores of the fresh slots are acknowledged: their tags may say `ready` (one wait per lane, all lanes at once)
+    drain_stores();
+    if (fresh_idx != kNoSlot) ast(&t.hot[fresh_idx].tag, tag_ready(t, fresh_hash));
     if (cnt) {
         if (tid == 0) {
-            const unsigned long long base = aadd(&t.ctr->n_live, (unsigned long long)cnt);
+            const unsigned long long base = base0;
             P.new_cnt[1] = (uint32_t)base; P.new_cnt[2] = (uint32_t)(base >> 32);
             if (base + cnt > t.claim_limit) {
                 const unsigned long long keep = base < t.claim_limit ? t.claim_limit - base : 0ull;
@@ -473,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
     if (count == 0) return;
     uint32_t* my_queue = q.queue + (uint64_t)blockIdx.x * q.qcap;
     cache_init(L, tid);
-    if (tid == 0) P.retry_cnt = 0;
+    if (tid == 0) { P.retry_cnt = 0; pass2_defer_ok(t, P); }
     if (tid < kSubs) { P.sub_cnt[tid] = 0; P.sub_fill[tid] = 0; }
     __syncthreads();
     if (tid == 0) q.qtail[blockIdx.x] = 0;                            // every lane has read it: ready for the next batch
@@ -481,12 +504,15 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
     if (TIMING) tp = __builtin_readcyclecounter();
     // sub-partition = the three hash bits below the partition's (slot-index bits, nfagg_create); retries need 29-bit indices
     // and room for the sorted list behind the queue
-    const uint32_t sub_shift = q.part_shift >= (uint32_t)kSubBits ? q.part_shift - kSubBits : 0;
+    const bool tagged = n <= (uint64_t)kIdxMask;                      // pass 1 put the sub-partition bits above the index
+    const uint32_t idx_mask = tagged ? kIdxMask : 0xffffffffu;
     const uint32_t sorted_at = (count + 3u) & ~3u;
-    const bool retry_ok = n <= (uint64_t)kIdxMask && (uint64_t)sorted_at + count <= q.qcap;
-    if (retry_ok) pass2_round<SKETCH, TIMING, true, false>(t, sk, L, P, my_queue, count, my_queue, recs, seq_base, sub_shift, direct, ph, tp);
-    else pass2_round<SKETCH, TIMING, false, false>(t, sk, L, P, my_queue, count, nullptr, recs, seq_base, sub_shift, direct, ph, tp);
+    const bool retry_ok = tagged && (uint64_t)sorted_at + count <= q.qcap;
+    if (retry_ok) pass2_round<SKETCH, TIMING, true, false>(t, sk, L, P, my_queue, count, my_queue, recs, seq_base, idx_mask, direct, ph, tp);
+    else pass2_round<SKETCH, TIMING, false, false>(t, sk, L, P, my_queue, count, nullptr, recs, seq_base, idx_mask, direct, ph, tp);
+#define NF_TICK3(k) do { if (TIMING) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
     pass2_flush<SKETCH>(t, sk, L, P, recs, seq_base32);
+    NF_TICK3(4);                                                      // phase 4 = the flushes, phase 6 = sort + cache set-up
     const uint32_t m = P.retry_cnt;
     if (m) {
         // ---- counting sort of the retry list by sub-partition, into the free tail of this workgroup's region
@@ -502,15 +528,25 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
         }
         drain_stores();
         __syncthreads();
-        for (int s = 0; s < kSubs; s++) {
-            const uint32_t c = P.sub_cnt[s];
-            if (c == 0) continue;
-            cache_init(L, tid);
-            __syncthreads();
-            pass2_round<SKETCH, TIMING, false, true>(t, sk, L, P, sorted + P.sub_off[s], c, nullptr, recs, seq_base, sub_shift, direct, ph, tp);
-            pass2_flush<SKETCH>(t, sk, L, P, recs, seq_base32);
+        // one round per run of consecutive sub-partitions that surely fits a cache (records >= flows): a partition with few
+        // misses gets one more round, not eight
+        for (int s = 0; s < kSubs;) {
+            uint32_t c = P.sub_cnt[s];
+            int e = s + 1;
+            while (e < kSubs && c + P.sub_cnt[e] <= kPackRecords) { c += P.sub_cnt[e]; e++; }
+            if (c) {
+                cache_init(L, tid);
+                if (tid == 0) pass2_defer_ok(t, P);
+                __syncthreads();
+                NF_TICK3(6);
+                pass2_round<SKETCH, TIMING, false, true>(t, sk, L, P, sorted + P.sub_off[s], c, nullptr, recs, seq_base, idx_mask, direct, ph, tp);
+                pass2_flush<SKETCH>(t, sk, L, P, recs, seq_base32);
+                NF_TICK3(4);
+            }
+            s = e;
         }
     }
+#undef NF_TICK3
     if (TIMING) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[6] += tn_ - tp; }
@@ -521,13 +557,16 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
 
 // pass 3: the (normally empty) overflow list, one record per lane, merged directly.
 template <bool SKETCH>
-__global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs, uint64_t seq_base) {
+__global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
+                                                        uint64_t n, uint64_t seq_base) {
+    const uint32_t idx_mask = n <= (uint64_t)kIdxMask ? kIdxMask : 0xffffffffu;
     uint32_t count = *q.ovf_tail;
     if (count > q.ovf_cap) count = q.ovf_cap;
     unsigned long long direct = 0;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t i = q.ovf[k];
-        if (i == 0xffffffffu) continue;
+        const uint32_t qi = q.ovf[k];
+        if (qi == 0xffffffffu) continue;
+        const uint32_t i = qi & idx_mask;
         Rec r; uint64_t w[5];
         load_record(recs, i, r); r.canonicalize(); r.key_words(w);
         Partial p;
@@ -567,7 +606,7 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     hipLaunchKernelGGL((k_pass2<SKETCH, T2>), dim3(kSpillParts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_merge_overflow<SKETCH>), dim3(256), dim3(256), 0, s, t, sk, q, d_records, seq_base);
+    hipLaunchKernelGGL((k_merge_overflow<SKETCH>), dim3(256), dim3(256), 0, s, t, sk, q, d_records, n, seq_base);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return hipMemsetAsync(q.ovf_tail, 0, sizeof(uint32_t), s);

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 N, KEYS = 100_000_000, 1_000_000
 
 
-def _fold_and_compare(nf, O, torch, d, host, mode, sketches, max_entries):
+def _fold_and_compare(nf, O, torch, d, host, mode, sketches, max_entries, N=N):
     want = O.run_accounter(host, max_entries, mode=mode)
     assert [r for r, _ in want] == ["closing"], "the bench configuration never evicts on full"
     want = want[0][1]
@@ -64,3 +64,14 @@ def test_configs4_hot_flow_dedup_bit_exact_100m(nf, O, torch):
     host = d.cpu().numpy()
     want = _fold_and_compare(nf, O, torch, d, host, nf.MODE_KERNEL_DEDUP, False, bench.DEFAULT_MAX_ENTRIES)
     assert (want["metrics"]["nb_observed_intf"] >= 1).any()
+
+
+def test_uniform_singleton_heavy_stream_bit_exact_80m(nf, O, torch):
+    """Scan-like traffic: 80 M records uniform over 8 M flows. Pass 1's cache holds next to nothing, every partition of pass 2
+    gets ~39 k queue entries over ~3 900 flows — four times its cache: most records go through the retry list, sorted by the
+    sub-partition bits their queue entries carry, and eight more rounds (csrc/nfagg_ingest_part.hip)."""
+    n, keys = 80_000_000, 8_000_000
+    d = dev_stream(torch, nf.synth, n, seed=11, n_keys=keys, variant=1)
+    host = d.cpu().numpy()
+    want = _fold_and_compare(nf, O, torch, d, host, nf.MODE_ACCOUNTER, False, 1 << 24, N=n)
+    assert 7_900_000 < len(want) <= keys

@@ -24,7 +24,7 @@ torch.cuda.synchronize()
 synth.stream_device(d.data_ptr(), n, seed=2, n_keys=flows, d_thresholds=d_th.data_ptr())
 torch.cuda.synchronize()
 out = torch.empty(flows * 144 + 16, dtype=torch.uint8, device="cuda")
-tab = nf.FlowTable(max_entries=1 << 21, profile=True, ingest_variant=variant)
+tab = nf.FlowTable(max_entries=int(os.environ.get("MAX_ENTRIES", 1 << 21)), profile=True, ingest_variant=variant)
 for it in range(3):
     tab.ingest_device(d.data_ptr(), n)
     tab.evict_device(out.data_ptr(), flows)
@@ -33,6 +33,9 @@ ph = (C.c_uint64 * 8)()
 nf._lib.lib.nfagg_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 nf._lib.lib.nfagg_debug_phase_cycles(tab._h, ph)
 names = ["load+hash", "A", "barrier1", "B", "barrier2", "C", "flush"]
+if variant == 9:     # pass 2 of the two-pass fold
+    names = ["gather+hash", "claim", "barrier", "fold", "flushes", "retry/direct", "sort+init+tail"]
+print("direct merges:", st.records_direct if hasattr(st, "records_direct") else "n/a")
 tot = sum(ph[:7]) or 1
 print(f"flows={flows} n={n} kernel_ms={st.ingest_kernel_ms / st.ingest_launches:.3f} bypass={st.records_bypassed / (3 * n):.3f}")
 for k, nm in enumerate(names):
