@@ -192,6 +192,10 @@ def main():
                                                                         else " (REHEARSAL: backend %s, same_device %s)" % (args.backend, args.same_device)), "ingest_variant": args.variant,
                 "evictions_per_step": 1, "evicted_flows_per_step": flows_total,
                 "evictions_per_s": round(steps / dt, 3), "evicted_flows_per_s": round(flows_total * steps / dt, 1),
+                **({"skew_note": "every rank's stream has ITS OWN hot flow (per-rank populations): the load is balanced by construction. "
+                                 "One node-wide hot flow under key-hash sharding lands on ONE GPU (SURVEY.md 8(e)); the one-process group "
+                                 "spreads it with NFAGG_GROUP_LOCAL_FOLD (bench.py --group-devices ... --group-local-fold, DESIGN.md 7 a')"}
+                   if world > 1 and args.hot_permille else {}),
             },
             "roofline": {
                 "bound": "hbm",
