@@ -92,8 +92,14 @@ struct nfagg_handle {
     size_t d_spill_cap = 0;
     // accounting
     uint64_t epoch_seq = 0;
-    uint64_t live = 0;       // exact when live_exact
-    uint64_t live_ub = 0;    // upper bound on the device's n_live
+    uint64_t live = 0;       // len(entries): exact after refresh_counters and on the paths that keep counters_exact
+    uint64_t live_ub = 0;    // upper bound on the device's n_live (the claimed slots); equal to it while counters_exact
+    // The host knows the device's n_live and len(entries) without asking (after an eviction; after a claim + flag chunk,
+    // whose counts it has just read): the next "might this batch fill the table" / eviction needs no round trip. Every
+    // asynchronous fold clears it. mirror_fresh: *h_ctr equals the device counters (what the optimistic fold's rollback restores).
+    bool counters_exact = false;
+    bool mirror_fresh = false;
+    uint8_t* h_careful = nullptr;   // pinned: block counts + flags of a claim + flag chunk of up to kCarefulMaxBatch records
     bool must_evict = false; // a "full" split is pending (account.go:85-94)
     uint64_t split_seq = 0;
     nfagg_stats stats{};
@@ -152,6 +158,7 @@ int ensure_bytes(nfagg_handle* h, void** p, size_t* cap, size_t need);
 
 int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t seq_base) {
     EventPair ep{};
+    h->counters_exact = false; h->mirror_fresh = false;      // callers that know the outcome set counters_exact again
     const bool prof = h->cfg.profile != 0;
     if (!ingest_needs_spill((int)h->cfg.mode, (int)h->cfg.ingest_variant, n)) h->epoch_unclustered = true;
     if (ingest_needs_spill((int)h->cfg.mode, (int)h->cfg.ingest_variant, n)) {
@@ -194,6 +201,7 @@ int refresh_counters(nfagg_handle* h) {
         return fail(h, NFAGG_EDEVICE, "flow table kernel bailed out (code %u: 1 = probe overflow / table too small, 2 = claim spin limit, 3 = slot lock spin limit)", h->h_ctr->error);
     h->live_ub = h->h_ctr->n_live;
     if (!h->must_evict) h->live = h->h_ctr->n_live;
+    h->counters_exact = true; h->mirror_fresh = true;
     h->stats.records_skipped = h->h_ctr->n_skipped;
     h->stats.records_bypassed = h->h_ctr->n_bypassed;
     if (h->h_ctr->max_probe > h->stats.max_probe) h->stats.max_probe = h->h_ctr->max_probe;
@@ -212,6 +220,7 @@ int refresh_counters(nfagg_handle* h) {
 // (now exactly `room` new keys: it fits), the caller gets NFAGG_FULL + consumed as the reference's eviction demands.
 // Claims are bounded by TableView.claim_limit whatever the batch holds: a batch with more new keys than the table has
 // room for is `aborted` by the kernels (some claims refused), rolled back the same way and retried with a quarter of it.
+constexpr size_t kCarefulCountsBytes = 256;    // h_careful: block counts of a small chunk (16 x 4 bytes), then its flags
 constexpr uint64_t kCarefulMaxBatch = 16384;   // below this the claim + flag path decides (two small launches, one host round trip)
 
 int snapshot_sketches(nfagg_handle* h, bool restore) {
@@ -295,6 +304,7 @@ int opt_result(nfagg_handle* h, OptState& st, uint64_t chunk, bool* crossed, boo
 
 void opt_commit(nfagg_handle* h, const OptState& st, uint64_t chunk) {
     h->live = h->live_ub = h->h_ctr->n_live;
+    h->counters_exact = true; h->mirror_fresh = true;          // opt_result read the counters after the fold
     h->epoch_seq = st.seq0 + chunk;
     h->stats.records_ingested += chunk;
 }
@@ -367,13 +377,14 @@ int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t*
             h->stats.records_ingested += rem;
             continue;
         }
-        if ((rc = refresh_counters(h)) != NFAGG_OK) break;
+        if (!h->counters_exact && (rc = refresh_counters(h)) != NFAGG_OK) break;
         const uint64_t room = maxe > h->live ? maxe - h->live : 0;
-        if (room >= rem) continue;
+        if (room >= rem) { h->live_ub = h->live; continue; }          // fits after all: the fast path above takes it
         // epochs shorter than a claim + flag chunk (tiny CACHE_MAX_FLOWS, the reference's default of 5000 among them): that path
         // finds the split with two small launches and one round trip, an optimistic fold would be rolled back every time
         const bool tiny_epochs = h->epoch_len_hint != 0 && h->epoch_len_hint <= kCarefulMaxBatch;
         if (rem > kCarefulMaxBatch && !tiny_epochs) {
+            if (!h->mirror_fresh && (rc = refresh_counters(h)) != NFAGG_OK) break;      // the rollback restores *h_ctr
             // ---- optimistic path (see fold_optimistic). How much to try: everything, unless this stream has been stopping on
             // full. Then an epoch is about epoch_len_hint records long: stay clearly inside it while far from its end (the chunk
             // fits, nothing is thrown away), and go for the split with a short chunk when close — a chunk that crosses
@@ -431,26 +442,37 @@ int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t*
         if (e != hipSuccess) { rc = fail(h, NFAGG_EDEVICE, "claim launch failed: %s", hipGetErrorString(e)); break; }
         const uint64_t nblk = (chunk + kFlagBlock - 1) / kFlagBlock;
         h->h_block_counts.resize(nblk);
-        e = hipMemcpyAsync(h->h_block_counts.data(), h->d_block_counts, nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+        h->mirror_fresh = false;
+        // small chunks (every chunk of a stream with tiny epochs): counts and flags come back together, one round trip
+        const bool one_trip = chunk <= kCarefulMaxBatch;
+        uint32_t* counts_dst = one_trip ? reinterpret_cast<uint32_t*>(h->h_careful) : h->h_block_counts.data();
+        e = hipMemcpyAsync(counts_dst, h->d_block_counts, nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && one_trip) e = hipMemcpyAsync(h->h_careful + kCarefulCountsBytes, h->d_flags, chunk, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) { rc = fail(h, NFAGG_EDEVICE, "claim sync failed: %s", hipGetErrorString(e)); break; }
+        if (one_trip) memcpy(h->h_block_counts.data(), counts_dst, nblk * sizeof(uint32_t));
         uint64_t total_new = 0;
         for (uint64_t b = 0; b < nblk; b++) total_new += h->h_block_counts[b];
         if (h->live + total_new <= maxe) {
             if ((rc = launch_ingest_profiled(h, d, chunk, seq0)) != NFAGG_OK) break;
             h->live += total_new; h->live_ub = h->live; h->epoch_seq += chunk; consumed += chunk;
             h->stats.records_ingested += chunk;
+            h->counters_exact = true;                              // n_live = live: every claimed slot is a flow of the epoch
             continue;
         }
         // The (room+1)-th new key of the chunk arrives with the table full:
         // everything before it is folded, then the caller must evict ("full").
         uint64_t want = room + 1, blk = 0, before = 0;
         while (before + h->h_block_counts[blk] < want) { before += h->h_block_counts[blk]; blk++; }
-        uint8_t fl[kFlagBlock];
+        uint8_t fl_buf[kFlagBlock];
         const uint64_t off = blk * kFlagBlock;
         const uint64_t cnt = (chunk - off) < (uint64_t)kFlagBlock ? (chunk - off) : (uint64_t)kFlagBlock;
-        e = hipMemcpy(fl, h->d_flags + off, cnt, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { rc = fail(h, NFAGG_EDEVICE, "flag copy failed: %s", hipGetErrorString(e)); break; }
+        const uint8_t* fl = fl_buf;
+        if (one_trip) fl = h->h_careful + kCarefulCountsBytes + off;
+        else {
+            e = hipMemcpy(fl_buf, h->d_flags + off, cnt, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { rc = fail(h, NFAGG_EDEVICE, "flag copy failed: %s", hipGetErrorString(e)); break; }
+        }
         uint64_t split = off;
         for (uint64_t k = 0; k < cnt; k++) {
             if (fl[k]) { before++; if (before == want) { split = off + k; break; } }
@@ -459,7 +481,9 @@ int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t*
         h->epoch_seq += split; consumed += split;
         h->stats.records_ingested += split;
         h->live = maxe > h->live ? maxe : h->live;   // len(entries) == maxEntries now
-        h->live_ub = h->live + (total_new - room);
+        h->live_ub = h->live + (total_new - room);   // = the device's n_live: the chunk's new keys all hold a slot
+        h->counters_exact = true;
+        h->epoch_len_hint = h->epoch_seq > 1 ? h->epoch_seq : 1;
         h->must_evict = true;
         h->split_seq = seq0 + split;
         rc = NFAGG_FULL;
@@ -551,6 +575,7 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
     }
     CREATE_TRY(hipMemsetAsync(h->tv.ctr, 0, sizeof(DevCounters), h->stream));
     CREATE_TRY(hipHostMalloc((void**)&h->h_ctr, sizeof(DevCounters), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_careful, kCarefulCountsBytes + kCarefulMaxBatch, hipHostMallocDefault));
     h->tv.mask = slots - 1; h->tv.n_shards = cfg.n_shards; h->tv.shard_id = cfg.shard_id;
     h->tv.claim_limit = slots / 4 * 3 + 16;   // max_entries <= slots/2 plus a careful chunk <= slots/4 always fit
     h->tv.epoch_bits = 1ull << 48;            // eviction epoch 1; 0 is "never used"
@@ -640,6 +665,7 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->tv.live_list) hipFree(h->tv.live_list);
     if (h->tv.ctr) hipFree(h->tv.ctr);
     if (h->h_ctr) hipHostFree(h->h_ctr);
+    if (h->h_careful) hipHostFree(h->h_careful);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -680,6 +706,21 @@ static void staged_copy(void* dst, const void* src, size_t bytes, unsigned threa
     for (unsigned t = 0; t < started; t++) th[t].join();
 }
 
+// How much of a host buffer goes up in one piece. A stream that keeps stopping on "full" (small CACHE_MAX_FLOWS: the reference's
+// default is 5000, config.go:146) consumes one epoch per call — about epoch_len_hint records — and what was staged beyond that
+// is staged again by the next call: copy what is left of the epoch and a quarter more (a longer epoch simply takes another
+// chunk), not a whole staging buffer. Measured at max_entries 5000: 3.6 -> 36 M records/s through nfagg_ingest / nfagg_evict.
+static size_t stage_chunk(const nfagg_handle* h, size_t remaining, size_t cap) {
+    size_t m = remaining < cap ? remaining : cap;
+    if (h->epoch_len_hint) {
+        const uint64_t reach = h->epoch_len_hint + h->epoch_len_hint / 4;
+        uint64_t want = reach > h->epoch_seq ? reach - h->epoch_seq : 0;
+        if (want < kCarefulMaxBatch) want = kCarefulMaxBatch;
+        if (m > want) m = (size_t)want;
+    }
+    return m;
+}
+
 int nfagg_ingest(nfagg_handle* h, const void* records, size_t n, size_t* consumed_out) {
     if (!h || (!records && n)) return fail(h, NFAGG_EINVAL, "null argument");
     if (h->stage_acquired) return fail(h, NFAGG_ESTATE, "a staging buffer is acquired; commit it first");
@@ -692,7 +733,7 @@ int nfagg_ingest(nfagg_handle* h, const void* records, size_t n, size_t* consume
     // pinned ring, double buffered: the CPU fills buffer b+1 while the GPU
     // copies/folds buffer b (tracer_ringbuf.go:112-134 forwards one record at a time)
     while (consumed < n) {
-        const size_t m = (n - consumed) < cap ? (n - consumed) : cap;
+        const size_t m = stage_chunk(h, n - consumed, cap);
         const int b = h->stage_next;
         HIP_TRY(h, hipEventSynchronize(h->stage_free[b]));
         staged_copy(h->pinned[b], src + consumed * kRecordBytes, m * kRecordBytes, h->cfg.copy_threads);
@@ -755,6 +796,7 @@ static int finish_epoch(nfagg_handle* h, int reason, uint64_t flows) {
     h->stats.evictions[reason]++;
     h->stats.evicted_flows[reason] += flows;
     h->epoch_seq = 0; h->live = 0; h->live_ub = 0; h->must_evict = false; h->split_seq = 0;
+    h->counters_exact = true;          // k_reset_after_evict left n_live = 0
     h->epoch_unclustered = false;
     // The table itself was not touched: the slots of the evicted flows simply belong to a past epoch now.
     // Tags hold 16 bits of epoch; when they wrap (every 65 535 evictions) the tags are cleared once.
@@ -770,10 +812,10 @@ static int finish_epoch(nfagg_handle* h, int reason, uint64_t flows) {
 static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device, size_t cap, size_t* n_out) {
     if (!h || !n_out || reason < 0 || reason > 2) return fail(h, NFAGG_EINVAL, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    int rc = refresh_counters(h);
-    if (rc != NFAGG_OK) return rc;
+    int rc = NFAGG_OK;
+    if (!h->counters_exact && (rc = refresh_counters(h)) != NFAGG_OK) return rc;
     const uint64_t legit = h->live;
-    const uint64_t claimed = h->h_ctr->n_live;
+    const uint64_t claimed = h->live_ub;          // = the device's n_live (counters_exact)
     *n_out = (size_t)legit;
     if (legit > cap) return NFAGG_TRUNCATED;
     if (legit && !out) return fail(h, NFAGG_EINVAL, "null output buffer");
@@ -813,12 +855,19 @@ static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device
     hipError_t e = launch_evict(tv, claimed, h->must_evict ? h->split_seq : ~0ull, d_out, h->stream);
     if (h->cfg.profile) prof_end(h, ep);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "evict launch failed: %s", hipGetErrorString(e));
+    // counters and (host variant) the records come back in stream order behind the kernel: one wait for both
     HIP_TRY(h, hipMemcpyAsync(h->h_ctr, h->tv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
+    if (!out_is_device && legit)
+        HIP_TRY(h, hipMemcpyAsync(out, h->d_evict, (size_t)legit * kRecordBytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->mirror_fresh = true;
+    if (h->h_ctr->error)
+        return fail(h, NFAGG_EDEVICE, "flow table kernel bailed out (code %u: 1 = probe overflow / table too small, 2 = claim spin limit, 3 = slot lock spin limit)", h->h_ctr->error);
     if (h->h_ctr->n_out != legit)
         return fail(h, NFAGG_EDEVICE, "evict wrote %llu records, expected %llu", (unsigned long long)h->h_ctr->n_out, (unsigned long long)legit);
-    if (!out_is_device && legit)
-        HIP_TRY(h, hipMemcpy(out, h->d_evict, (size_t)legit * kRecordBytes, hipMemcpyDeviceToHost));
+    h->stats.records_skipped = h->h_ctr->n_skipped;
+    h->stats.records_bypassed = h->h_ctr->n_bypassed;
+    if (h->h_ctr->max_probe > h->stats.max_probe) h->stats.max_probe = h->h_ctr->max_probe;
     return finish_epoch(h, reason, legit);
 }
 
