@@ -1,23 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — flow-records/s of the MI355X flow-aggregation hot path.
 
-One "step" = one pass of the hot path over one batch of synthetic input:
-fold a Zipf(1.1) stream of 144-byte flow_record_t (already resident in HBM)
-into the flow table (nfagg_ingest_device) and evict it (nfagg_evict_device).
-Workload at N=1: BASELINE.json configs[1] — 100 M records, 1 M unique flows,
-hash-aggregate only. At N>1 the records shard by flow-key hash: every rank owns
-the population members whose key hashes to it and folds its own stream of the
-same size (weak scaling, no data-path collective; --sketches adds the per-tick
-RCCL all-reduce of the Count-Min / HLL arrays, configs[2]/[3]).
+One "step" = one pass of the hot path over one batch of synthetic input: fold a Zipf(1.1) stream of 144-byte
+flow_record_t (already resident in HBM) into the flow table and evict it.
 
-Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit,
-`roofline` (HBM-bound: algorithmic bytes / ingest-kernel time measured with HIP
-events on the kernel's stream) and `cpu_baseline` (the CPU oracle — a C
+N = 1 (default): BASELINE.json configs[1] — 100 M records, 1 M unique flows, hash-aggregate only: ONE
+  nfagg_ingest_device call + one nfagg_evict_device per step. After the timed steps the same run measures, bounded to a few
+  seconds, the other legs the reference's users care about (`extra`): the PCIe-inclusive host path, configs[2] (+ Count-Min
+  + HLL), the configs[4] shape (dedup merge on, 90 % of the records one flow) and the reference's default CACHE_MAX_FLOWS.
+
+N > 1: BASELINE.json configs[3] — ONE common stream of N x 125 M records over N x 1.25 M flows, Count-Min + HLL on, one
+  process per GPU (torch.distributed, backend nccl = RCCL). Slice r of the stream (arrival positions [r n, (r+1) n)) is
+  resident on rank r, as if it had come up that GPU's PCIe link. Nothing is pre-sharded: every rank folds what arrived at
+  it, whatever its keys, with sequence numbers global to the job (LOCAL FOLD), and per step — inside the
+  timed region — the sketches are all-reduced (RCCL, sum u64 / max u32), every rank's flows travel as 192-byte partials to
+  the rank that owns them (nfagg_shard_of; RCCL all-to-all over xGMI), the owners merge and evict. The union of the ranks'
+  evictions is bit-identical to one Accounter over the whole stream (tests/test_partials_gpu.py).
+  `python bench.py --gpus N` as a plain process spawns its N ranks itself (python -m torch.distributed.run); launched by
+  torch.distributed.run it is one of them. --presharded keeps round 2's communication-free line (every rank folds a
+  private stream over its own shard's population: linear by construction) for comparison.
+
+Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit, `roofline` (HBM-bound: algorithmic bytes /
+ingest-kernel time measured with HIP events on the kernel's stream) and, at N = 1, `cpu_baseline` (the CPU oracle — a C
 restatement of pkg/flow.Accounter — timed on a bounded sample of the same stream).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,52 +40,110 @@ sys.path.insert(0, ROOT)
 ALG_BYTES_INGEST = 392      # 144 read record + 144 read slot + 104 write value
 ALG_BYTES_SKETCH = 130      # CM 2 keys x 4 rows x (8+8) + HLL 2 x (1+1)
 ALG_BYTES_EVICT = 296       # per evicted flow
-DEFAULT_MAX_ENTRIES = 1 << 21   # CACHE_MAX_FLOWS of the bench table: SURVEY.md §8(d) config 2 sizing (2^22 slots = 1 GiB); tests/test_full_size_gpu.py uses the same
+DEFAULT_MAX_ENTRIES = 1 << 21   # CACHE_MAX_FLOWS of the bench table: SURVEY.md §8(d) config 2 sizing (2^22 slots = 768 MiB); tests/test_full_size_gpu.py uses the same
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+METRIC = "flow-records/s ingested + evictions/s, 1/2/4/8 GPU; % HBM roofline"
+PARTIAL_BYTES = 192
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--records", type=int, default=100_000_000, help="records per GPU per step")
-    ap.add_argument("--flows", type=int, default=1_000_000, help="unique flows per GPU")
+    ap.add_argument("--records", type=int, default=0, help="records per GPU per step (0: 100 M at N = 1, 125 M at N > 1)")
+    ap.add_argument("--flows", type=int, default=0, help="unique flows per GPU (0: 1 M at N = 1, 1.25 M at N > 1)")
     ap.add_argument("--zipf", type=float, default=1.1)
     ap.add_argument("--hot-permille", type=int, default=0, help="configs[4]: share of records hitting one flow")
-    ap.add_argument("--sketches", action="store_true", help="configs[2]/[3]: CM(d=4,w=2^20)+HLL(p=14), all-reduced per step when N>1")
+    ap.add_argument("--sketches", action="store_true", help="configs[2]: CM(d=4,w=2^20)+HLL(p=14) at N = 1 (always on at N > 1 unless --no-sketches)")
+    ap.add_argument("--no-sketches", action="store_true", help="N > 1 without the sketches and their all-reduce")
     ap.add_argument("--variant", type=int, default=0, help="ingest kernel variant (DESIGN.md)")
     ap.add_argument("--dedup", action="store_true", help="configs[4]: NFAGG_MODE_KERNEL_DEDUP, every flow seen on two interfaces (stream variant 2)")
     ap.add_argument("--chunk", type=int, default=0, help="records per nfagg_ingest_device call (0 = whole stream)")
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="records of the stream the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--max-entries", type=int, default=0)
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the bounded extra legs (e2e host path, configs[2], configs[4] shape, CACHE_MAX_FLOWS 5000)")
+    ap.add_argument("--presharded", action="store_true", help="N > 1: round 2's line — every rank folds a private stream over its own shard's "
+                    "population through the shard filter; no data-path exchange (linear by construction; for comparison only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1: nccl (= RCCL, the product path) or gloo "
                     "(rehearsal of the N>1 code path on a 1-GPU box together with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--group-local-fold", action="store_true", help="with --group-devices: NFAGG_GROUP_LOCAL_FOLD (no routing; every member "
                     "folds its own slice, the members' slots are merged into their owners at the eviction)")
+    ap.add_argument("--group-threads", action="store_true", help="with --group-devices --group-local-fold: one host thread per member "
+                    "(the members' folds overlap; the Go host would use one goroutine per GPU)")
     ap.add_argument("--group-devices", default="", help="ONE process driving several GPUs through nfagg_group_* (how the one-process Go agent "
                     "runs): comma-separated HIP ordinals, e.g. 0,1,2,3,4,5,6,7 — or 0,0,0,0 to rehearse four members on one GPU. One COMMON "
                     "stream (slice i arrives on member i's device), partitioned on the device and routed by key hash; not the torchrun contract path")
-    args = ap.parse_args()
+    ap.add_argument("--print-spawn", action="store_true", help="print the command line --gpus N would spawn and exit (no GPU needed)")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_command(argv, gpus, port):
+    """`python bench.py --gpus N` as a plain process: the ranks are spawned exactly as the driver's contract launches them."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--print-spawn"]
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
     if os.environ.get("NFAGG_BENCH_WATCHDOG"):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["NFAGG_BENCH_WATCHDOG"]), exit=True)
+    if args.print_spawn:
+        print(" ".join(spawn_command(argv, args.gpus, 29500)))
+        return 0
+    if args.group_devices:
+        import torch
+        return group_main(args, torch)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain process: become the launcher of N ranks (one per GPU) — the same command line the driver's contract uses
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        import __graft_entry__
+        __graft_entry__.ensure_built()            # once, before N ranks race for it
+        return subprocess.call(spawn_command(argv, args.gpus, free_port()), env=env)
+    return rank_main(args)
 
+
+def resolve_sizes(args, world):
+    n = args.records or (100_000_000 if world == 1 else 125_000_000)
+    keys = args.flows or (1_000_000 if world == 1 else 1_250_000)
+    return n, keys
+
+
+def next_pow2(v):
+    p = 1
+    while p < v:
+        p <<= 1
+    return p
+
+
+def rank_main(args):
     import torch
     import torch.distributed as dist
 
-    if args.group_devices:
-        return group_main(args, torch)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
     if args.same_device:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (rehearse the N > 1 path on one GPU with --same-device --backend gloo)"
+                         % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -91,51 +160,122 @@ def main():
     import netobserv_ebpf_agent_amd as nf
     from netobserv_ebpf_agent_amd import synth
 
-    n, keys = args.records, args.flows
-    # ---- synthetic stream, generated in HBM (SURVEY.md §8(d) config 2, seed 2)
-    th = synth.zipf_thresholds(keys, args.zipf)
+    n, keys = resolve_sizes(args, world)
+    local_fold = world > 1 and not args.presharded
+    sketches = args.sketches or (world > 1 and not args.no_sketches)
+    keys_total = keys * world if local_fold else keys
+    # ---- synthetic stream, generated in HBM (SURVEY.md §8(d), seed 2)
+    th = synth.zipf_thresholds(keys_total, args.zipf)
     d_th = torch.from_numpy(th.view(np.int64)).cuda()
     d_pop = None
-    if world > 1:
+    j0, seed = 0, 2
+    if local_fold:
+        j0 = rank * n                           # ONE stream of world x n records: this rank holds arrival positions [rank n, (rank + 1) n)
+    elif world > 1:
         pop = synth.shard_population(keys, world, rank)
         d_pop = torch.from_numpy(pop.view(np.int64)).cuda()
+        seed = 2 + 1000 * rank
     d_recs = torch.empty(n * 144, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
-    seed = 2 + 1000 * rank
-    synth.stream_device(d_recs.data_ptr(), n, seed=seed, n_keys=keys, d_thresholds=d_th.data_ptr(),
-                        hot_permille=args.hot_permille, variant=2 if args.dedup else 0,
-                        d_pop_index=d_pop.data_ptr() if d_pop is not None else 0)
-    torch.cuda.synchronize()
+
+    def gen_stream(variant, hot):
+        synth.stream_device(d_recs.data_ptr(), n, j0=j0, seed=seed, n_keys=keys_total, d_thresholds=d_th.data_ptr(),
+                            hot_permille=hot, variant=variant, d_pop_index=d_pop.data_ptr() if d_pop is not None else 0)
+        torch.cuda.synchronize()
+
+    gen_stream(2 if args.dedup else 0, args.hot_permille)
 
     # CACHE_MAX_FLOWS. The 100 M-record call has live + batch > max_entries, so the library folds it optimistically
     # (one fold, then the proof that no record found the table full: n_live <= max_entries) — DESIGN.md §2.
-    max_entries = args.max_entries or DEFAULT_MAX_ENTRIES
-    sk_flags = (nf.SKETCH_CM | nf.SKETCH_HLL) if args.sketches else 0
+    # Local fold: a rank may see any flow of the stream (5.4 M of 10 M at N = 8), and its table also takes the flows it owns
+    # from the other ranks.
+    max_entries = args.max_entries or (DEFAULT_MAX_ENTRIES if not local_fold else max(DEFAULT_MAX_ENTRIES, min(next_pow2(keys_total), 1 << 23)))
+    sk_flags = (nf.SKETCH_CM | nf.SKETCH_HLL) if sketches else 0
     ext = None
     cm_t = hll_t = None
-    if args.sketches:
+    if sketches:
         cm_t = [torch.zeros(4 << 20, dtype=torch.int64, device="cuda") for _ in range(2)]
         hll_t = [torch.zeros(1 << 14, dtype=torch.int32, device="cuda") for _ in range(2)]
         ext = [cm_t[0].data_ptr(), cm_t[1].data_ptr(), hll_t[0].data_ptr(), hll_t[1].data_ptr()]
         torch.cuda.synchronize()
     tab = nf.FlowTable(max_entries=max_entries, device=local_rank, sketches=sk_flags, profile=True,
                        mode=nf.MODE_KERNEL_DEDUP if args.dedup else nf.MODE_ACCOUNTER,
-                       ingest_variant=args.variant, n_shards=world, shard_id=rank, ext_sketch=ext)
-    d_out = torch.empty(keys * 144 + 16, dtype=torch.uint8, device="cuda")
+                       ingest_variant=args.variant, n_shards=1 if local_fold else world, shard_id=0 if local_fold else rank, ext_sketch=ext)
+    out_cap = (keys_total if local_fold else keys) + 4096
+    d_out = torch.empty(min(out_cap, max_entries + 4096) * 144 + 16, dtype=torch.uint8, device="cuda")
+    out_cap = (d_out.numel() - 16) // 144
     chunk = args.chunk or n
+    # local fold: partials out (at most max_entries flows live here) and in (what this rank owns of the others' flows)
+    d_exp = d_imp = None
+    if local_fold:
+        d_exp = torch.empty(max_entries * (PARTIAL_BYTES // 8), dtype=torch.int64, device="cuda")
+        d_imp = torch.empty(max_entries * (PARTIAL_BYTES // 8), dtype=torch.int64, device="cuda")
+    phase = {}
 
-    def step():
+    def exchange(counts):
+        """Segment o of this rank's export goes to rank o: RCCL all-to-all over xGMI (through host memory in the gloo rehearsal)."""
+        W8 = PARTIAL_BYTES // 8
+        send_counts = torch.tensor(counts, dtype=torch.int64)
+        recv_counts = torch.empty(world, dtype=torch.int64)
+        if args.backend == "nccl":
+            sc, rc_ = send_counts.cuda(), recv_counts.cuda()
+            dist.all_to_all_single(rc_, sc)
+            recv_counts = rc_.cpu()
+        else:
+            dist.all_to_all_single(recv_counts, send_counts)
+        ins = [int(c) * W8 for c in counts]
+        outs = [int(c) * W8 for c in recv_counts.tolist()]
+        total_in = sum(outs)
+        assert total_in <= d_imp.numel(), "partials landing area too small"
+        send, recv = d_exp[: sum(ins)], d_imp[:total_in]
+        if args.backend == "nccl":
+            dist.all_to_all_single(recv, send, outs, ins)
+        else:
+            r_cpu = torch.empty(total_in, dtype=torch.int64)
+            dist.all_to_all_single(r_cpu, send.cpu(), outs, ins)
+            recv.copy_(r_cpu)
+        torch.cuda.synchronize()
+        return total_in // W8, sum(counts)
+
+    def step(timed=None):
+        def mark(name, t_prev):
+            if timed is None:
+                return t_prev
+            torch.cuda.synchronize(); tab.sync()
+            t = time.perf_counter()
+            timed[name] = timed.get(name, 0.0) + (t - t_prev) * 1e3
+            return t
+        t = time.perf_counter()
+        if local_fold:
+            tab.set_sequence(rank * n)
         off = 0
         while off < n:
             m = min(chunk, n - off)
             rc, c = tab.ingest_device(d_recs.data_ptr() + off * 144, m)
             assert rc == nf.OK and c == m, (rc, c)
             off += m
-        if args.sketches and world > 1:
+        t = mark("fold_ms", t)
+        if sketches and world > 1:
             tab.sync()          # the sketch kernels run on the table's stream
             nf.distributed.merge_sketches(cm_t, hll_t)
-        flows = tab.evict_device(d_out.data_ptr(), keys, nf.REASON_TIMEOUT)
-        if args.sketches:
+            torch.cuda.synchronize()
+        t = mark("sketch_allreduce_ms", t)
+        if local_fold:
+            rc, counts, n_exp = tab.partials_export_device(world, rank, d_exp.data_ptr(), d_exp.numel() * 8 // PARTIAL_BYTES)
+            assert rc == nf.OK, "partials buffer too small: %d needed" % n_exp
+            t = mark("export_ms", t)
+            n_in, n_sent = exchange(counts)
+            t = mark("all_to_all_ms", t)
+            tab.partials_merge_device(world, rank, d_imp.data_ptr(), n_in)
+            rc, flows = tab.evict_owned_device(world, rank, d_out.data_ptr(), out_cap, nf.REASON_TIMEOUT)
+            assert rc == nf.OK, "eviction buffer too small: %d needed" % flows
+            t = mark("merge_evict_ms", t)
+            if timed is not None:
+                timed["partials_sent"], timed["partials_received"] = n_sent, n_in
+        else:
+            flows = tab.evict_device(d_out.data_ptr(), out_cap, nf.REASON_TIMEOUT)
+            t = mark("evict_ms", t)
+        if sketches:
             tab.sketch_reset()
         return flows
 
@@ -143,6 +283,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        tab.sync()
 
     flows = 0
     for _ in range(args.warmup):
@@ -155,13 +296,21 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     st = tab.stats()
+    records_folded = [int(st.records_ingested)]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        mdev = "cuda" if args.backend == "nccl" else "cpu"          # bookkeeping collectives (gloo rehearsal: host tensors)
+        t = torch.tensor([dt], dtype=torch.float64, device=mdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        f = torch.tensor([flows], dtype=torch.int64, device="cuda")
+        f = torch.tensor([flows], dtype=torch.int64, device=mdev)
         dist.all_reduce(f, op=dist.ReduceOp.SUM)
         flows_total = int(f.item())
+        rf = [torch.zeros(1, dtype=torch.int64, device=mdev) for _ in range(world)]
+        dist.all_gather(rf, torch.tensor([int(st.records_ingested)], dtype=torch.int64, device=mdev))
+        records_folded = [int(x.item()) for x in rf]
+        # one more, instrumented step (outside the timed region): where the time of a step goes
+        step(timed=phase)
+        barrier()
     else:
         flows_total = flows
 
@@ -170,10 +319,21 @@ def main():
         total_records = n * world * steps
         ingest_ms = st.ingest_kernel_ms / max(st.ingest_launches, 1)
         recs_per_launch = n * steps / max(st.ingest_launches, 1)
-        alg_bytes = ALG_BYTES_INGEST + (ALG_BYTES_SKETCH if args.sketches else 0)   # 392 B/record, 522 with the sketches
+        alg_bytes = ALG_BYTES_INGEST + (ALG_BYTES_SKETCH if sketches else 0)   # 392 B/record, 522 with the sketches
         achieved = alg_bytes * recs_per_launch / (ingest_ms * 1e-3) / 1e9 if ingest_ms > 0 else 0.0
+        cfg_no = 4 if args.dedup else (3 if world > 1 else (2 if sketches else 1))
+        if local_fold:
+            workload = ("configs[3]: ONE %dM-record Zipf(%.1f) stream over %dk unique flows, %dM records per GPU resident on the GPU they "
+                        "arrived at, local fold (no per-record routing) + per step: RCCL all-reduce of CM(d=4,w=2^20)+HLL(p=14), flow "
+                        "partials to their key-hash owners (all-to-all), merge, eviction"
+                        % (n * world // 1_000_000, args.zipf, keys_total // 1000, n // 1_000_000))
+        else:
+            workload = ("configs[%d]: %dM-record Zipf(%.1f) stream, %dk unique flows per GPU, hash-aggregate%s%s, device-resident input"
+                        % (cfg_no, n // 1_000_000, args.zipf, keys // 1000, "+CM(d=4,w=2^20)+HLL(p=14)" if sketches else " only",
+                           ", kernel-dedup merge on" if args.dedup else ""))
+        rehearsal = "" if (args.backend == "nccl" and not args.same_device) else " (REHEARSAL: backend %s, same_device %s)" % (args.backend, args.same_device)
         out = {
-            "metric": "flow-records/s ingested + evictions/s, 1/2/4/8 GPU; % HBM roofline",
+            "metric": METRIC,
             "value": round(total_records / dt / 1e6, 3),
             "unit": "Mrecords/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,21 +341,19 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {
-                "workload": ("configs[%d]: %dM-record Zipf(%.1f) stream, %dk unique flows per GPU, hash-aggregate%s%s, device-resident input"
-                             % (4 if args.dedup else (2 if args.sketches else 1), n // 1_000_000, args.zipf, keys // 1000,
-                                "+CM(d=4,w=2^20)+HLL(p=14)" if args.sketches else " only",
-                                ", kernel-dedup merge on" if args.dedup else "")),
+                "workload": workload,
                 "records_per_gpu_per_step": n, "unique_flows_per_gpu": keys, "hot_permille": args.hot_permille,
                 "stream_variant": 2 if args.dedup else 0, "mode": "kernel_dedup" if args.dedup else "accounter",
                 "max_entries": max_entries, "table_bytes": int(st.table_bytes), "chunk": chunk,
-                "parallelism": "key-hash shards x%d" % world + ("" if args.backend == "nccl" and not args.same_device
-                                                                        else " (REHEARSAL: backend %s, same_device %s)" % (args.backend, args.same_device)), "ingest_variant": args.variant,
+                "parallelism": ("one process per GPU x%d, local fold + partials to key-hash owners" % world if local_fold
+                                else "key-hash shards x%d" % world) + rehearsal,
+                "ingest_variant": args.variant,
                 "evictions_per_step": 1, "evicted_flows_per_step": flows_total,
                 "evictions_per_s": round(steps / dt, 3), "evicted_flows_per_s": round(flows_total * steps / dt, 1),
                 **({"skew_note": "every rank's stream has ITS OWN hot flow (per-rank populations): the load is balanced by construction. "
-                                 "One node-wide hot flow under key-hash sharding lands on ONE GPU (SURVEY.md 8(e)); the one-process group "
-                                 "spreads it with NFAGG_GROUP_LOCAL_FOLD (bench.py --group-devices ... --group-local-fold, DESIGN.md 7 a')"}
-                   if world > 1 and args.hot_permille else {}),
+                                 "One node-wide hot flow under key-hash sharding lands on ONE GPU (SURVEY.md 8(e)); the local fold "
+                                 "spreads it (default at N > 1)"}
+                   if world > 1 and args.hot_permille and args.presharded else {}),
             },
             "roofline": {
                 "bound": "hbm",
@@ -211,14 +369,28 @@ def main():
                 "frac_traffic": None,
                 "alg_bytes_per_record": alg_bytes, "records_per_launch": int(recs_per_launch),
                 "launch_ms": round(ingest_ms, 4), "launches": int(st.ingest_launches),
-                "lds_cache_hit_rate": round(1.0 - st.records_bypassed / max(1, n * (args.steps + args.warmup)), 4),
+                "lds_cache_hit_rate": round(1.0 - st.records_bypassed / max(1, n * (args.steps + args.warmup + (1 if world > 1 else 0))), 4),
                 "kernel_Mrecords_per_s": round(recs_per_launch / (ingest_ms * 1e-3) / 1e6, 1) if ingest_ms > 0 else None,
                 "evict_launch_ms": round(st.evict_kernel_ms / max(st.evict_launches, 1), 4),
                 "sketch_launch_ms": round(st.sketch_kernel_ms / max(st.sketch_launches, 1), 4) if st.sketch_launches else None,
             },
         }
+        if world > 1:
+            out["config"]["rccl_ranks"] = world if args.backend == "nccl" else 0
+            out["config"]["backend"] = args.backend
+            out["config"]["member_records_folded"] = records_folded
+            if local_fold:
+                out["config"]["unique_flows_total"] = keys_total
+                out["config"]["exchange"] = {
+                    "what": "rank 0, one instrumented step after the timed ones (host clock, device synchronised between the phases)",
+                    **{k: (round(v, 3) if isinstance(v, float) else v) for k, v in phase.items()},
+                    "partial_bytes": PARTIAL_BYTES,
+                    "routed_bytes_per_step_rank0": int(phase.get("partials_sent", 0)) * PARTIAL_BYTES,
+                    "routed_bytes_if_records_were_routed": int(n * (world - 1) / world) * 144,
+                    "sketch_allreduce_bytes": (2 * (4 << 20) * 8 + 2 * (1 << 14) * 4) if sketches else 0,
+                }
         ev_ms = st.evict_kernel_ms / max(st.evict_launches, 1)
-        if ev_ms > 0 and not args.dedup:
+        if ev_ms > 0 and not args.dedup and not local_fold:
             ev_ach = ALG_BYTES_EVICT * (flows_total / world) / (ev_ms * 1e-3) / 1e9
             out["roofline_evict"] = {"bound": "hbm", "kernel": "k_evict", "achieved": round(ev_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(ev_ach / HBM_PEAK_GBS, 4), "alg_bytes_per_flow": ALG_BYTES_EVICT,
@@ -244,48 +416,20 @@ def main():
                 break
         # ---- CPU baseline: the oracle (C restatement of pkg/flow.Accounter), 1 core, bounded sample
         if args.cpu_sample > 0 and world == 1:     # rank 0 at N=1 only
-            from oracle import oracle as O
-            O.build()
-            m = min(args.cpu_sample, n)
-            sample = d_recs[: m * 144].cpu().numpy()
-            acc = O.Accounter(max_entries, 1 if args.dedup else 0)
-            t1 = time.perf_counter()
-            consumed = acc.ingest(sample)
-            ev = acc.evict()
-            cpu_dt = time.perf_counter() - t1
-            acc.close()
-            assert consumed == m
-            out["cpu_baseline"] = {
-                "value": round(m / cpu_dt / 1e6, 3), "unit": "Mrecords/s", "cores": 1, "kind": "port", "what": "C restatement of pkg/flow.Accounter (oracle/nfagg_oracle.c); the Go reference cannot be built here",
-                "sample": "first %d records of rank 0's stream (%d flows), oracle Accounter ingest+evict, %.1f s" % (m, len(ev), cpu_dt),
-                "host_cores_available": os.cpu_count(),
-            }
-            # best-effort multi-core variant of the same restatement: the sample split by a key hash
-            # over T workers, one oracle Accounter each (ctypes releases the GIL). The reference itself is one goroutine.
-            if not args.dedup:
-                import threading
-                T = max(2, min(32, (os.cpu_count() or 2) // 2))
-                accs = [O.Accounter(max_entries, 0) for _ in range(T)]
-                got = [0] * T
-
-                def work(k):
-                    got[k] = accs[k].ingest_shard(sample, T, k)
-                    got[k] = (got[k], len(accs[k].evict()))
-                t1 = time.perf_counter()
-                ths = [threading.Thread(target=work, args=(k,)) for k in range(T)]
-                for t_ in ths:
-                    t_.start()
-                for t_ in ths:
-                    t_.join()
-                mc_dt = time.perf_counter() - t1
-                for a_ in accs:
-                    a_.close()
-                assert sum(g[0] for g in got) == m and sum(g[1] for g in got) == len(ev)
-                out["cpu_baseline"]["multicore"] = {"value": round(m / mc_dt / 1e6, 3), "unit": "Mrecords/s", "cores": T, "kind": "port",
-                                                    "sample": "same sample, key-hash split over %d threads, %.1f s" % (T, mc_dt)}
+            out["cpu_baseline"] = cpu_baseline(args, d_recs, n, max_entries)
         # ---- the chip's copy bandwidth in this very run (state the peak used, confirm it with a D2D copy):
         # up to 4 GiB device-to-device (the stream's first half over its second: nothing reads the stream after this point),
         # read + written bytes over the time of the copy
+        default_workload = (world == 1 and not args.dedup and not args.sketches and not args.hot_permille and args.variant == 0
+                            and not args.chunk and not args.max_entries)
+        if default_workload and not args.no_extras:
+            # the extra legs regenerate streams into d_recs: before the copy test overwrites half of it
+            tab.close()
+            tab = None
+            try:
+                out["extra"] = extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys)
+            except Exception as exc:                      # never a reason to lose the bench line
+                out["extra"] = {"error": repr(exc)[:300]}
         try:
             nb = min(4 << 30, (n * 144) // 2 // 256 * 256)
             src_t, dst_t = d_recs[:nb], d_recs[nb:2 * nb]
@@ -297,9 +441,146 @@ def main():
             out["roofline"]["hbm_copy_measured_GBs"] = None
             out["roofline"]["hbm_copy_error"] = str(exc)[:100]
         print(json.dumps(out), flush=True)
-    tab.close()
+    if tab is not None:
+        tab.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def cpu_baseline(args, d_recs, n, max_entries):
+    from oracle import oracle as O
+    O.build()
+    m = min(args.cpu_sample, n)
+    sample = d_recs[: m * 144].cpu().numpy()
+    acc = O.Accounter(max_entries, 1 if args.dedup else 0)
+    t1 = time.perf_counter()
+    consumed = acc.ingest(sample)
+    ev = acc.evict()
+    cpu_dt = time.perf_counter() - t1
+    acc.close()
+    assert consumed == m
+    res = {
+        "value": round(m / cpu_dt / 1e6, 3), "unit": "Mrecords/s", "cores": 1, "kind": "port", "what": "C restatement of pkg/flow.Accounter (oracle/nfagg_oracle.c); the Go reference cannot be built here",
+        "sample": "first %d records of rank 0's stream (%d flows), oracle Accounter ingest+evict, %.1f s" % (m, len(ev), cpu_dt),
+        "host_cores_available": os.cpu_count(),
+    }
+    # best-effort multi-core variant of the same restatement: the sample split by a key hash
+    # over T workers, one oracle Accounter each (ctypes releases the GIL). The reference itself is one goroutine.
+    if not args.dedup:
+        import threading
+        T = max(2, min(32, (os.cpu_count() or 2) // 2))
+        accs = [O.Accounter(max_entries, 0) for _ in range(T)]
+        got = [0] * T
+
+        def work(k):
+            got[k] = accs[k].ingest_shard(sample, T, k)
+            got[k] = (got[k], len(accs[k].evict()))
+        t1 = time.perf_counter()
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(T)]
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join()
+        mc_dt = time.perf_counter() - t1
+        for a_ in accs:
+            a_.close()
+        assert sum(g[0] for g in got) == m and sum(g[1] for g in got) == len(ev)
+        res["multicore"] = {"value": round(m / mc_dt / 1e6, 3), "unit": "Mrecords/s", "cores": T, "kind": "port",
+                            "sample": "same sample, key-hash split over %d threads, %.1f s" % (T, mc_dt)}
+    return res
+
+
+def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
+    """The legs next to the headline, measured in the same run (bounded: a few seconds in all). Every block: what ran, ms per
+    step, records/s, and — where one kernel family dominates — its HIP-event time per call against SURVEY §8(d)'s bytes and
+    against the stream floor (the 144-byte records alone)."""
+    ex = {}
+
+    def device_leg(name, mode, sk, variant, hot, what, steps=3):
+        gen_stream(variant, hot)
+        cm_t = [torch.zeros(4 << 20, dtype=torch.int64, device="cuda") for _ in range(2)] if sk else None
+        hll_t = [torch.zeros(1 << 14, dtype=torch.int32, device="cuda") for _ in range(2)] if sk else None
+        ext = [cm_t[0].data_ptr(), cm_t[1].data_ptr(), hll_t[0].data_ptr(), hll_t[1].data_ptr()] if sk else None
+        torch.cuda.synchronize()
+        with nf.FlowTable(max_entries=DEFAULT_MAX_ENTRIES, device=torch.cuda.current_device(), sketches=(nf.SKETCH_CM | nf.SKETCH_HLL) if sk else 0,
+                          profile=True, mode=mode, ext_sketch=ext) as tab:
+            def one():
+                rc, c = tab.ingest_device(d_recs.data_ptr(), n)
+                assert rc == nf.OK and c == n, (rc, c)
+                f = tab.evict_device(d_out.data_ptr(), (d_out.numel() - 16) // 144, nf.REASON_TIMEOUT)
+                if sk:
+                    tab.sketch_reset()
+                return f
+            one()
+            tab.sync(); tab.reset_profile()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                flows = one()
+            tab.sync()
+            dt = (time.perf_counter() - t0) / steps
+            st = tab.stats()
+        k_ms = (st.ingest_kernel_ms + st.sketch_kernel_ms) / max(st.ingest_launches, 1)
+        alg = ALG_BYTES_INGEST + (ALG_BYTES_SKETCH if sk else 0)
+        ex[name] = {"what": what, "steps": steps, "ms_per_step": round(dt * 1e3, 3), "Mrecords_per_s": round(n / dt / 1e6, 1),
+                    "evicted_flows_per_step": int(flows), "ingest_call_ms": round(k_ms, 4),
+                    "frac": round(alg * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
+                    "frac_stream_floor": round(144 * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
+                    "alg_bytes_per_record": alg}
+
+    device_leg("configs2", nf.MODE_ACCOUNTER, True, 0, 0,
+               "configs[2]: the configs[1] stream + Count-Min(d=4,w=2^20) + HLL(p=14) per src/dst IP, one ingest call + eviction per step, device-resident")
+    device_leg("configs4_shape", nf.MODE_KERNEL_DEDUP, False, 2, 900,
+               "configs[4] shape on one GPU: 90 % of the records one flow (two interfaces), NFAGG_MODE_KERNEL_DEDUP (bpf/flows.c:76-143 merge), "
+               "one ingest call + eviction per step, device-resident")
+
+    # ---- host path (PCIe-inclusive): the route the cgo shim takes. 20 M records from pageable host memory through
+    # nfagg_ingest (pinned double-buffered ring, H2D on its own stream) + nfagg_evict (records back to host memory)
+    gen_stream(0, 0)
+    m = min(20_000_000, n)
+    host = d_recs[: m * 144].cpu().numpy().view(nf.FLOW_RECORD)
+    with nf.FlowTable(max_entries=DEFAULT_MAX_ENTRIES, device=torch.cuda.current_device()) as tab:
+        def e2e():
+            rc, c = tab.ingest(host)
+            assert rc == nf.OK and c == m, (rc, c)
+            return len(tab.evict(nf.REASON_TIMEOUT, cap=keys))
+        e2e()
+        t0 = time.perf_counter()
+        flows = e2e()
+        dt = time.perf_counter() - t0
+    ex["e2e"] = {"what": "host buffer (pageable) -> nfagg_ingest -> nfagg_evict to host memory: PCIe-inclusive, %d M records, 1 timed pass after 1 warm-up" % (m // 1_000_000),
+                 "ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m / dt / 1e6, 1), "GBs_host_to_device": round(m * 144 / dt / 1e9, 1),
+                 "evicted_flows": int(flows), "bound": "PCIe Gen5 x16 + host memcpy into the pinned ring"}
+
+    # ---- the reference's default CACHE_MAX_FLOWS = 5000 (pkg/config/config.go:146): the stream stops on "full" every few
+    # thousand records; host path and device-resident
+    m2 = min(4_000_000, m)
+    with nf.FlowTable(max_entries=5000, device=torch.cuda.current_device()) as tab:
+        def small(dev):
+            off, evictions, flows = 0, 0, 0
+            while off < m2:
+                if dev:
+                    rc, c = tab.ingest_device(d_recs.data_ptr() + off * 144, m2 - off)
+                else:
+                    rc, c = tab.ingest(host[off:m2])
+                off += c
+                if rc == nf.FULL:
+                    flows += tab.evict_device(d_out.data_ptr(), 8192, nf.REASON_FULL) if dev else len(tab.evict(nf.REASON_FULL, cap=8192))
+                    evictions += 1
+            flows += len(tab.evict(nf.REASON_CLOSING, cap=8192))
+            return evictions + 1, flows
+        res = {}
+        for dev in (False, True):
+            small(dev)
+            t0 = time.perf_counter()
+            evs, flows = small(dev)
+            dt = time.perf_counter() - t0
+            res["device_resident" if dev else "host_path"] = {"ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m2 / dt / 1e6, 1), "evictions": evs,
+                                                             "evicted_flows": int(flows), "us_per_epoch": round(dt / evs * 1e6, 1)}
+    ex["cache_max_flows_5000"] = {"what": "CACHE_MAX_FLOWS = 5000 (the reference's default): %d M records of the configs[1] stream, evict-on-full "
+                                          "(account.go:85-94) every ~%d records" % (m2 // 1_000_000, m2 // max(res["host_path"]["evictions"], 1)), **res}
+    return ex
 
 
 def group_main(args, torch):
@@ -313,7 +594,8 @@ def group_main(args, torch):
     import netobserv_ebpf_agent_amd as nf
     from netobserv_ebpf_agent_amd import synth
     devs = [int(x) for x in args.group_devices.split(",")]
-    D, n, keys = len(devs), args.records, args.flows * len(devs)
+    n, keys1 = resolve_sizes(args, 1)
+    D, keys = len(devs), keys1 * len(devs)
     th = synth.zipf_thresholds(keys, args.zipf)
     slices, outs = [], []
     for i, d in enumerate(devs):
@@ -324,7 +606,7 @@ def group_main(args, torch):
         synth.stream_device(buf.data_ptr(), n, j0=i * n, seed=2, n_keys=keys, d_thresholds=d_th.data_ptr(), hot_permille=args.hot_permille, variant=0)
         torch.cuda.synchronize()
         slices.append(buf)
-        outs.append(torch.empty((2 * args.flows + 4096) * 144, dtype=torch.uint8, device="cuda"))
+        outs.append(torch.empty((2 * keys1 + 4096) * 144, dtype=torch.uint8, device="cuda"))
     sk_flags = (nf.SKETCH_CM | nf.SKETCH_HLL) if args.sketches else 0
     max_entries = (args.max_entries or DEFAULT_MAX_ENTRIES) * D
     if args.group_local_fold:
@@ -332,11 +614,23 @@ def group_main(args, torch):
         outs = [torch.empty((2 * keys // D + 4096) * 144, dtype=torch.uint8, device="cuda:%d" % d) for d in devs]
     grp = nf.FlowGroup(devs, max_entries=max_entries, sketches=sk_flags, profile=True, local_fold=args.group_local_fold)
     out_cap = [o.numel() // 144 for o in outs]
+    threads = args.group_threads and args.group_local_fold
+
+    def feed(i):
+        rc, c = grp.ingest_device(i, slices[i].data_ptr(), n)
+        assert rc == nf.OK and c == n, (rc, c)
 
     def step():
-        for i in range(D):
-            rc, c = grp.ingest_device(i, slices[i].data_ptr(), n)
-            assert rc == nf.OK and c == n, (rc, c)
+        if threads:
+            import threading
+            ths = [threading.Thread(target=feed, args=(i,)) for i in range(D)]
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join()
+        else:
+            for i in range(D):
+                feed(i)
         if args.sketches:
             grp.merge_sketches()
         got = grp.evict_device([o.data_ptr() for o in outs], out_cap, nf.REASON_TIMEOUT)
@@ -362,17 +656,17 @@ def group_main(args, torch):
     sts = [m.stats() for m in grp.members]
     fold_ms = [st.ingest_kernel_ms / max(st.ingest_launches, 1) for st in sts]
     out = {
-        "metric": "flow-records/s ingested + evictions/s, 1/2/4/8 GPU; % HBM roofline",
+        "metric": METRIC,
         "value": round(n * D * steps / dt / 1e6, 3), "unit": "Mrecords/s", "n_gpus": len(set(devs)), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {
             "workload": "configs[3] shape through nfagg_group_*: ONE common %dM-record Zipf(%.1f) stream over %dk flows, %d members on devices %s, "
                         "%s%s, device-resident input" % (n * D // 1_000_000, args.zipf, keys // 1000, D, devs,
-                                                         "local fold, raw slots merged into their owners at the eviction" if args.group_local_fold
+                                                         "local fold, partials merged into their owners at the eviction" if args.group_local_fold
                                                          else "device partition + routing by key hash",
                                                          ", CM+HLL merged per step" if args.sketches else ""),
-            "group_mode": "local_fold" if args.group_local_fold else "routed",
+            "group_mode": "local_fold" if args.group_local_fold else "routed", "host_threads": D if threads else 1,
             "members": D, "devices": devs, "records_per_member_slice": n, "unique_flows_total": keys, "max_entries_total": max_entries,
             "evicted_flows_per_step": flows, "parallelism": "one process, group of %d members (distinct devices: %s)" % (D, len(set(devs)) == D),
             "member_fold_ms_per_launch": [round(x, 3) for x in fold_ms],
@@ -381,7 +675,8 @@ def group_main(args, torch):
     }
     print(json.dumps(out), flush=True)
     grp.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

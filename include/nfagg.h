@@ -684,6 +684,55 @@ int nfagg_group_evict(nfagg_group* g, int reason, void* out, size_t cap, size_t*
  * buffer is too small. */
 int nfagg_group_evict_device(nfagg_group* g, int reason, void* const* d_out, const size_t* cap, size_t* n_out);
 
+/* ------------------------------------------------------------------ */
+/* Local fold across GPUs with ONE PROCESS PER GPU (ranks of a           */
+/* torch.distributed / MPI job; the in-process form is                   */
+/* NFAGG_GROUP_LOCAL_FOLD above). Every rank owns an unsharded handle     */
+/* (n_shards = 1) and folds the part of the ONE record stream that        */
+/* arrives at it, whatever its keys — no per-record routing. Sequence     */
+/* numbers must be global to the job: before folding a chunk the rank     */
+/* tells the handle the arrival position of its first record              */
+/* (nfagg_set_sequence). At the eviction tick a table's slots are         */
+/* mergeable partials of their flows (sums, ORs, maxima, sequence-tagged  */
+/* words where the earlier / later record wins):                          */
+/*   1. nfagg_partials_export_device  the live flows as 192-byte          */
+/*      partials grouped by owner, owner = nfagg_shard_of(key, n_shards)  */
+/*   2. the caller moves segment o to rank o (RCCL all-to-all over xGMI,  */
+/*      hipMemcpyPeerAsync, ...)                                          */
+/*   3. nfagg_partials_merge_device   rank o merges what it received      */
+/*   4. nfagg_evict_owned_device      rank o evicts the flows it owns;    */
+/*      everything else in its table expires with the epoch.              */
+/* The union of the ranks' evictions is bit-identical to ONE sequential   */
+/* Accounter (pkg/flow/account.go:58-124) over the records folded since   */
+/* the last eviction, in the order of their sequence numbers.             */
+/* NFAGG_MODE_ACCOUNTER only.                                             */
+/* ------------------------------------------------------------------ */
+#define NFAGG_PARTIAL_BYTES 192u
+#define NFAGG_SHARD_NONE 0xFFFFFFFFu
+
+/* The next record folded by this handle carries sequence number next_seq (epoch-relative: every eviction restarts the
+ * epoch at 0). Must not be smaller than the number the handle has reached. Gaps are harmless: only the order matters. */
+int nfagg_set_sequence(nfagg_handle* h, uint64_t next_seq);
+
+/* Step 1. d_out: DEVICE memory, 64-byte aligned, room for `cap` partials of NFAGG_PARTIAL_BYTES. Segment o (the flows shard
+ * o owns) starts at partial sum(counts[0..o)) and holds counts[o] partials; counts: HOST array of n_shards (<= 64) words.
+ * The flows of self_shard stay in the table and are not exported (counts[self_shard] = 0); NFAGG_SHARD_NONE exports all.
+ * *n_out = partials written. NFAGG_TRUNCATED (nothing written, nothing changed, *n_out = partials needed; an upper bound
+ * known in advance is nfagg_len) when cap is too small. Synchronous: the partials are complete when the call returns.
+ * Afterwards the handle accepts no records (nfagg_ingest* return NFAGG_FULL) until nfagg_evict_owned_device ran: the
+ * exported flows still sit in the table and would be exported twice. */
+int nfagg_partials_export_device(nfagg_handle* h, uint32_t n_shards, uint32_t self_shard, void* d_out, size_t cap,
+                                 uint64_t* counts, size_t* n_out);
+/* Step 3. d_partials: n partials in DEVICE memory of this handle's device (16-byte aligned), all owned by shard_id of
+ * n_shards (a partial of another shard fails the next synchronising call). Asynchronous on the handle's stream: the buffer
+ * must stay valid until the handle synchronises. May be called several times (one call per source). The table needs room
+ * for the flows it receives: size it with table_log2_slots (about 4 slots per max_entries, as the group does). */
+int nfagg_partials_merge_device(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id, const void* d_partials, size_t n);
+/* Step 4. nfagg_evict_device restricted to the flows shard_id of n_shards owns; ends the epoch of the whole table.
+ * NFAGG_TRUNCATED (nothing evicted, *n_out = records needed) when cap is too small. */
+int nfagg_evict_owned_device(nfagg_handle* h, int reason, uint32_t n_shards, uint32_t shard_id, void* d_out, size_t cap,
+                             size_t* n_out);
+
 /* Testing aid: account for `records` more records in the current eviction epoch without folding any (their sequence
  * numbers are skipped), so that the 2^32-16 records-per-epoch boundary can be reached without feeding 600 GB. */
 int nfagg_debug_skip_sequence(nfagg_handle* h, uint64_t records);

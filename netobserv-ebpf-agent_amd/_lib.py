@@ -30,6 +30,8 @@ REASON_TIMEOUT, REASON_FULL, REASON_CLOSING = 0, 1, 2
 REASON_NAMES = {0: "timeout", 1: "full", 2: "closing"}
 MODE_ACCOUNTER, MODE_KERNEL_DEDUP = 0, 1
 GROUP_LOCAL_FOLD = 1
+PARTIAL_BYTES = 192
+SHARD_NONE = 0xFFFFFFFF
 SKETCH_CM, SKETCH_HLL = 1, 2
 CM_SRC, CM_DST, HLL_SRC, HLL_DST = 0, 1, 2, 3
 
@@ -138,6 +140,10 @@ SIGNATURES = {
     "nfagg_sync": (C.c_int, [_vp]),
     "nfagg_stream": (_vp, [_vp]),
     "nfagg_debug_skip_sequence": (C.c_int, [_vp, C.c_uint64]),
+    "nfagg_set_sequence": (C.c_int, [_vp, C.c_uint64]),
+    "nfagg_partials_export_device": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _sz, C.POINTER(C.c_uint64), _psz]),
+    "nfagg_partials_merge_device": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _sz]),
+    "nfagg_evict_owned_device": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, _vp, _sz, _psz]),
     "nfagg_group_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(_vp)]),
     "nfagg_group_destroy": (None, [_vp]),
     "nfagg_group_last_error": (C.c_char_p, [_vp]),

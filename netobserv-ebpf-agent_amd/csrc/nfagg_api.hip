@@ -102,6 +102,12 @@ struct nfagg_handle {
     uint8_t* h_careful = nullptr;   // pinned: block counts + flags of a claim + flag chunk of up to kCarefulMaxBatch records
     bool must_evict = false; // a "full" split is pending (account.go:85-94)
     uint64_t split_seq = 0;
+    // local fold across GPUs (nfagg_partials_*): the flows of other shards have been exported to their owners; nothing may be
+    // folded on top of them before the eviction (they would be exported twice)
+    bool exported = false;
+    void* d_exp = nullptr;          // 64 owner counts + 64 segment cursors + the owned-flows count
+    size_t d_exp_cap = 0;
+    unsigned long long* h_exp = nullptr;   // pinned mirror of the counts
     nfagg_stats stats{};
     std::vector<EventPair> ev_pending;
     std::vector<EventPair> ev_free;
@@ -198,7 +204,7 @@ int refresh_counters(nfagg_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->h_ctr, h->tv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->h_ctr->error)
-        return fail(h, NFAGG_EDEVICE, "flow table kernel bailed out (code %u: 1 = probe overflow / table too small, 2 = claim spin limit, 3 = slot lock spin limit)", h->h_ctr->error);
+        return fail(h, NFAGG_EDEVICE, "flow table kernel bailed out (code %u: 1 = probe overflow / table too small, 2 = claim spin limit, 5 = spill overflow list full, 6 = claimed slot without a record, 7 = partial of another shard merged)", h->h_ctr->error);
     h->live_ub = h->h_ctr->n_live;
     if (!h->must_evict) h->live = h->h_ctr->n_live;
     h->counters_exact = true; h->mirror_fresh = true;
@@ -353,7 +359,7 @@ int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t*
     const uint64_t maxe = h->cfg.max_entries;
     const char* base = static_cast<const char*>(d_records);
     int rc = NFAGG_OK;
-    if (h->must_evict) { if (consumed_out) *consumed_out = 0; return n ? NFAGG_FULL : NFAGG_OK; }
+    if (h->must_evict || h->exported) { if (consumed_out) *consumed_out = 0; return n ? NFAGG_FULL : NFAGG_OK; }
     constexpr uint64_t kSeqLimit = 0xFFFFFFF0ull;   // sequence numbers are epoch-relative and 32 bits wide
     while (consumed < n) {
         uint64_t rem = n - consumed;
@@ -666,6 +672,8 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->tv.ctr) hipFree(h->tv.ctr);
     if (h->h_ctr) hipHostFree(h->h_ctr);
     if (h->h_careful) hipHostFree(h->h_careful);
+    if (h->h_exp) hipHostFree(h->h_exp);
+    if (h->d_exp) hipFree(h->d_exp);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -795,9 +803,10 @@ int nfagg_len(nfagg_handle* h, uint64_t* entries) {
 static int finish_epoch(nfagg_handle* h, int reason, uint64_t flows) {
     h->stats.evictions[reason]++;
     h->stats.evicted_flows[reason] += flows;
-    h->epoch_seq = 0; h->live = 0; h->live_ub = 0; h->must_evict = false; h->split_seq = 0;
+    h->epoch_seq = 0; h->live = 0; h->live_ub = 0; h->must_evict = false; h->split_seq = 0; h->exported = false;
     h->counters_exact = true;          // k_reset_after_evict left n_live = 0
     h->epoch_unclustered = false;
+    h->abort_cap = 0;                  // one batch with more new keys than the table takes does not cap the chunks of later epochs
     // The table itself was not touched: the slots of the evicted flows simply belong to a past epoch now.
     // Tags hold 16 bits of epoch; when they wrap (every 65 535 evictions) the tags are cleared once.
     uint64_t next_epoch = (h->tv.epoch_bits >> 48) + 1;
@@ -813,6 +822,7 @@ static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device
     if (!h || !n_out || reason < 0 || reason > 2) return fail(h, NFAGG_EINVAL, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = NFAGG_OK;
+    if (h->exported) return fail(h, NFAGG_ESTATE, "partials were exported from / merged into this table: evict it with nfagg_evict_owned_device");
     if (!h->counters_exact && (rc = refresh_counters(h)) != NFAGG_OK) return rc;
     const uint64_t legit = h->live;
     const uint64_t claimed = h->live_ub;          // = the device's n_live (counters_exact)
@@ -862,7 +872,7 @@ static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->mirror_fresh = true;
     if (h->h_ctr->error)
-        return fail(h, NFAGG_EDEVICE, "flow table kernel bailed out (code %u: 1 = probe overflow / table too small, 2 = claim spin limit, 3 = slot lock spin limit)", h->h_ctr->error);
+        return fail(h, NFAGG_EDEVICE, "flow table kernel bailed out (code %u: 1 = probe overflow / table too small, 2 = claim spin limit, 5 = spill overflow list full, 6 = claimed slot without a record, 7 = partial of another shard merged)", h->h_ctr->error);
     if (h->h_ctr->n_out != legit)
         return fail(h, NFAGG_EDEVICE, "evict wrote %llu records, expected %llu", (unsigned long long)h->h_ctr->n_out, (unsigned long long)legit);
     h->stats.records_skipped = h->h_ctr->n_skipped;
@@ -878,6 +888,138 @@ int nfagg_evict(nfagg_handle* h, int reason, void* out, size_t cap, size_t* n_ou
 int nfagg_evict_device(nfagg_handle* h, int reason, void* d_out, size_t cap, size_t* n_out) {
     if (d_out && ((uintptr_t)d_out & 15u)) return fail(h, NFAGG_EINVAL, "device output must be 16-byte aligned");
     return evict_core(h, reason, d_out, true, cap, n_out);
+}
+
+// ---------------------------------------------------------------- local fold across GPUs: partials (nfagg_combine.hip)
+// The three steps of the local-fold tick as handle calls. The one-process group (nfagg_group.inc) and one-process-per-GPU
+// ranks (bench.py --gpus N: exchange with an RCCL all-to-all) run the same code.
+static int partials_scratch(nfagg_handle* h) {
+    int rc = ensure_bytes(h, &h->d_exp, &h->d_exp_cap, 136 * sizeof(unsigned long long));
+    if (rc != NFAGG_OK) return rc;
+    if (!h->h_exp) HIP_TRY(h, hipHostMalloc((void**)&h->h_exp, 136 * sizeof(unsigned long long), hipHostMallocDefault));
+    return NFAGG_OK;
+}
+
+// counts[o] (host, n_shards words) = flows of segment o; *n_out = their sum. NFAGG_TRUNCATED (nothing written, state unchanged)
+// when cap is too small. The partials are complete in d_out when the call returns.
+static int partials_export_core(nfagg_handle* h, uint32_t n_shards, uint32_t self_shard, void* d_out, size_t cap, uint64_t* counts,
+                                size_t* n_out) {
+    if (!h || !counts || !n_out) return fail(h, NFAGG_EINVAL, "null argument");
+    if (n_shards == 0 || n_shards > 64) return fail(h, NFAGG_EINVAL, "n_shards must be in [1, 64]");
+    if (h->cfg.mode != NFAGG_MODE_ACCOUNTER) return fail(h, NFAGG_EINVAL, "partials need NFAGG_MODE_ACCOUNTER (the kernel-dedup slots do not merge across tables)");
+    if (h->cfg.n_shards > 1) return fail(h, NFAGG_ESTATE, "a handle that filters its input by shard (n_shards > 1) holds no other shard's flows");
+    if (d_out && ((uintptr_t)d_out & 63u)) return fail(h, NFAGG_EINVAL, "partials buffer must be 64-byte aligned");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = partials_scratch(h);
+    if (rc != NFAGG_OK) return rc;
+    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;
+    const uint64_t claimed = h->h_ctr->n_live;
+    const uint64_t seq_limit = h->must_evict ? h->split_seq : ~0ull;
+    unsigned long long* d_counts = (unsigned long long*)h->d_exp;
+    unsigned long long* d_cursor = d_counts + 64;
+    hipError_t e = launch_export_count(h->tv, claimed, seq_limit, n_shards, self_shard, d_counts, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "partials count launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync(h->h_exp, d_counts, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    uint64_t total = 0;
+    for (uint32_t o = 0; o < n_shards; o++) { counts[o] = h->h_exp[o]; h->h_exp[64 + o] = total; total += counts[o]; }
+    *n_out = (size_t)total;
+    if (total > cap) return NFAGG_TRUNCATED;
+    if (total && !d_out) return fail(h, NFAGG_EINVAL, "null partials buffer");
+    if (total) {
+        HIP_TRY(h, hipMemcpyAsync(d_cursor, h->h_exp + 64, 64 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+        e = launch_export_scatter(h->tv, claimed, seq_limit, n_shards, self_shard, d_cursor, d_out, h->stream);
+        if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "partials export launch failed: %s", hipGetErrorString(e));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    if (self_shard < n_shards && n_shards > 1) h->exported = true;       // other shards' flows are on their way to their owners
+    return NFAGG_OK;
+}
+
+// Asynchronous (the handle's stream); d_partials must stay valid until the handle synchronises.
+static int partials_merge_core(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id, const void* d_partials, size_t n) {
+    if (!h || (n && !d_partials)) return fail(h, NFAGG_EINVAL, "null argument");
+    if (n_shards == 0 || n_shards > 64 || shard_id >= n_shards) return fail(h, NFAGG_EINVAL, "bad shard (n_shards in [1, 64], shard_id < n_shards)");
+    if (h->cfg.mode != NFAGG_MODE_ACCOUNTER) return fail(h, NFAGG_EINVAL, "partials need NFAGG_MODE_ACCOUNTER");
+    if ((uintptr_t)d_partials & 15u) return fail(h, NFAGG_EINVAL, "partials buffer must be 16-byte aligned");
+    if (n == 0) return NFAGG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    TableView tv = h->tv;
+    tv.n_shards = n_shards; tv.shard_id = shard_id;
+    h->counters_exact = false; h->mirror_fresh = false;                  // the merge claims slots
+    h->exported = true;                                                  // merged state: only the eviction may follow
+    const hipError_t e = launch_merge_raw(tv, d_partials, n, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "partials merge launch failed: %s", hipGetErrorString(e));
+    return NFAGG_OK;
+}
+
+// *owned = flows of this table that (n_shards, shard_id) owns — what evict_owned_core will write. Synchronises; reports
+// claims refused by a merge.
+static int owned_count_core(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id, uint64_t* owned, uint64_t* claimed_out) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = partials_scratch(h);
+    if (rc != NFAGG_OK) return rc;
+    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;
+    if (h->h_ctr->aborted) return fail(h, NFAGG_EDEVICE, "table too small for the flows this shard owns (claims refused while merging)");
+    const uint64_t claimed = h->h_ctr->n_live;
+    TableView tv = h->tv;
+    tv.n_shards = n_shards; tv.shard_id = shard_id;
+    unsigned long long* d_owned = (unsigned long long*)h->d_exp + 128;
+    const hipError_t e = launch_count_owned(tv, claimed, h->must_evict ? h->split_seq : ~0ull, d_owned, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "owned count launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync(h->h_exp + 128, d_owned, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *owned = h->h_exp[128];
+    if (claimed_out) *claimed_out = claimed;
+    return NFAGG_OK;
+}
+
+static int evict_owned_core(nfagg_handle* h, int reason, uint32_t n_shards, uint32_t shard_id, void* d_out, size_t cap, size_t* n_out) {
+    if (!h || !n_out || reason < 0 || reason > 2) return fail(h, NFAGG_EINVAL, "bad argument");
+    if (n_shards == 0 || n_shards > 64 || shard_id >= n_shards) return fail(h, NFAGG_EINVAL, "bad shard (n_shards in [1, 64], shard_id < n_shards)");
+    if (h->cfg.mode != NFAGG_MODE_ACCOUNTER) return fail(h, NFAGG_EINVAL, "partials need NFAGG_MODE_ACCOUNTER");
+    if (d_out && ((uintptr_t)d_out & 15u)) return fail(h, NFAGG_EINVAL, "device output must be 16-byte aligned");
+    uint64_t owned = 0, claimed = 0;
+    int rc = owned_count_core(h, n_shards, shard_id, &owned, &claimed);
+    if (rc != NFAGG_OK) return rc;
+    *n_out = (size_t)owned;
+    if (owned > cap) return NFAGG_TRUNCATED;
+    if (owned && !d_out) return fail(h, NFAGG_EINVAL, "null output buffer");
+    if (reason == NFAGG_REASON_TIMEOUT && claimed == 0 && !h->exported) return NFAGG_OK;      // account.go:64-66
+    HIP_TRY(h, hipMemsetAsync(&h->tv.ctr->n_out, 0, sizeof(unsigned long long), h->stream));
+    TableView tv = h->tv;
+    tv.n_shards = n_shards; tv.shard_id = shard_id;
+    EventPair ep{};
+    if (h->cfg.profile) prof_begin(h, ep, 1);
+    const hipError_t e = launch_evict_filtered(tv, claimed, h->must_evict ? h->split_seq : ~0ull, d_out, h->stream);
+    if (h->cfg.profile) prof_end(h, ep);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "evict launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync(h->h_ctr, h->tv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->h_ctr->n_out != owned)
+        return fail(h, NFAGG_EDEVICE, "evict wrote %llu records, expected %llu", (unsigned long long)h->h_ctr->n_out, (unsigned long long)owned);
+    return finish_epoch(h, reason, owned);
+}
+
+int nfagg_partials_export_device(nfagg_handle* h, uint32_t n_shards, uint32_t self_shard, void* d_out, size_t cap, uint64_t* counts, size_t* n_out) {
+    return partials_export_core(h, n_shards, self_shard, d_out, cap, counts, n_out);
+}
+
+int nfagg_partials_merge_device(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id, const void* d_partials, size_t n) {
+    return partials_merge_core(h, n_shards, shard_id, d_partials, n);
+}
+
+int nfagg_evict_owned_device(nfagg_handle* h, int reason, uint32_t n_shards, uint32_t shard_id, void* d_out, size_t cap, size_t* n_out) {
+    return evict_owned_core(h, reason, n_shards, shard_id, d_out, cap, n_out);
+}
+
+int nfagg_set_sequence(nfagg_handle* h, uint64_t next_seq) {
+    if (!h) return NFAGG_EINVAL;
+    if (next_seq < h->epoch_seq) return fail(h, NFAGG_EINVAL, "sequence numbers do not go backwards inside an epoch (%llu < %llu)",
+                                             (unsigned long long)next_seq, (unsigned long long)h->epoch_seq);
+    if (next_seq >= 0xFFFFFFF0ull) return fail(h, NFAGG_ERANGE, "would pass the end of the epoch's sequence space");
+    h->epoch_seq = next_seq;
+    return NFAGG_OK;
 }
 
 // pkg/model/record.go:90-97

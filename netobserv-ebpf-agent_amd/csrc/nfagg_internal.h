@@ -183,10 +183,16 @@ hipError_t launch_partition(const void* d_records, uint64_t n, uint32_t n_shards
 // d_cnt[s] = entries of bucket s with original index < m
 hipError_t launch_partition_prefix_counts(const uint32_t* d_orig, const uint64_t* d_count, uint32_t n_shards, uint64_t m,
                                           uint64_t* d_cnt, hipStream_t s);
-// Group local-fold mode (nfagg_combine.hip): merge the raw slots at d_raw (k_snapshot's layout, n slots of another member's
-// table) that THIS shard owns (t.n_shards / t.shard_id) into t: phase 1 (identity_phase = false) everything that combines,
-// phase 2 the winner's plain identity dwords. launch_count_owned: owned flows of t itself.
-hipError_t launch_merge_raw(const TableView& t, const void* d_raw, uint64_t n, uint64_t seq_limit, bool identity_phase, hipStream_t s);
+// Local-fold mode (nfagg_combine.hip): the live slots of a table as 192-byte PARTIALS grouped by owner shard, and their merge
+// into the owner's table. launch_export_count: d_counts[0..64) = flows per owner (self_shard's are not exported);
+// launch_export_scatter: d_cursor[o] = first position of segment o in d_out; launch_merge_raw: everything that combines, then
+// the winner's plain identity dwords (t.n_shards / t.shard_id = the merging shard); launch_count_owned: owned flows of t itself.
+constexpr size_t kPartialBytes = 192;
+hipError_t launch_export_count(const TableView& t, uint64_t n_live, uint64_t seq_limit, uint32_t n_shards, uint32_t self_shard,
+                               unsigned long long* d_counts, hipStream_t s);
+hipError_t launch_export_scatter(const TableView& t, uint64_t n_live, uint64_t seq_limit, uint32_t n_shards, uint32_t self_shard,
+                                 unsigned long long* d_cursor, void* d_out, hipStream_t s);
+hipError_t launch_merge_raw(const TableView& t, const void* d_partials, uint64_t n, hipStream_t s);
 hipError_t launch_count_owned(const TableView& t, uint64_t n_live, uint64_t seq_limit, unsigned long long* d_count, hipStream_t s);
 // Sketch update over a batch (nfagg_sketch.hip).
 hipError_t launch_sketch_update(const SketchView& sk, const TableView& t, const void* d_records, uint64_t n, hipStream_t s);

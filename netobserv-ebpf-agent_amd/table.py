@@ -330,6 +330,29 @@ class FlowTable:
     def sync(self):
         self._check(L.lib.nfagg_sync(self._h))
 
+    # -- local fold across GPUs, one process per GPU (nfagg_partials_*)
+    def set_sequence(self, next_seq: int):
+        self._check(L.lib.nfagg_set_sequence(self._h, next_seq))
+
+    def partials_export_device(self, n_shards: int, self_shard: int, d_out: int, cap: int):
+        """The live flows as 192-byte partials grouped by owner shard, into device memory at d_out (room for cap partials).
+        Returns (rc, counts[n_shards], n): rc TRUNCATED = nothing written, n partials needed."""
+        counts = (C.c_uint64 * n_shards)()
+        n = C.c_size_t(0)
+        rc = L.lib.nfagg_partials_export_device(self._h, n_shards, self_shard, C.c_void_p(d_out or None), cap, counts, C.byref(n))
+        self._check(rc, (L.OK, L.TRUNCATED))
+        return rc, [int(x) for x in counts], n.value
+
+    def partials_merge_device(self, n_shards: int, shard_id: int, d_partials: int, n: int):
+        self._check(L.lib.nfagg_partials_merge_device(self._h, n_shards, shard_id, C.c_void_p(d_partials or None), n))
+
+    def evict_owned_device(self, n_shards: int, shard_id: int, d_out: int, cap: int, reason=L.REASON_TIMEOUT):
+        """Returns (rc, n): rc TRUNCATED = nothing evicted, n records needed."""
+        n = C.c_size_t(0)
+        rc = L.lib.nfagg_evict_owned_device(self._h, reason, n_shards, shard_id, C.c_void_p(d_out or None), cap, C.byref(n))
+        self._check(rc, (L.OK, L.TRUNCATED))
+        return rc, n.value
+
     def debug_skip_sequence(self, records: int):
         self._check(L.lib.nfagg_debug_skip_sequence(self._h, records))
 

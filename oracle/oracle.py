@@ -314,11 +314,10 @@ _REF_SO = os.path.join(_HERE, "_ref", "libref_flows.so")
 _ref = None
 
 
-def ref_available(build_if_possible=True) -> bool:
-    """True when oracle/_ref/libref_flows.so exists (it is built only where /root/reference exists; the built file
-    travels to the GPU box with the snapshot)."""
-    if not os.path.exists(_REF_SO) and build_if_possible and os.path.exists("/root/reference/bpf/flows.c"):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+def ref_available() -> bool:
+    """True when oracle/_ref/libref_flows.so exists. A pure predicate: the library is built explicitly — `make -C oracle ref`
+    (what __graft_entry__.build() runs where /root/reference exists), which refuses to compile anything but the text pinned
+    in oracle/ref_flows.sha256 — and travels to the GPU box with the snapshot."""
     return os.path.exists(_REF_SO)
 
 

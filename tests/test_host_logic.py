@@ -136,3 +136,25 @@ def test_oracle_heavy_hitters_against_numpy(O):
             assert len(got) == len(want)
             assert [g["ip"].tobytes() for g in got] == [ips[i].tobytes() for i in want]
             assert [int(g["estimate"]) for g in got] == [int(est[i]) for i in want]
+
+
+def test_bench_gpus_n_as_a_plain_process_spawns_its_ranks():
+    """`python bench.py --gpus N` must not exit with an error when it is not launched by torch.distributed.run (the driver
+    ran the N = 1 bench as a plain command): it becomes the launcher of its N ranks, with the contract's own command line."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--print-spawn"],
+                         capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    cmd = out.stdout.split()
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    sys.path.insert(0, root)
+    import bench
+    a = bench.parse_args(["--gpus", "8"])
+    assert bench.resolve_sizes(a, 8) == (125_000_000, 1_250_000)         # BASELINE.json configs[3]: 1 B records, 10 M flows over 8 GPUs
+    assert bench.resolve_sizes(bench.parse_args([]), 1) == (100_000_000, 1_000_000)   # configs[1]
