@@ -33,21 +33,26 @@ constexpr int kEntries = 1024;
 constexpr int kProbe = 8;         // cache probe window
 constexpr int kStage = 4;         // staged spills per partition = one 16-byte store
 
+// 116 bytes per entry, laid out as arrays of 16-BYTE UNITS so that phase B reads an entry's key with three ds_read_b128 and its
+// guard words (what decides which atomics can change anything) with two, instead of eleven 8- and 4-byte reads (round 2's
+// field-per-array layout): the fold loops are bound by LDS instructions issued, not by LDS bytes.
 struct Cache {
-    uint64_t h64[kEntries];       // 0 = free, else key hash | 1
-    uint64_t key[5][kEntries];
-    uint64_t bytes[kEntries];
-    uint64_t end[kEntries];
-    uint64_t start_inv[kEntries];
-    uint64_t eth_tag[kEntries];
-    uint64_t dscp_tag[kEntries];
-    uint64_t samp_tag[kEntries];
+    uint4 k0[kEntries];           // x,y: key hash | 1 (0 = free)   z,w: key word 0
+    uint4 k1[kEntries];           // key words 1, 2
+    uint4 k2[kEntries];           // key words 3, 4
+    uint4 t[kEntries];            // x,y: end (max)                 z,w: start_inv (max of ~start)
+    uint4 q[kEntries];            // x: flags (OR)  y: first_seq  z: smac_seq  w: dmac_seq — min seq32 of the records folded into the entry
+                                  //    (all of them / those with a non-zero src_mac / dst_mac)
+    uint4 v[kEntries];            // x,y: bytes (sum)               z,w: samp_tag
+    uint4 w[kEntries];            // x,y: eth_tag                   z,w: dscp_tag
     uint32_t packets[kEntries];
-    uint32_t flags[kEntries];
-    uint32_t first_seq[kEntries]; // min seq32 of the records folded into the entry
-    uint32_t smac_seq[kEntries];  // min seq32 over those with a non-zero src_mac
-    uint32_t dmac_seq[kEntries];
 };
+static_assert(sizeof(Cache) == 116 * kEntries, "cache entry");
+NF_DEV uint64_t u64lo(const uint4& a) { return (uint64_t)a.x | ((uint64_t)a.y << 32); }
+NF_DEV uint64_t u64hi(const uint4& a) { return (uint64_t)a.z | ((uint64_t)a.w << 32); }
+NF_DEV uint4 mk4(uint64_t lo, uint64_t hi) { return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)); }
+NF_DEV unsigned long long* lo64(uint4* a) { return reinterpret_cast<unsigned long long*>(a); }
+NF_DEV unsigned long long* hi64(uint4* a) { return reinterpret_cast<unsigned long long*>(a) + 1; }
 
 struct Stage {
     uint32_t buf[kSpillParts][kStage];
@@ -66,10 +71,10 @@ struct Door { uint32_t bits[kDoorBits / 32]; };
 NF_DEV uint32_t part_of(uint64_t h, uint32_t shift) { return (uint32_t)(h >> shift) & (kSpillParts - 1); }
 
 NF_DEV void cache_init(Cache& L, int tid) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
     for (int e = tid; e < kEntries; e += kBlock) {
-        L.h64[e] = 0; L.bytes[e] = 0; L.end[e] = 0; L.start_inv[e] = 0; L.eth_tag[e] = 0; L.dscp_tag[e] = 0;
-        L.samp_tag[e] = 0; L.packets[e] = 0; L.flags[e] = 0;
-        L.first_seq[e] = 0xffffffffu; L.smac_seq[e] = 0xffffffffu; L.dmac_seq[e] = 0xffffffffu;
+        L.k0[e] = z; L.t[e] = z; L.v[e] = z; L.w[e] = z; L.packets[e] = 0;
+        L.q[e] = make_uint4(0, 0xffffffffu, 0xffffffffu, 0xffffffffu);
     }
 }
 
@@ -80,7 +85,7 @@ NF_DEV int cache_claim(Cache& L, uint32_t* door, uint64_t h, const uint64_t w[5]
     uint32_t e = (uint32_t)(h >> 40) & (kEntries - 1);
 #pragma unroll 1
     for (int p = 0; p < kProbe; p++) {
-        uint64_t cur = L.h64[e];
+        uint64_t cur = *lo64(&L.k0[e]);
         if (cur == 0) {
             if (DOOR) {
                 const uint32_t b = (uint32_t)(h >> 14) & (kDoorBits - 1), m = 1u << (b & 31);
@@ -88,10 +93,11 @@ NF_DEV int cache_claim(Cache& L, uint32_t* door, uint64_t h, const uint64_t w[5]
                 // is turned away (a hot flow would otherwise spill a whole burst into one partition's staging group)
                 if (!(door[b >> 5] & m) && !(atomicOr(&door[b >> 5], m) & m)) return -1;
             }
-            cur = atomicCAS((unsigned long long*)&L.h64[e], 0ull, (unsigned long long)hk);
+            cur = atomicCAS(lo64(&L.k0[e]), 0ull, (unsigned long long)hk);
             if (cur == 0) {
-#pragma unroll
-                for (int k = 0; k < 5; k++) L.key[k][e] = w[k];
+                *hi64(&L.k0[e]) = w[0];
+                L.k1[e] = mk4(w[1], w[2]);
+                L.k2[e] = mk4(w[3], w[4]);
                 return (int)e;
             }
         }
@@ -103,23 +109,23 @@ NF_DEV int cache_claim(Cache& L, uint32_t* door, uint64_t h, const uint64_t w[5]
 
 // phase B (after a barrier): full-key check, then AccumulateBase into the entry
 NF_DEV int cache_fold(Cache& L, int ent, const Rec& r, const uint64_t w[5], uint32_t seq32) {
-    bool same = true;
-#pragma unroll
-    for (int k = 0; k < 5; k++) same &= (L.key[k][ent] == w[k]);
+    const uint4 a = L.k0[ent], b = L.k1[ent], c = L.k2[ent];
+    const bool same = ((u64hi(a) ^ w[0]) | (u64lo(b) ^ w[1]) | (u64hi(b) ^ w[2]) | (u64lo(c) ^ w[3]) | (u64hi(c) ^ w[4])) == 0;
     if (!same) return -1;         // two flows with one 64-bit hash: the later one is spilled / merged directly
-    if (r.bytes()) atomicAdd((unsigned long long*)&L.bytes[ent], (unsigned long long)r.bytes());
+    const uint4 tt = L.t[ent], qq = L.q[ent];
+    if (r.bytes()) atomicAdd(lo64(&L.v[ent]), (unsigned long long)r.bytes());
     if (r.packets()) atomicAdd(&L.packets[ent], r.packets());
-    if (r.flags() & ~L.flags[ent]) atomicOr(&L.flags[ent], r.flags());
-    if (r.end() > L.end[ent]) atomicMax((unsigned long long*)&L.end[ent], (unsigned long long)r.end());
-    if (r.start() && ~r.start() > L.start_inv[ent])
-        atomicMax((unsigned long long*)&L.start_inv[ent], (unsigned long long)~r.start());
+    if (r.flags() & ~qq.x) atomicOr(reinterpret_cast<uint32_t*>(&L.q[ent]), r.flags());
+    if (r.end() > u64lo(tt)) atomicMax(lo64(&L.t[ent]), (unsigned long long)r.end());
+    if (r.start() && ~r.start() > u64hi(tt)) atomicMax(hi64(&L.t[ent]), (unsigned long long)~r.start());
     const uint64_t s1 = (uint64_t)seq32 + 1;
-    if (r.eth()) atomicMax((unsigned long long*)&L.eth_tag[ent], (unsigned long long)((s1 << 16) | r.eth()));
-    if (r.dscp()) atomicMax((unsigned long long*)&L.dscp_tag[ent], (unsigned long long)((s1 << 8) | r.dscp()));
-    if (r.sampling()) atomicMax((unsigned long long*)&L.samp_tag[ent], (unsigned long long)((s1 << 32) | r.sampling()));
-    if (L.first_seq[ent] > seq32) atomicMin(&L.first_seq[ent], seq32);
-    if (r.smac() && L.smac_seq[ent] > seq32) atomicMin(&L.smac_seq[ent], seq32);
-    if (r.dmac() && L.dmac_seq[ent] > seq32) atomicMin(&L.dmac_seq[ent], seq32);
+    if (r.eth()) atomicMax(lo64(&L.w[ent]), (unsigned long long)((s1 << 16) | r.eth()));
+    if (r.dscp()) atomicMax(hi64(&L.w[ent]), (unsigned long long)((s1 << 8) | r.dscp()));
+    if (r.sampling()) atomicMax(hi64(&L.v[ent]), (unsigned long long)((s1 << 32) | r.sampling()));
+    uint32_t* qw = reinterpret_cast<uint32_t*>(&L.q[ent]);
+    if (qq.y > seq32) atomicMin(qw + 1, seq32);
+    if (r.smac() && qq.z > seq32) atomicMin(qw + 2, seq32);
+    if (r.dmac() && qq.w > seq32) atomicMin(qw + 3, seq32);
     return ent;
 }
 
@@ -157,12 +163,12 @@ NF_DEV uint4 rec_chunk(const void* recs, uint64_t i, int k) {
 template <bool SKETCH, bool EXCL>
 NF_DEV uint32_t cache_flush_entry(const TableView& t, const SketchView& sk, Cache& L, int e, const void* recs, uint32_t seq_base32,
                                   uint32_t* new_list, uint32_t* new_cnt, bool defer, uint64_t* fresh_hash = nullptr) {
-    if (L.h64[e] == 0 || L.first_seq[e] == 0xffffffffu) return kNoSlot;   // free, or claimed but never folded into
-    uint64_t w[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
+    const uint4 ka = L.k0[e], qq = L.q[e];
+    if (u64lo(ka) == 0 || qq.y == 0xffffffffu) return kNoSlot;            // free, or claimed but never folded into
+    const uint4 kb = L.k1[e], kc = L.k2[e];
+    const uint64_t w[5] = {u64hi(ka), u64lo(kb), u64hi(kb), u64lo(kc), u64hi(kc)};
     const uint64_t h = key_hash(w);
-    const uint32_t fs = L.first_seq[e], ss = L.smac_seq[e], ds = L.dmac_seq[e];
+    const uint32_t fs = qq.y, ss = qq.z, ds = qq.w;
     uint4 s4 = make_uint4(0, 0, 0, 0), d4 = s4, d5 = s4;
     if (ss != 0xffffffffu) s4 = rec_chunk(recs, (uint64_t)(ss - seq_base32), 4);
     if (ds != 0xffffffffu) { d4 = rec_chunk(recs, (uint64_t)(ds - seq_base32), 4); d5 = rec_chunk(recs, (uint64_t)(ds - seq_base32), 5); }
@@ -176,9 +182,10 @@ NF_DEV uint32_t cache_flush_entry(const TableView& t, const SketchView& sk, Cach
         else load_hints(&t.hot[idx], x);
     }
     Partial p;
-    p.bytes = L.bytes[e]; p.end = L.end[e]; p.start_inv = L.start_inv[e];
-    p.packets = L.packets[e]; p.flags = L.flags[e];
-    p.eth_tag = L.eth_tag[e]; p.dscp_tag = L.dscp_tag[e]; p.samp_tag = L.samp_tag[e];
+    const uint4 tt = L.t[e], vv = L.v[e], ww = L.w[e];
+    p.bytes = u64lo(vv); p.end = u64lo(tt); p.start_inv = u64hi(tt);
+    p.packets = L.packets[e]; p.flags = qq.x;
+    p.eth_tag = u64lo(ww); p.dscp_tag = u64hi(ww); p.samp_tag = u64hi(vv);
     // The entry's earliest record may be the flow's first: only its sequence number goes into the slot (the tag of
     // id0); k_finalize copies that record's identity dwords from the batch after the last fold kernel of the call.
     p.first_inv = ((uint32_t)(x.id0 >> 32) <= ~fs) ? ~fs : 0u;   // tagged(0, 0) = 0 never wins
@@ -211,7 +218,9 @@ NF_DEV uint32_t sub_shift_of(const SpillView& q) { return q.part_shift >= (uint3
 // 256 workgroups stream records[0..n), tiles of 1024 consecutive records, one per lane. Hot flows fold in the workgroup's
 // persistent LDS cache; a record whose flow has no entry is spilled: its index goes to the queue of its flow's partition,
 // staged four at a time in LDS so that a spill costs one 16-byte store and a quarter of an atomic.
-template <bool SKETCH, bool TIMING, bool DOOR>
+// ABL (libnfagg_diag.so only, ingest_variant 20..27: timing experiments, results are WRONG): bit 0 = spills are counted but not
+// queued, bit 1 = no fold into the cache entry, bit 2 = no cache claim (every record counts as a miss).
+template <bool SKETCH, bool TIMING, bool DOOR, int ABL = 0>
 __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
                                                   uint64_t n, uint64_t seq_base) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -232,14 +241,17 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
     unsigned long long skipped = 0, spilled = 0;
     const bool tag_on = n <= (uint64_t)kIdxMask;                       // the index leaves room for the sub-partition bits
     const uint32_t sub_shift = sub_shift_of(q);
-    // drain state: this lane serves partitions tid and tid + kBlock. A drained group is stored one tile later, when the
-    // reservation (a returning atomic) has long arrived: no HBM round trip inside a tile.
+    // Drain state. The lane whose append FILLS a staging group (position kStage - 1) drains it one tile later — no lane polls the
+    // 2048 group counters (round 2: two LDS reads per lane and tile) — and stores the drained group another tile later, when the
+    // queue reservation (a returning atomic) has long arrived: no HBM round trip inside a tile. A lane fills at most two groups per
+    // tile: one with a carried-over spill, one with its own.
     constexpr int kMine = kSpillParts / kBlock;
-    uint4 pend_v[kMine];
-    uint32_t pend_at[kMine];
-    bool pend[kMine];
+    constexpr uint32_t kNoPart = 0xffffffffu;
+    uint4 pend_v[2];
+    uint32_t pend_at[2], pend_p[2], fill_p[2];
+    bool pend[2];
 #pragma unroll
-    for (int k = 0; k < kMine; k++) { pend[k] = false; pend_at[k] = 0; pend_v[k] = make_uint4(0, 0, 0, 0); }
+    for (int k = 0; k < 2; k++) { pend[k] = false; pend_at[k] = 0; pend_p[k] = 0; fill_p[k] = kNoPart; pend_v[k] = make_uint4(0, 0, 0, 0); }
     uint32_t carry = 0xffffffffu, carry_p = 0;                         // a spill that found its group full: retried next tile
     // Software pipeline: the records of tile k+1 are requested before tile k is folded, so no HBM latency is exposed inside
     // a tile. Loads are unconditional on a clamped index; `valid` only gates the fold.
@@ -266,24 +278,24 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
         }
         const uint32_t seq32 = seq_base32 + (uint32_t)i;
         if (TIMING) { asm volatile("" :: "v"(h)); NF_TICK(0); }
-        int ent = valid ? cache_claim<DOOR>(L, door, h, w) : -1;
+        int ent = (valid && !(ABL & 4)) ? cache_claim<DOOR>(L, door, h, w) : -1;
         NF_TICK(1);
         __syncthreads();
         NF_TICK(2);
-        if (valid && ent >= 0) ent = cache_fold(L, ent, r, w, seq32);
+        if (valid && ent >= 0 && !(ABL & 2)) ent = cache_fold(L, ent, r, w, seq32);
 #pragma unroll
-        for (int k = 0; k < kMine; k++) {
-            const int p = tid + k * kBlock;
+        for (int k = 0; k < 2; k++) {
             if (pend[k]) {
-                if (pend_at[k] + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)p * q.qcap + pend_at[k]) = pend_v[k];
+                if (pend_at[k] + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)pend_p[k] * q.qcap + pend_at[k]) = pend_v[k];
                 else overflow_push(q, pend_v[k]);                     // partition queue full (adversarial skew)
                 pend[k] = false;
             }
-            if (S.cnt[p] >= (uint32_t)kStage) {
+            if (fill_p[k] != kNoPart) {                               // filled by this lane in the previous tile: every append is in LDS (barriers since)
+                const uint32_t p = fill_p[k];
                 pend_v[k] = *reinterpret_cast<const uint4*>(S.buf[p]);
-                S.cnt[p] = 0;
+                S.cnt[p] = 0;                                         // appends resume after the next barrier
                 pend_at[k] = aadd(&q.qtail[p], (uint32_t)kStage);
-                pend[k] = true;
+                pend_p[k] = p; pend[k] = true; fill_p[k] = kNoPart;
             }
         }
         NF_TICK(3);
@@ -291,17 +303,19 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
         NF_TICK(4);
         if (carry != 0xffffffffu) {
             const uint32_t at = atomicAdd(&S.cnt[carry_p], 1u);
-            if (at < (uint32_t)kStage) S.buf[carry_p][at] = carry;
+            if (at < (uint32_t)kStage) { S.buf[carry_p][at] = carry; if (at == (uint32_t)kStage - 1) fill_p[0] = carry_p; }
             else overflow_push(q, make_uint4(carry, 0xffffffffu, 0xffffffffu, 0xffffffffu));   // full twice in a row: very rare
             carry = 0xffffffffu;
         }
         if (valid && ent < 0) {
-            const uint32_t p = part_of(h, q.part_shift);
-            const uint32_t at = atomicAdd(&S.cnt[p], 1u);
-            const uint32_t qi = (uint32_t)i | (tag_on ? ((uint32_t)(h >> sub_shift) & (uint32_t)(kSubs - 1)) << kIdxBits : 0u);
             spilled++;
-            if (at < (uint32_t)kStage) S.buf[p][at] = qi;
-            else { carry = qi; carry_p = p; }
+            if (!(ABL & 1)) {
+                const uint32_t p = part_of(h, q.part_shift);
+                const uint32_t at = atomicAdd(&S.cnt[p], 1u);
+                const uint32_t qi = (uint32_t)i | (tag_on ? ((uint32_t)(h >> sub_shift) & (uint32_t)(kSubs - 1)) << kIdxBits : 0u);
+                if (at < (uint32_t)kStage) { S.buf[p][at] = qi; if (at == (uint32_t)kStage - 1) fill_p[1] = p; }
+                else { carry = qi; carry_p = p; }
+            }
         }
         if (TIMING) NF_TICK(5);
         valid = valid_n; i = i_n;
@@ -317,14 +331,18 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
         else overflow_push(q, make_uint4(carry, 0xffffffffu, 0xffffffffu, 0xffffffffu));
     }
     __syncthreads();
-    // pending groups, then whatever is staged (padded with invalid indices)
+    // pending groups, then whatever is staged (padded with invalid indices): groups filled in the last tile are still in LDS
+    // (their fill marks are dropped here), every lane looks after its two partitions
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (pend[k]) {
+            if (pend_at[k] + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)pend_p[k] * q.qcap + pend_at[k]) = pend_v[k];
+            else overflow_push(q, pend_v[k]);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < kMine; k++) {
         const int p = tid + k * kBlock;
-        if (pend[k]) {
-            if (pend_at[k] + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)p * q.qcap + pend_at[k]) = pend_v[k];
-            else overflow_push(q, pend_v[k]);
-        }
         uint32_t c = S.cnt[p];
         if (c > (uint32_t)kStage) c = kStage;
         if (c) {
@@ -578,7 +596,7 @@ __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView 
     if (direct) aadd(&t.ctr->n_direct, direct);
 }
 
-template <bool SKETCH, bool T1 = false, bool T2 = false, bool DOOR = true>
+template <bool SKETCH, bool T1 = false, bool T2 = false, bool DOOR = true, int ABL = 0>
 static hipError_t run(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                       uint64_t seq_base, hipStream_t s) {
     const size_t lds1 = sizeof(Cache) + sizeof(Stage) + (DOOR ? sizeof(Door) : 0), lds2 = sizeof(Cache) + sizeof(Pass2Lds);
@@ -588,7 +606,7 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<SKETCH, T1, DOOR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<SKETCH, T1, DOOR, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<SKETCH, T2>),
@@ -600,7 +618,7 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     uint64_t grid = 256;
     if (grid > tiles) grid = tiles;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_pass1<SKETCH, T1, DOOR>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
+    hipLaunchKernelGGL((k_pass1<SKETCH, T1, DOOR, ABL>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_pass2<SKETCH, T2>), dim3(kSpillParts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
@@ -620,6 +638,14 @@ hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const Sp
 #ifdef NFAGG_DIAG
     if (variant == 8) return part::run<false, true, false>(t, sk, q, d_records, n, seq_base, s);   // diagnostics: pass-1 phase timing
     if (variant == 9) return part::run<false, false, true>(t, sk, q, d_records, n, seq_base, s);   // diagnostics: pass-2 phase timing
+    switch (variant) {                                                                              // diagnostics: pass-1 ablations (wrong results)
+        case 21: return part::run<false, false, false, true, 1>(t, sk, q, d_records, n, seq_base, s);
+        case 22: return part::run<false, false, false, true, 2>(t, sk, q, d_records, n, seq_base, s);
+        case 23: return part::run<false, false, false, true, 3>(t, sk, q, d_records, n, seq_base, s);
+        case 25: return part::run<false, false, false, true, 5>(t, sk, q, d_records, n, seq_base, s);
+        case 27: return part::run<false, false, false, true, 7>(t, sk, q, d_records, n, seq_base, s);
+        default: break;
+    }
 #endif
     if (variant == 11)   // A/B: pass 1 without the admission filter (first come, first served)
         return sk.flags ? part::run<true, false, false, false>(t, sk, q, d_records, n, seq_base, s)
