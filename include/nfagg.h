@@ -351,6 +351,30 @@ int nfagg_evict(nfagg_handle* h, int reason, void* out, size_t cap, size_t* n_ou
 /* Same with `d_out` in DEVICE memory. */
 int nfagg_evict_device(nfagg_handle* h, int reason, void* d_out, size_t cap, size_t* n_out);
 
+/* ------------------------------------------------------------------ */
+/* Account — the record arm of Accounter.Account WITH its evictions on   */
+/* "full" (pkg/flow/account.go:81-96) in one call.                      */
+/* ------------------------------------------------------------------ */
+
+/* Folds records in arrival order exactly as nfagg_ingest does, but does not stop at a record whose NEW key finds
+ * len(entries) >= max_entries (account.go:85): as the reference does inline (:86-94) it evicts every live flow — appended to
+ * `out`, reason "full" — restarts the epoch and inserts that record. On return *n_epochs evictions have taken place; the
+ * e-th delivered out[epoch_end[e-1] .. epoch_end[e]) (epoch_end[-1] = 0), the caller turns each into one `[]*model.Record`
+ * for the exporter (account.go:111-123, one channel send per eviction); the table holds the epoch in progress, as after
+ * nfagg_ingest. *consumed = leading records folded. Returns NFAGG_OK when all n are, NFAGG_TRUNCATED when `out` has no room
+ * for another eviction (out_cap - records written < live flows; keep out_cap >= max_entries) or max_epochs are used up:
+ * drain `out`, then call again with the rest (a pending eviction is delivered first).
+ * With a small CACHE_MAX_FLOWS (the reference ships 5000, pkg/config/config.go:146) the stream stops on "full" every few
+ * thousand records; here that whole loop — split search, fold, eviction, next epoch — runs on the device in one persistent
+ * kernel (max_entries <= 32768, NFAGG_MODE_ACCOUNTER), the host reads back one control block per call.
+ * All pointers HOST memory: */
+int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, size_t out_cap, uint64_t* epoch_end,
+                  size_t max_epochs, size_t* n_epochs, size_t* consumed);
+/* Same with d_records / d_out in DEVICE memory (16-byte aligned); epoch_end stays in HOST memory. Synchronous: d_records
+ * may be reused when the call returns. */
+int nfagg_account_device(nfagg_handle* h, const void* d_records, size_t n, void* d_out, size_t out_cap, uint64_t* epoch_end,
+                         size_t max_epochs, size_t* n_epochs, size_t* consumed);
+
 /* pkg/model/record.go:90-97: TimeFlowStart = now - (mono_now - start_mono),
  * TimeFlowEnd likewise; uint64 wrap then signed nanoseconds, as Go does.
  * now_unix_ns is the wall clock in ns since the Unix epoch. */

@@ -109,6 +109,8 @@ SIGNATURES = {
     "nfagg_len": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "nfagg_evict": (C.c_int, [_vp, C.c_int, _vp, _sz, _psz]),
     "nfagg_evict_device": (C.c_int, [_vp, C.c_int, _vp, _sz, _psz]),
+    "nfagg_account": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(C.c_uint64), _sz, _psz, _psz]),
+    "nfagg_account_device": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(C.c_uint64), _sz, _psz, _psz]),
     "nfagg_record_times": (None, [C.c_int64, C.c_uint64, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "nfagg_rollup_additional": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "nfagg_rollup_dns": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),

@@ -108,6 +108,14 @@ struct nfagg_handle {
     void* d_exp = nullptr;          // 64 owner counts + 64 segment cursors + the owned-flows count
     size_t d_exp_cap = 0;
     unsigned long long* h_exp = nullptr;   // pinned mirror of the counts
+    // nfagg_account*: control block of the persistent epoch kernel (device + pinned mirror), epoch ends, ring scratch
+    void* d_ep[3] = {};             // [0] control block, [1] epoch ends, [2] live-list scratch
+    size_t d_ep_cap[3] = {};
+    void* d_ep_out = nullptr;       // second device buffer for evictions (nfagg_account alternates with d_evict)
+    size_t d_ep_out_cap = 0;
+    void* h_ep = nullptr;           // pinned: control block, then the epoch ends
+    size_t h_ep_cap = 0;
+    uint64_t ep_phase[8] = {};      // diagnostics: accumulated phase ticks of the epoch kernel
     nfagg_stats stats{};
     std::vector<EventPair> ev_pending;
     std::vector<EventPair> ev_free;
@@ -674,6 +682,9 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->h_careful) hipHostFree(h->h_careful);
     if (h->h_exp) hipHostFree(h->h_exp);
     if (h->d_exp) hipFree(h->d_exp);
+    if (h->h_ep) hipHostFree(h->h_ep);
+    if (h->d_ep_out) hipFree(h->d_ep_out);
+    for (int k = 0; k < 3; k++) if (h->d_ep[k]) hipFree(h->d_ep[k]);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1020,6 +1031,194 @@ int nfagg_set_sequence(nfagg_handle* h, uint64_t next_seq) {
     if (next_seq >= 0xFFFFFFF0ull) return fail(h, NFAGG_ERANGE, "would pass the end of the epoch's sequence space");
     h->epoch_seq = next_seq;
     return NFAGG_OK;
+}
+
+// ---------------------------------------------------------------- nfagg_account*: the record arm WITH its evictions on "full"
+constexpr uint64_t kAccountFastMaxEntries = 32768;   // beyond that an epoch is long enough for the optimistic fold of nfagg_ingest
+
+// May the persistent epoch kernel (nfagg_epochs.hip) take this batch?
+static bool account_fast_ok(const nfagg_handle* h, size_t n, size_t out_cap) {
+    return h->cfg.mode == NFAGG_MODE_ACCOUNTER && h->cfg.max_entries <= kAccountFastMaxEntries && !h->must_evict && !h->exported &&
+           h->cfg.max_entries + epoch_window() + 16 <= h->tv.claim_limit && out_cap >= h->cfg.max_entries &&
+           h->epoch_seq + n < 0xFFFFFFF0ull - epoch_window() && (h->tv.epoch_bits >> 48) < 0xFFFFull;
+}
+
+// One launch of the epoch kernel over d[0..n). *consumed / *n_ep / *n_out: records consumed, evictions performed, records written
+// to d_out (epoch e ends at epoch_end[e] records); *stop as the kernel reports it.
+static int account_fast_launch(nfagg_handle* h, const void* d, size_t n, void* d_out, size_t out_cap, uint64_t* epoch_end, size_t max_epochs,
+                               size_t* consumed, size_t* n_ep, size_t* n_out, uint32_t* stop) {
+    int rc;
+    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;                       // exact len(entries), n_live, n_finalized
+    if (h->h_ctr->n_finalized != h->h_ctr->n_live) return fail(h, NFAGG_ESTATE, "account: unfinalized slots at the start of a batch");
+    const uint32_t me = max_epochs > 0xFFFFu ? 0xFFFFu : (uint32_t)max_epochs;
+    const size_t ctlb = (epoch_ctl_bytes() + 63) & ~(size_t)63;
+    if ((rc = ensure_bytes(h, &h->d_ep[0], &h->d_ep_cap[0], ctlb)) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_ep[1], &h->d_ep_cap[1], (size_t)(me + 1) * sizeof(uint64_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_ep[2], &h->d_ep_cap[2], (size_t)(h->cfg.max_entries + epoch_window() + 64) * sizeof(uint32_t))) != NFAGG_OK) return rc;
+    const size_t hb = ctlb + (size_t)(me + 1) * sizeof(uint64_t);
+    if (h->h_ep_cap < hb) {
+        if (h->h_ep) { hipHostFree(h->h_ep); h->h_ep = nullptr; h->h_ep_cap = 0; }
+        HIP_TRY(h, hipHostMalloc(&h->h_ep, hb + 4096, hipHostMallocDefault));
+        h->h_ep_cap = hb + 4096;
+    }
+    const uint64_t seq_start = h->epoch_seq, n_live0 = h->h_ctr->n_live;
+    epoch_ctl_fill(h->h_ep, seq_start, h->live, 0, n_live0, h->tv.epoch_bits);
+    HIP_TRY(h, hipMemcpyAsync(h->d_ep[0], h->h_ep, epoch_ctl_bytes(), hipMemcpyHostToDevice, h->stream));
+    EventPair ep{};
+    if (h->cfg.profile) prof_begin(h, ep, 0);
+    hipError_t e = launch_account_epochs(h->tv, h->sk, d, n, d_out, out_cap, (uint64_t*)h->d_ep[1], me, h->cfg.max_entries, h->d_ep[0], h->stream);
+    if (h->cfg.profile) prof_end(h, ep);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "epoch kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync(h->h_ep, h->d_ep[0], epoch_ctl_bytes(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync((char*)h->h_ep + ctlb, h->d_ep[1], (size_t)me * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    h->counters_exact = false; h->mirror_fresh = false;
+    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;                       // synchronises: control block, epoch ends, counters
+    uint64_t v[9];
+    epoch_ctl_read(h->h_ep, v);
+    { uint64_t ph[8]; epoch_ctl_phases(h->h_ep, ph); for (int k = 0; k < 8; k++) h->ep_phase[k] += ph[k]; }
+    const uint64_t pos = v[0], seq = v[1], live = v[2], list_base = v[3], list_fin = v[4], out_pos = v[5], n_epochs = v[7];
+    const uint64_t n_abs = h->h_ctr->n_live;
+    if (n_abs < list_base || n_abs - list_base != live || list_fin < list_base)
+        return fail(h, NFAGG_EDEVICE, "epoch kernel: %llu claimed slots, len(entries) %llu", (unsigned long long)(n_abs - list_base), (unsigned long long)live);
+    for (uint64_t k = 0; k < n_epochs && k < max_epochs; k++) epoch_end[k] = ((const uint64_t*)((const char*)h->h_ep + ctlb))[k];
+    // the epoch in progress to the front of the live list; identity dwords of its slots claimed by this launch, from the
+    // batch: the epoch began at record pos - (seq - seq_at_its_start) of the batch
+    h->tv.epoch_bits = v[6];
+    e = launch_ring_to_front(h->tv, list_base, live, list_fin - list_base, (uint32_t*)h->d_ep[2], h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "ring fix-up launch failed: %s", hipGetErrorString(e));
+    const uint64_t seq_at_start = n_epochs ? 0 : seq_start;
+    const uint64_t first_rec = pos - (seq - seq_at_start);
+    e = launch_finalize(h->tv, (const char*)d + first_rec * kRecordBytes, pos - first_rec, seq_at_start, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "finalize launch failed: %s", hipGetErrorString(e));
+    h->epoch_seq = seq; h->live = h->live_ub = live;
+    h->counters_exact = true;                                   // n_live = live: k_ring_counters wrote it
+    h->epoch_unclustered = true;
+    h->stats.records_ingested += pos;
+    h->stats.evictions[NFAGG_REASON_FULL] += n_epochs;
+    h->stats.evicted_flows[NFAGG_REASON_FULL] += out_pos;
+    *consumed = (size_t)pos; *n_ep = (size_t)n_epochs; *n_out = (size_t)out_pos; *stop = (uint32_t)v[8];
+    return NFAGG_OK;
+}
+
+// d_out: DEVICE. epoch_end: HOST. Evictions append to d_out; *n_epochs of them, the e-th ends at record epoch_end[e].
+static int account_device_core(nfagg_handle* h, const void* d_records, size_t n, void* d_out, size_t out_cap, uint64_t* epoch_end,
+                               size_t max_epochs, size_t* n_epochs_out, size_t* consumed_out) {
+    size_t consumed = 0, n_ep = 0, out_pos = 0;
+    int rc = NFAGG_OK;
+    const char* base = static_cast<const char*>(d_records);
+    char* obase = static_cast<char*>(d_out);
+    auto evict_pending = [&]() -> int {                         // the map is full and the record that found it so is next (account.go:85-94)
+        if (n_ep >= max_epochs) return NFAGG_TRUNCATED;
+        size_t got = 0;
+        const int r = evict_core(h, NFAGG_REASON_FULL, obase + out_pos * kRecordBytes, true, out_cap - out_pos, &got);
+        if (r != NFAGG_OK) return r;                            // NFAGG_TRUNCATED: nothing evicted, the caller drains `out` and calls again
+        out_pos += got;
+        epoch_end[n_ep++] = out_pos;
+        return NFAGG_OK;
+    };
+    if (h->must_evict && n) rc = evict_pending();
+    while (rc == NFAGG_OK && consumed < n) {
+        if (account_fast_ok(h, n - consumed, out_cap - out_pos) && n_ep < max_epochs) {
+            size_t c = 0, e = 0, o = 0; uint32_t stop = 0;
+            rc = account_fast_launch(h, base + consumed * kRecordBytes, n - consumed, obase + out_pos * kRecordBytes, out_cap - out_pos,
+                                     epoch_end + n_ep, max_epochs - n_ep, &c, &e, &o, &stop);
+            if (rc != NFAGG_OK) break;
+            for (size_t k = 0; k < e; k++) epoch_end[n_ep + k] += out_pos;
+            consumed += c; n_ep += e; out_pos += o;
+            if (stop == 2) { rc = NFAGG_TRUNCATED; break; }     // no room for another eviction
+            if (stop != 3) continue;                            // 3: the epoch tags wrap at the next eviction — that epoch goes through the host path below
+        }
+        size_t c = 0;
+        rc = ingest_device_core(h, base + consumed * kRecordBytes, n - consumed, &c);
+        consumed += c;
+        if (rc == NFAGG_FULL) rc = evict_pending();
+    }
+    if (n_epochs_out) *n_epochs_out = n_ep;
+    if (consumed_out) *consumed_out = consumed;
+    return rc;
+}
+
+int nfagg_account_device(nfagg_handle* h, const void* d_records, size_t n, void* d_out, size_t out_cap, uint64_t* epoch_end,
+                         size_t max_epochs, size_t* n_epochs, size_t* consumed) {
+    if (!h || (!d_records && n) || !epoch_end || !n_epochs || !consumed || (!d_out && out_cap)) return fail(h, NFAGG_EINVAL, "null argument");
+    if ((((uintptr_t)d_records | (uintptr_t)d_out) & 15u) != 0) return fail(h, NFAGG_EINVAL, "device buffers must be 16-byte aligned");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return account_device_core(h, d_records, n, d_out, out_cap, epoch_end, max_epochs, n_epochs, consumed);
+}
+
+int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, size_t out_cap, uint64_t* epoch_end, size_t max_epochs,
+                  size_t* n_epochs_out, size_t* consumed_out) {
+    if (!h || (!records && n) || !epoch_end || !n_epochs_out || !consumed_out || (!out && out_cap)) return fail(h, NFAGG_EINVAL, "null argument");
+    if (h->stage_acquired) return fail(h, NFAGG_ESTATE, "a staging buffer is acquired; commit it first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = staging_alloc(h);
+    if (rc != NFAGG_OK) return rc;
+    const char* src = static_cast<const char*>(records);
+    const size_t cap = (size_t)h->cfg.staging_records;
+    size_t consumed = 0, n_ep = 0, out_pos = 0;
+    // Pinned ring, double buffered as in nfagg_ingest: chunk k+1 is copied into its pinned buffer and sent up on the copy
+    // stream while the epoch kernel works on chunk k. A chunk that stops early (no room for another eviction) ends the call.
+    size_t staged_lo[2] = {0, 0}, staged_n[2] = {0, 0};
+    auto stage = [&](int b, size_t lo) -> int {
+        const size_t m = (n - lo) < cap ? (n - lo) : cap;
+        HIP_TRY(h, hipEventSynchronize(h->stage_free[b]));
+        staged_copy(h->pinned[b], src + lo * kRecordBytes, m * kRecordBytes, h->cfg.copy_threads);
+        HIP_TRY(h, hipMemcpyAsync(h->d_stage[b], h->pinned[b], m * kRecordBytes, hipMemcpyHostToDevice, h->copy_stream));
+        HIP_TRY(h, hipEventRecord(h->stage_up[b], h->copy_stream));
+        staged_lo[b] = lo; staged_n[b] = m;
+        return NFAGG_OK;
+    };
+    int b = h->stage_next;
+    if (n && (rc = stage(b, 0)) != NFAGG_OK) return rc;
+    // Three things overlap per chunk k: this thread drives the epoch kernel over chunk k (synchronous); a helper thread brings
+    // the evictions of chunk k-1 down into the caller's buffer and sends chunk k+1 up. Two device buffers take the evictions
+    // in turn; a chunk of m records delivers at most m + max_entries flows.
+    struct { bool has = false; const void* d = nullptr; size_t got = 0, at = 0; } prev;
+    auto bring_down = [&]() -> int {
+        if (prev.has && prev.got) HIP_TRY(h, hipMemcpy((char*)out + prev.at * kRecordBytes, prev.d, prev.got * kRecordBytes, hipMemcpyDeviceToHost));
+        prev.has = false;
+        return NFAGG_OK;
+    };
+    int ebuf = 0;
+    while (rc == NFAGG_OK && consumed < n) {
+        const size_t lo = staged_lo[b], m = staged_n[b];
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->stage_up[b], 0));
+        const bool more = lo + m < n;
+        size_t room = out_cap - out_pos;
+        if (room > m + (size_t)h->cfg.max_entries) room = m + (size_t)h->cfg.max_entries;
+        void** dbuf = ebuf ? &h->d_ep_out : &h->d_evict;
+        size_t capb = ebuf ? h->d_ep_out_cap : (size_t)h->d_evict_cap;
+        rc = ensure_bytes(h, dbuf, &capb, room * kRecordBytes + 16);
+        if (ebuf) h->d_ep_out_cap = capb; else h->d_evict_cap = capb;
+        if (rc != NFAGG_OK) break;
+        size_t c = 0, e = 0;
+        int rc_helper = NFAGG_OK;
+        std::thread helper;
+        const bool use_helper = more || prev.has;
+        if (use_helper) helper = std::thread([&] {
+            (void)hipSetDevice(h->device);
+            rc_helper = bring_down();
+            if (rc_helper == NFAGG_OK && more) rc_helper = stage(b ^ 1, lo + m);
+        });
+        rc = account_device_core(h, h->d_stage[b], m, *dbuf, room, epoch_end + n_ep, max_epochs - n_ep, &e, &c);
+        if (use_helper) helper.join();
+        if (rc == NFAGG_OK && rc_helper != NFAGG_OK) rc = rc_helper;
+        HIP_TRY(h, hipEventRecord(h->stage_free[b], h->stream));
+        const size_t got = e ? (size_t)epoch_end[n_ep + e - 1] : 0;
+        prev.has = true; prev.d = *dbuf; prev.got = got; prev.at = out_pos;
+        for (size_t k = 0; k < e; k++) epoch_end[n_ep + k] += out_pos;
+        n_ep += e; out_pos += got; consumed += c;
+        h->stage_next = b ^ 1;
+        ebuf ^= 1;
+        if (rc != NFAGG_OK || c < m) break;                     // stopped inside the chunk: what was staged beyond it is staged again by the next call
+        b ^= 1;
+    }
+    {
+        const int rc_down = bring_down();
+        if (rc == NFAGG_OK || rc == NFAGG_TRUNCATED) { if (rc_down != NFAGG_OK) rc = rc_down; }
+    }
+    *n_epochs_out = n_ep; *consumed_out = consumed;
+    return rc;
 }
 
 // pkg/model/record.go:90-97
@@ -1533,6 +1732,11 @@ int nfagg_encode_pb_content(nfagg_handle* h, const void* records, size_t n, cons
 }
 
 #ifdef NFAGG_DIAG
+int nfagg_debug_epoch_phases(nfagg_handle* h, uint64_t out[8]) {
+    if (!h || !out) return NFAGG_EINVAL;
+    for (int k = 0; k < 8; k++) { out[k] = h->ep_phase[k]; h->ep_phase[k] = 0; }
+    return NFAGG_OK;
+}
 // libnfagg_diag.so only (not part of the drop-in ABI): per-phase wave-cycle sums of the phase-timing builds (variants 6/8/9).
 int nfagg_debug_phase_cycles(nfagg_handle* h, uint64_t out[8]) {
     if (!h || !out) return NFAGG_EINVAL;

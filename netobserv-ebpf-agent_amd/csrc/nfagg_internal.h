@@ -194,6 +194,19 @@ hipError_t launch_export_scatter(const TableView& t, uint64_t n_live, uint64_t s
                                  unsigned long long* d_cursor, void* d_out, hipStream_t s);
 hipError_t launch_merge_raw(const TableView& t, const void* d_partials, uint64_t n, hipStream_t s);
 hipError_t launch_count_owned(const TableView& t, uint64_t n_live, uint64_t seq_limit, unsigned long long* d_count, hipStream_t s);
+// Accounter.Account with its evictions on "full" as one persistent cooperative kernel (nfagg_epochs.hip), for small max_entries.
+// The control block lives in device memory (epoch_ctl_bytes()); the API fills / reads a host copy through the two helpers:
+// read -> {pos, seq, live, list_base, list_fin, out_pos, epoch_bits, n_epochs, stop (1 batch consumed, 2 no room for another
+// eviction, 3 epoch tags wrap next)}.
+size_t epoch_ctl_bytes();
+uint32_t epoch_window();
+void epoch_ctl_fill(void* h_ctl, uint64_t seq, uint64_t live, uint64_t list_base, uint64_t list_fin, uint64_t epoch_bits);
+void epoch_ctl_read(const void* h_ctl, uint64_t out[9]);
+void epoch_ctl_phases(const void* h_ctl, uint64_t out[8]);   // diagnostics: 100 MHz ticks per phase (lane 0)
+hipError_t launch_account_epochs(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, void* d_out, uint64_t out_cap,
+                                 uint64_t* d_epoch_end, uint32_t max_epochs, uint64_t max_entries, void* d_ctl, hipStream_t s);
+// the epoch in progress, ring positions [base, base + cnt) of the live list, to the front; device counters n_live / n_finalized
+hipError_t launch_ring_to_front(const TableView& t, uint64_t base, uint64_t cnt, uint64_t n_finalized, uint32_t* d_tmp, hipStream_t s);
 // Sketch update over a batch (nfagg_sketch.hip).
 hipError_t launch_sketch_update(const SketchView& sk, const TableView& t, const void* d_records, uint64_t n, hipStream_t s);
 hipError_t launch_cm_estimate(const uint64_t* d_cm, uint32_t depth, uint32_t log2w, int side, const void* d_records, uint64_t n,

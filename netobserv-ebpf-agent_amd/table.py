@@ -124,6 +124,39 @@ class FlowTable:
             return self.evict(reason, cap=n.value)
         return out[: n.value]
 
+    # -- account: the record arm with its evictions on "full" (account.go:81-96) in one call
+    def account(self, records: np.ndarray, out_cap=None, max_epochs=None, out=None):
+        """nfagg_account. Returns (status, consumed, epochs): epochs = list of arrays (views of `out`), one per eviction on
+        "full", in order. out: a FLOW_RECORD array to deliver into (a caller that accounts batch after batch reuses one)."""
+        records = np.ascontiguousarray(records)
+        n = records.nbytes // 144
+        if out is not None:
+            out_cap = len(out)
+        if out_cap is None:
+            out_cap = max(n + self.max_entries, self.max_entries)        # every record may start a flow; plus what is live already
+        if max_epochs is None:
+            max_epochs = n // max(self.max_entries, 1) + 2
+        if out is None:
+            out = np.empty(max(out_cap, 1), dtype=FLOW_RECORD)
+        ends = (C.c_uint64 * max(max_epochs, 1))()
+        n_ep, consumed = C.c_size_t(0), C.c_size_t(0)
+        rc = L.lib.nfagg_account(self._h, records.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p), out_cap, ends, max_epochs,
+                                 C.byref(n_ep), C.byref(consumed))
+        self._check(rc, (L.OK, L.TRUNCATED))
+        epochs, lo = [], 0
+        for e in range(n_ep.value):
+            epochs.append(out[lo:int(ends[e])])
+            lo = int(ends[e])
+        return rc, consumed.value, epochs
+
+    def account_device(self, d_ptr: int, n: int, d_out: int, out_cap: int, max_epochs: int):
+        """nfagg_account_device. Returns (status, consumed, epoch_end list)."""
+        ends = (C.c_uint64 * max(max_epochs, 1))()
+        n_ep, consumed = C.c_size_t(0), C.c_size_t(0)
+        rc = L.lib.nfagg_account_device(self._h, C.c_void_p(d_ptr), n, C.c_void_p(d_out or None), out_cap, ends, max_epochs, C.byref(n_ep), C.byref(consumed))
+        self._check(rc, (L.OK, L.TRUNCATED))
+        return rc, consumed.value, [int(ends[e]) for e in range(n_ep.value)]
+
     def evict_device(self, d_ptr: int, cap: int, reason=L.REASON_TIMEOUT) -> int:
         n = C.c_size_t(0)
         self._check(L.lib.nfagg_evict_device(self._h, reason, C.c_void_p(d_ptr), cap, C.byref(n)))

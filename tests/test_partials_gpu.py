@@ -217,4 +217,5 @@ def test_bench_n1_line_carries_the_extra_legs(nf):
     for k in ("configs2", "configs4_shape", "e2e", "cache_max_flows_5000"):
         assert k in ex, ex.keys()
     assert ex["configs2"]["alg_bytes_per_record"] == 522 and ex["configs2"]["Mrecords_per_s"] > 0
-    assert ex["e2e"]["Mrecords_per_s"] > 0 and ex["cache_max_flows_5000"]["host_path"]["evictions"] > 10
+    assert ex["e2e"]["Mrecords_per_s"] > 0 and ex["cache_max_flows_5000"]["account_host_path"]["evictions"] > 10
+    assert ex["cache_max_flows_5000"]["account_host_path"]["evicted_flows"] == ex["cache_max_flows_5000"]["account_device_resident"]["evicted_flows"]
