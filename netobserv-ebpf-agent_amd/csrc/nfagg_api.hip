@@ -634,6 +634,7 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
         int bits = 0;
         while ((1ull << bits) < slots) bits++;
         h->tv.spill.part_shift = (uint32_t)(bits - 11);
+        h->tv.spill.n_parts = kSpillParts;
     }
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY

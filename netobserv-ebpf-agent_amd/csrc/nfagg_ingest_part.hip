@@ -68,7 +68,7 @@ struct Stage {
 constexpr int kDoorBits = 32768;
 struct Door { uint32_t bits[kDoorBits / 32]; };
 
-NF_DEV uint32_t part_of(uint64_t h, uint32_t shift) { return (uint32_t)(h >> shift) & (kSpillParts - 1); }
+NF_DEV uint32_t part_of(uint64_t h, const SpillView& q) { return (uint32_t)(h >> q.part_shift) & (q.n_parts - 1); }
 
 NF_DEV void cache_init(Cache& L, int tid) {
     const uint4 z = make_uint4(0, 0, 0, 0);
@@ -172,15 +172,7 @@ NF_DEV uint32_t cache_flush_entry(const TableView& t, const SketchView& sk, Cach
     uint4 s4 = make_uint4(0, 0, 0, 0), d4 = s4, d5 = s4;
     if (ss != 0xffffffffu) s4 = rec_chunk(recs, (uint64_t)(ss - seq_base32), 4);
     if (ds != 0xffffffffu) { d4 = rec_chunk(recs, (uint64_t)(ds - seq_base32), 4); d5 = rec_chunk(recs, (uint64_t)(ds - seq_base32), 5); }
-    Hints x;
-    bool fresh = false;
-    uint32_t idx = probe_home(t, w, h, x);
-    if (idx == kNoSlot) {
-        idx = (EXCL && defer) ? find_or_claim<true>(t, w, h, &fresh, &x.home_tag) : find_or_claim(t, w, h, nullptr, &x.home_tag);
-        if (idx == kNoSlot) return kNoSlot;
-        if (fresh) { x.end = 0; x.start_inv = 0; x.id0 = 0; x.smac_lo = 0; x.dmac_lo = 0; x.flags = 0; new_list[atomicAdd(new_cnt, 1u)] = idx; }
-        else load_hints(&t.hot[idx], x);
-    }
+    // the entry as the partial of its flow: for a slot that holds nothing older every part of it counts
     Partial p;
     const uint4 tt = L.t[e], vv = L.v[e], ww = L.w[e];
     p.bytes = u64lo(vv); p.end = u64lo(tt); p.start_inv = u64hi(tt);
@@ -188,17 +180,28 @@ NF_DEV uint32_t cache_flush_entry(const TableView& t, const SketchView& sk, Cach
     p.eth_tag = u64lo(ww); p.dscp_tag = u64hi(ww); p.samp_tag = u64hi(vv);
     // The entry's earliest record may be the flow's first: only its sequence number goes into the slot (the tag of
     // id0); k_finalize copies that record's identity dwords from the batch after the last fold kernel of the call.
-    p.first_inv = ((uint32_t)(x.id0 >> 32) <= ~fs) ? ~fs : 0u;   // tagged(0, 0) = 0 never wins
-    p.ident0 = 0;
+    p.first_inv = ~fs; p.ident0 = 0;
     p.smac_inv = 0; p.dmac_inv = 0; p.smac = 0; p.dmac = 0;
-    if (ss != 0xffffffffu && (uint32_t)(x.smac_lo >> 32) <= ~ss) {
-        p.smac = (uint64_t)s4.z | ((uint64_t)(s4.w & 0xffffu) << 32);
-        p.smac_inv = ~ss;
+    if (ss != 0xffffffffu) { p.smac = (uint64_t)s4.z | ((uint64_t)(s4.w & 0xffffu) << 32); p.smac_inv = p.smac ? ~ss : 0u; }
+    if (ds != 0xffffffffu) { p.dmac = (uint64_t)(d4.w >> 16) | ((uint64_t)d5.x << 16); p.dmac_inv = p.dmac ? ~ds : 0u; }
+    Hints x;
+    bool fresh = false;
+    uint32_t idx = probe_home(t, w, h, x);
+    if (idx == kNoSlot) {
+        idx = (EXCL && defer) ? find_or_claim<true>(t, w, h, &fresh, &x.home_tag)
+                              : find_or_claim(t, w, h, &fresh, &x.home_tag, EXCL ? nullptr : &p);   // !EXCL: a claimer writes p as the slot's first value
+        if (idx == kNoSlot) return kNoSlot;
+        if (!EXCL && fresh) {                                    // claimed and filled in one go: nothing left to merge
+            if (SKETCH) sketch_add(sk, w, p.bytes);
+            return kNoSlot;
+        }
+        if (fresh) { x.end = 0; x.start_inv = 0; x.id0 = 0; x.smac_lo = 0; x.dmac_lo = 0; x.flags = 0; new_list[atomicAdd(new_cnt, 1u)] = idx; }
+        else load_hints(&t.hot[idx], x);
     }
-    if (ds != 0xffffffffu && (uint32_t)(x.dmac_lo >> 32) <= ~ds) {
-        p.dmac = (uint64_t)(d4.w >> 16) | ((uint64_t)d5.x << 16);
-        p.dmac_inv = ~ds;
-    }
+    // against what the slot already holds (possibly stale = smaller, see Hints): drop what cannot win
+    if ((uint32_t)(x.id0 >> 32) > ~fs) p.first_inv = 0;          // tagged(0, 0) = 0 never wins
+    if (p.smac_inv && (uint32_t)(x.smac_lo >> 32) > p.smac_inv) { p.smac_inv = 0; p.smac = 0; }
+    if (p.dmac_inv && (uint32_t)(x.dmac_lo >> 32) > p.dmac_inv) { p.dmac_inv = 0; p.dmac = 0; }
     if (EXCL) merge_partial_exclusive(t, idx, p, fresh, w, h, false);
     else merge_partial(t, idx, p, x);
     if (SKETCH) sketch_add(sk, w, p.bytes);
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
         if (valid && ent < 0) {
             spilled++;
             if (!(ABL & 1)) {
-                const uint32_t p = part_of(h, q.part_shift);
+                const uint32_t p = part_of(h, q);
                 const uint32_t at = atomicAdd(&S.cnt[p], 1u);
                 const uint32_t qi = (uint32_t)i | (tag_on ? ((uint32_t)(h >> sub_shift) & (uint32_t)(kSubs - 1)) << kIdxBits : 0u);
                 if (at < (uint32_t)kStage) { S.buf[p][at] = qi; if (at == (uint32_t)kStage - 1) fill_p[1] = p; }
@@ -615,42 +618,60 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
         attr_set = true;
     }
     const uint64_t tiles = (n + kBlock - 1) / kBlock;
-    uint64_t grid = 256;
+    // a workgroup's cache pays for itself (set-up, one flush of up to 1024 entries — ~10 small coherent operations each, and the
+    // chip retires ~24 G of those per second) only over several tiles: at least eight each
+    uint64_t grid = (tiles + 7) / 8;
+    if (grid < 64) grid = 64;               // ... but a 256 Ki batch still wants 64 CUs streaming it
+    if (grid > 256) grid = 256;
     if (grid > tiles) grid = tiles;
     (void)hipGetLastError();
     hipLaunchKernelGGL((k_pass1<SKETCH, T1, DOOR, ABL>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_pass2<SKETCH, T2>), dim3(kSpillParts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
+    hipLaunchKernelGGL((k_pass2<SKETCH, T2>), dim3(q.n_parts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_merge_overflow<SKETCH>), dim3(256), dim3(256), 0, s, t, sk, q, d_records, n, seq_base);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return hipMemsetAsync(q.ovf_tail, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL((k_merge_overflow<SKETCH>), dim3(32), dim3(256), 0, s, t, sk, q, d_records, n, seq_base);   // normally empty
+    return hipGetLastError();              // the overflow tail is reset by k_finalize, the last launch of every ingest call
 }
 
 }  // namespace part
 
-hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
+hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const SpillView& q_in, const void* d_records, uint64_t n,
                               uint64_t seq_base, int variant, hipStream_t s) {
-    if (!q.queue || !q.qtail || !q.ovf || !q.ovf_tail || q.qcap < 4 || (q.qcap & 3u)) return hipErrorInvalidValue;
+    if (!q_in.queue || !q_in.qtail || !q_in.ovf || !q_in.ovf_tail || q_in.qcap < 4 || (q_in.qcap & 3u)) return hipErrorInvalidValue;
+    // Partitions scaled to the batch. One pass-2 workgroup per partition costs ~25 us whatever it folds (cache set-up, one
+    // gather tile, a latency-bound flush): 2048 of them were 0.2 ms of a 0.28 ms call at 1 Mi records (round 2). About a
+    // third of a Zipf batch spills; aim at ~700 spilled records (at most as many flows: they fit the 1024-entry cache) per
+    // partition. The queue memory is the same, cut into fewer, longer queues.
+    SpillView q = q_in;
+    uint32_t parts = kSpillParts;
+    while (parts > 256 && (uint64_t)parts * 2048 > n) parts >>= 1;     // 2048 from 4 Mi records, 1024 from 2 Mi, 512 from 1 Mi, 256 below
+    int bits = 0;
+    while ((1ull << bits) <= t.mask) bits++;
+    int lg = 0;
+    while ((1u << lg) < parts) lg++;
+    q.n_parts = parts;
+    q.part_shift = (uint32_t)(bits - lg);
+    q.qcap = (uint32_t)((((uint64_t)q_in.qcap * kSpillParts) / parts) & ~3ull);
+    TableView tq = t;
+    tq.spill = q;
 #ifdef NFAGG_DIAG
-    if (variant == 8) return part::run<false, true, false>(t, sk, q, d_records, n, seq_base, s);   // diagnostics: pass-1 phase timing
-    if (variant == 9) return part::run<false, false, true>(t, sk, q, d_records, n, seq_base, s);   // diagnostics: pass-2 phase timing
+    if (variant == 8) return part::run<false, true, false>(tq, sk, q, d_records, n, seq_base, s);   // diagnostics: pass-1 phase timing
+    if (variant == 9) return part::run<false, false, true>(tq, sk, q, d_records, n, seq_base, s);   // diagnostics: pass-2 phase timing
     switch (variant) {                                                                              // diagnostics: pass-1 ablations (wrong results)
-        case 21: return part::run<false, false, false, true, 1>(t, sk, q, d_records, n, seq_base, s);
-        case 22: return part::run<false, false, false, true, 2>(t, sk, q, d_records, n, seq_base, s);
-        case 23: return part::run<false, false, false, true, 3>(t, sk, q, d_records, n, seq_base, s);
-        case 25: return part::run<false, false, false, true, 5>(t, sk, q, d_records, n, seq_base, s);
-        case 27: return part::run<false, false, false, true, 7>(t, sk, q, d_records, n, seq_base, s);
+        case 21: return part::run<false, false, false, true, 1>(tq, sk, q, d_records, n, seq_base, s);
+        case 22: return part::run<false, false, false, true, 2>(tq, sk, q, d_records, n, seq_base, s);
+        case 23: return part::run<false, false, false, true, 3>(tq, sk, q, d_records, n, seq_base, s);
+        case 25: return part::run<false, false, false, true, 5>(tq, sk, q, d_records, n, seq_base, s);
+        case 27: return part::run<false, false, false, true, 7>(tq, sk, q, d_records, n, seq_base, s);
         default: break;
     }
 #endif
     if (variant == 11)   // A/B: pass 1 without the admission filter (first come, first served)
-        return sk.flags ? part::run<true, false, false, false>(t, sk, q, d_records, n, seq_base, s)
-                        : part::run<false, false, false, false>(t, sk, q, d_records, n, seq_base, s);
-    return sk.flags ? part::run<true>(t, sk, q, d_records, n, seq_base, s) : part::run<false>(t, sk, q, d_records, n, seq_base, s);
+        return sk.flags ? part::run<true, false, false, false>(tq, sk, q, d_records, n, seq_base, s)
+                        : part::run<false, false, false, false>(tq, sk, q, d_records, n, seq_base, s);
+    return sk.flags ? part::run<true>(tq, sk, q, d_records, n, seq_base, s) : part::run<false>(tq, sk, q, d_records, n, seq_base, s);
 }
 
 }  // namespace nfagg

@@ -98,7 +98,7 @@ struct DevCounters {
     unsigned long long n_finalized;// live_list[0..n_finalized) have their identity dwords written (k_finalize)
     unsigned int aborted;          // a claim was refused because n_live reached TableView.claim_limit: the fold of this
                                    // batch is incomplete and the API rolls it back (optimistic fold, nfagg_api.hip)
-    unsigned int pad1;
+    unsigned int fin_ticket;       // k_finalize: blocks done (the last one publishes n_finalized and resets this)
     unsigned long long phase[8];   // diagnostic builds only: per-phase wave-cycle sums
 };
 
@@ -112,7 +112,9 @@ struct SpillView {
     uint32_t* ovf_tail;
     uint32_t ovf_cap;
     unsigned int* error;           // = &DevCounters.error
-    uint32_t part_shift;           // partition of a key = (hash >> part_shift) & (kSpillParts - 1); see nfagg_create
+    uint32_t part_shift;           // partition of a key = (hash >> part_shift) & (n_parts - 1); see nfagg_create
+    uint32_t n_parts;              // partitions in use (power of two, <= kSpillParts): the two-pass accounter fold scales them to the
+                                   // batch (launch_ingest_part), the kernel-dedup passes always use kSpillParts
 };
 
 struct TableView {
@@ -173,6 +175,7 @@ hipError_t launch_snapshot(const TableView& t, uint64_t n, void* d_snap, bool re
 hipError_t launch_discard(const TableView& t, uint64_t from, uint64_t to, hipStream_t s);
 hipError_t launch_first_seqs(const TableView& t, uint64_t from, uint64_t to, uint32_t* d_out, hipStream_t s);
 // Last launch of an ingest call: identity dwords of the slots claimed since the previous finalize, from records[0..n).
+// Also resets the spill overflow tail for the next two-pass call (one launch less than a memset node).
 hipError_t launch_finalize(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
 hipError_t launch_sort_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, void* d_temp, size_t* temp_bytes, hipStream_t s);
 // Stable partition of a batch by key-hash shard (nfagg_partition.hip): buckets back to back in shard order in d_out, the

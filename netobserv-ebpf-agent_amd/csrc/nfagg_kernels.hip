@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * kEvictWaves) void k_evict(TableView t, uint64_
 // from the batch into the slot — plain stores, this lane is the only writer, every fold kernel of the call is done.
 // ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize(TableView t, const void* __restrict__ recs, uint64_t n, uint32_t seq_base32) {
-    const uint64_t from = t.ctr->n_finalized, to = t.ctr->n_live;
+    const uint64_t from = ald(&t.ctr->n_finalized), to = t.ctr->n_live;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < to; i += stride) {
         const uint32_t idx = t.live_list[i];
@@ -222,9 +222,19 @@ __global__ __launch_bounds__(256) void k_finalize(TableView t, const void* __res
         cw[3] = make_uint4(c7.w, c8.x, c8.y, c8.z);                     // 31..34
         reinterpret_cast<uint32_t*>(&H->id0)[0] = c5.y;                 // dword 21: if_index_first_seen
     }
+    // The last block to get here publishes "everything up to n_live is finalized" (every block has read n_finalized by then:
+    // its ticket comes after its loop) and resets the spill overflow tail of the two-pass fold. Round 2 spent two more
+    // launches on this (k_finalize_done, a memset node): ~4 us of every small ingest call.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int ticket = aadd(&t.ctr->fin_ticket, 1u);
+        if (ticket == gridDim.x - 1) {
+            ast(&t.ctr->n_finalized, (unsigned long long)to);
+            ast(&t.ctr->fin_ticket, 0u);
+            if (t.spill.ovf_tail) ast(t.spill.ovf_tail, 0u);
+        }
+    }
 }
-
-__global__ void k_finalize_done(DevCounters* c) { c->n_finalized = c->n_live; }
 
 __global__ void k_reset_after_evict(DevCounters* c, int n_out_is_n_live) {
     if (n_out_is_n_live) c->n_out = c->n_live;
@@ -286,7 +296,7 @@ hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const 
 //   from there the two-pass partitioned fold: 0.28 against 0.40 ms at 1 Mi, 0.62 against 1.29 ms at 4 Mi (since pass 2 flushes
 //     with plain read-modify-writes the crossover lies at ~0.5 Mi; it was 3 Mi in round 1).
 constexpr uint64_t kDirectMaxBatch = 6144;
-constexpr uint64_t kPartMinBatch = 3u << 18;   // 768 Ki
+constexpr uint64_t kPartMinBatch = 3u << 17;   // 384 Ki (round 3: 0.114 against 0.128 ms at 256 Ki, 0.18 against 0.23 at 512 Ki)
 constexpr uint64_t kDedupCachedMinBatch = 1u << 16;
 static bool takes_two_pass(int variant, uint64_t n) { return (variant >= 8 && variant <= 11) || (variant >= 20 && variant <= 27) || (variant == 0 && n >= kPartMinBatch); }
 // Shipping variants: 0 (by batch size), 1 direct, 3/4/5/7 geometries of the single-pass cached kernel, 10/11 two-pass
@@ -376,9 +386,6 @@ hipError_t launch_finalize(const TableView& t, const void* d_records, uint64_t n
     // the number of new slots is only known on the device: a fixed grid strides over [n_finalized, n_live)
     const int grid = n >= (1u << 20) ? 1024 : (n >= (1u << 14) ? 64 : 4);
     hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, t, d_records, n, (uint32_t)seq_base);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_finalize_done, dim3(1), dim3(1), 0, s, t.ctr);
     return hipGetLastError();
 }
 

@@ -126,7 +126,7 @@ def test_account_device_and_sharded_handle(nf, O):
         mine = recs if n_shards == 1 else recs[nf.distributed.shard_ids(recs.view(nf.FLOW_RECORD), n_shards) == shard]
         want = O.run_accounter(mine, max_entries)
         with nf.FlowTable(max_entries=max_entries, n_shards=n_shards, shard_id=shard) as tab:
-            out = torch.zeros((len(recs) + max_entries) * 144, dtype=torch.uint8, device="cuda")
+            out = torch.zeros((len(recs) + max_entries) * 144, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
             rc, c, ends = tab.account_device(d.data_ptr(), len(recs), out.data_ptr(), len(recs) + max_entries, 4096)
             assert (rc, c) == (nf.OK, len(recs)) and len(ends) == len(want) - 1
             ev = out.cpu().numpy()

@@ -95,6 +95,7 @@ def test_local_fold_truncated_eviction_is_repeatable(nf, O):
         assert grp.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
         want = O.run_accounter(recs, 1 << 20)[0][1]
         bufs = [torch.zeros(144 * 16, dtype=torch.uint8, device="cuda") for _ in range(n_members)]
+        torch.cuda.synchronize()                               # torch fills them on ITS stream, the library writes on its own
         with pytest.raises(nf.NfaggError) as ei:
             grp.evict_device([b.data_ptr() for b in bufs], [16] * n_members)
         assert ei.value.code == nf.TRUNCATED
@@ -106,6 +107,7 @@ def test_local_fold_truncated_eviction_is_repeatable(nf, O):
         need = [int(x) for x in need]
         assert sum(need) == len(want)
         bufs = [torch.zeros(144 * max(k, 1), dtype=torch.uint8, device="cuda") for k in need]
+        torch.cuda.synchronize()
         counts = grp.evict_device([b.data_ptr() for b in bufs], need)
         assert counts == need
         got = np.concatenate([b.cpu().numpy()[: 144 * k].view(nf.FLOW_RECORD) for b, k in zip(bufs, counts)])

@@ -30,6 +30,7 @@ class Ranks:
         self.nf, self.n, self.torch = nf, n, torch
         self.tabs = [nf.FlowTable(max_entries=max_entries, table_log2_slots=20, **kw) for _ in range(n)]
         self.exp = [torch.zeros(max_entries * 24, dtype=torch.int64, device="cuda") for _ in range(n)]
+        torch.cuda.synchronize()
         self.keep = []
 
     def close(self):
@@ -38,6 +39,7 @@ class Ranks:
 
     def fold(self, rank, recs, seq):
         d = self.torch.from_numpy(np.ascontiguousarray(recs).view(np.uint8).reshape(-1).copy()).cuda()
+        self.torch.cuda.synchronize()            # the upload runs on torch's stream, the fold on the library's
         self.keep.append(d)                      # the fold is asynchronous
         self.tabs[rank].set_sequence(seq)
         rc, c = self.tabs[rank].ingest_device(d.data_ptr(), len(recs))
@@ -60,7 +62,7 @@ class Ranks:
         out = []
         for r in range(n):
             rc, need = self.tabs[r].evict_owned_device(n, r, 0, 0, reason if reason is not None else nf.REASON_TIMEOUT)
-            buf = torch.zeros(max(need, 1) * 144, dtype=torch.uint8, device="cuda")
+            buf = torch.zeros(max(need, 1) * 144, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()   # torch fills on ITS stream
             if need:
                 assert rc == nf.TRUNCATED
                 rc, got = self.tabs[r].evict_owned_device(n, r, buf.data_ptr(), need, reason if reason is not None else nf.REASON_TIMEOUT)
@@ -122,12 +124,12 @@ def test_export_states_and_errors(nf, O):
         # too small: nothing written, the size needed comes back, the handle still takes records
         rc, counts, need = tab.partials_export_device(4, 1, 0, 0)
         assert rc == nf.TRUNCATED and need == sum(counts) and 0 < need < len(want) and counts[1] == 0
-        small = torch.zeros(16 * 24, dtype=torch.int64, device="cuda")
+        small = torch.zeros(16 * 24, dtype=torch.int64, device="cuda"); torch.cuda.synchronize()
         assert tab.partials_export_device(4, 1, small.data_ptr(), 16)[0] == nf.TRUNCATED
         assert tab.ingest_device(d.data_ptr(), 10) == (nf.OK, 10)
         want2 = O.run_accounter(np.concatenate([recs, recs[:10]]), 1 << 20)[0][1].view(nf.FLOW_RECORD)   # the first ten records folded twice
         # NFAGG_SHARD_NONE: every flow leaves, grouped by owner
-        buf = torch.zeros(len(want) * 24, dtype=torch.int64, device="cuda")
+        buf = torch.zeros(len(want) * 24, dtype=torch.int64, device="cuda"); torch.cuda.synchronize()
         rc, counts, total = tab.partials_export_device(4, 0xFFFFFFFF, buf.data_ptr(), len(want))
         assert rc == nf.OK and total == len(want) == sum(counts) and all(counts)
         raw = buf.cpu().numpy().view(np.uint8).reshape(-1, 192)
@@ -144,7 +146,7 @@ def test_export_states_and_errors(nf, O):
         with pytest.raises(nf.NfaggError) as ei:
             tab.evict(nf.REASON_TIMEOUT)
         assert ei.value.code == -5 and "nfagg_evict_owned_device" in str(ei.value)
-        out = torch.zeros(len(want) * 144, dtype=torch.uint8, device="cuda")
+        out = torch.zeros(len(want) * 144, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
         rc, n = tab.evict_owned_device(4, 2, out.data_ptr(), len(want), nf.REASON_TIMEOUT)
         ev = out.cpu().numpy()[: n * 144].view(nf.FLOW_RECORD)
         mine = want2[nf.distributed.shard_ids(want2, 4) == 2]
