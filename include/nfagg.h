@@ -166,11 +166,10 @@ enum {
     NFAGG_FULL     = 1,  /* ingest stopped before a record whose NEW key would
                             exceed max_entries (account.go:85): evict with
                             NFAGG_REASON_FULL, then resubmit the remainder.
-                            Also returned (stats.seq_space_evictions) when an
-                            epoch reaches 2^32-16 records — sequence numbers
-                            are epoch-relative and 32 bits wide; the reference
-                            has no such limit, the flows are merely exported
-                            one eviction early */
+                            (An epoch is never ended for lack of sequence
+                            numbers: the slots' 32-bit sequence tags are
+                            window-relative and the window moves,
+                            stats.sequence_rebases.) */
     NFAGG_TRUNCATED = 2, /* output buffer smaller than the result */
     /* <0: errors */
     NFAGG_EINVAL   = -1,
@@ -289,7 +288,8 @@ typedef struct nfagg_stats {
                                     second pass, or merged into HBM one by one by the single-pass kernel) */
     uint64_t optimistic_folds;   /* batches with live + batch > max_entries folded whole and checked afterwards */
     uint64_t optimistic_rollbacks; /* ... of which crossed max_entries (account.go:85) and were rolled back and split */
-    uint64_t seq_space_evictions;  /* NFAGG_FULL returned because an epoch reached 2^32-16 records (no reference counterpart) */
+    uint64_t sequence_rebases;     /* times the 32-bit window of the slots' sequence tags was moved (once per ~2^32 records of an
+                                      epoch; the epoch itself goes on: account.go:58-100 has no maximum length) */
 } nfagg_stats;
 
 uint32_t nfagg_abi_version(void);
@@ -735,7 +735,8 @@ int nfagg_group_evict_device(nfagg_group* g, int reason, void* const* d_out, con
 #define NFAGG_SHARD_NONE 0xFFFFFFFFu
 
 /* The next record folded by this handle carries sequence number next_seq (epoch-relative: every eviction restarts the
- * epoch at 0). Must not be smaller than the number the handle has reached. Gaps are harmless: only the order matters. */
+ * epoch at 0; 64 bits). Must not be smaller than the number the handle has reached. Gaps are harmless: only the order
+ * matters. Marks the handle as sharing its numbering with other tables (see nfagg_window_restart_device). */
 int nfagg_set_sequence(nfagg_handle* h, uint64_t next_seq);
 
 /* Step 1. d_out: DEVICE memory, 64-byte aligned, room for `cap` partials of NFAGG_PARTIAL_BYTES. Segment o (the flows shard
@@ -757,9 +758,25 @@ int nfagg_partials_merge_device(nfagg_handle* h, uint32_t n_shards, uint32_t sha
 int nfagg_evict_owned_device(nfagg_handle* h, int reason, uint32_t n_shards, uint32_t shard_id, void* d_out, size_t cap,
                              size_t* n_out);
 
+/* The sequence window of ranks that share one numbering. The slots carry sequence numbers relative to a 32-bit window; a
+ * handle that alone holds its flows moves the window by itself when ~2^32 records of an epoch have gone by. Ranks of a
+ * local-fold job cannot (the order between the ranks' partials of one flow would be lost): nfagg_ingest* fails with
+ * NFAGG_ERANGE on such a handle (one that had nfagg_set_sequence) when its window is used up. Before that happens — every
+ * rank knows the job's position — all ranks bring the flows together at their owners WITHOUT evicting:
+ *   nfagg_partials_export_device(h, n_shards, NFAGG_SHARD_NONE, ...)   every flow, the rank's own included
+ *   exchange: segment o to rank o (the own segment stays)
+ *   nfagg_window_restart_device(h, n_shards, shard_id, d_partials, n, next_seq)
+ * which empties the table (the epoch tag; nothing is written), merges the n partials this rank owns and rebases their tags;
+ * the next record folded carries next_seq (>= every number used in the job so far). The epoch goes on: sketches untouched,
+ * nfagg_len = the flows this rank owns. The in-process group (NFAGG_GROUP_LOCAL_FOLD) does all of this by itself. */
+int nfagg_window_restart_device(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id, const void* d_partials, size_t n,
+                                uint64_t next_seq);
+
 /* Testing aid: account for `records` more records in the current eviction epoch without folding any (their sequence
- * numbers are skipped), so that the 2^32-16 records-per-epoch boundary can be reached without feeding 600 GB. */
+ * numbers are skipped), so that the moves of the 32-bit sequence window (every ~2^32 records) can be exercised without
+ * feeding 600 GB. */
 int nfagg_debug_skip_sequence(nfagg_handle* h, uint64_t records);
+int nfagg_group_debug_skip_sequence(nfagg_group* g, uint64_t records);   /* the group's common position (local fold) / every member's */
 
 #ifdef __cplusplus
 }

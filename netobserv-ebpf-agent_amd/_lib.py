@@ -90,7 +90,7 @@ class Stats(C.Structure):
         ("evict_launches", C.c_uint64), ("evict_kernel_ms", C.c_double),
         ("sketch_launches", C.c_uint64), ("sketch_kernel_ms", C.c_double), ("max_probe", C.c_uint64),
         ("records_bypassed", C.c_uint64),
-        ("optimistic_folds", C.c_uint64), ("optimistic_rollbacks", C.c_uint64), ("seq_space_evictions", C.c_uint64),
+        ("optimistic_folds", C.c_uint64), ("optimistic_rollbacks", C.c_uint64), ("sequence_rebases", C.c_uint64),
     ]
 
 
@@ -145,7 +145,9 @@ SIGNATURES = {
     "nfagg_set_sequence": (C.c_int, [_vp, C.c_uint64]),
     "nfagg_partials_export_device": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _sz, C.POINTER(C.c_uint64), _psz]),
     "nfagg_partials_merge_device": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _sz]),
+    "nfagg_window_restart_device": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _sz, C.c_uint64]),
     "nfagg_evict_owned_device": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, _vp, _sz, _psz]),
+    "nfagg_group_debug_skip_sequence": (C.c_int, [_vp, C.c_uint64]),
     "nfagg_group_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(_vp)]),
     "nfagg_group_destroy": (None, [_vp]),
     "nfagg_group_last_error": (C.c_char_p, [_vp]),

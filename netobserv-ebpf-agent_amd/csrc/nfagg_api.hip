@@ -91,7 +91,10 @@ struct nfagg_handle {
     void* d_spill = nullptr;
     size_t d_spill_cap = 0;
     // accounting
-    uint64_t epoch_seq = 0;
+    uint64_t epoch_seq = 0;         // sequence number of the next record, counted from the start of the epoch (64 bits: never runs out)
+    uint64_t seq_origin = 0;        // the device sees epoch_seq - seq_origin: a 32-bit window, moved by a rebase (nfagg_rebase.hip)
+    bool ext_sequenced = false;     // sequence numbers are handed in (nfagg_set_sequence, group local fold): other tables hold tags of the
+                                    // same numbering, so this handle must not move its window on its own
     uint64_t live = 0;       // len(entries): exact after refresh_counters and on the paths that keep counters_exact
     uint64_t live_ub = 0;    // upper bound on the device's n_live (the claimed slots); equal to it while counters_exact
     // The host knows the device's n_live and len(entries) without asking (after an eviction; after a claim + flag chunk,
@@ -193,9 +196,10 @@ int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t 
         }
     }
     if (prof) { if (h->ev_pending.size() >= 8192) prof_resolve(h); prof_begin(h, ep, 0); }
-    hipError_t e = launch_ingest(h->tv, h->sk, d, n, seq_base, (int)h->cfg.mode, (int)h->cfg.ingest_variant, h->stream);
+    const uint64_t rel = seq_base - h->seq_origin;              // what the slots' 32-bit tags carry (callers keep rel + n inside the window)
+    hipError_t e = launch_ingest(h->tv, h->sk, d, n, rel, (int)h->cfg.mode, (int)h->cfg.ingest_variant, h->stream);
     // identity dwords of the flows this batch created, from the batch (the caller owns it until the call returns)
-    if (e == hipSuccess) e = launch_finalize(h->tv, d, n, seq_base, h->stream);
+    if (e == hipSuccess) e = launch_finalize(h->tv, d, n, rel, h->stream);
     if (prof) prof_end(h, ep);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "ingest launch failed: %s", hipGetErrorString(e));
     if (h->sk.flags && !ingest_fuses_sketches((int)h->cfg.mode, (int)h->cfg.ingest_variant, n, h->sk.flags)) {
@@ -236,6 +240,24 @@ int refresh_counters(nfagg_handle* h) {
 // room for is `aborted` by the kernels (some claims refused), rolled back the same way and retried with a quarter of it.
 constexpr size_t kCarefulCountsBytes = 256;    // h_careful: block counts of a small chunk (16 x 4 bytes), then its flags
 constexpr uint64_t kCarefulMaxBatch = 16384;   // below this the claim + flag path decides (two small launches, one host round trip)
+
+// ---- the sequence window (nfagg_rebase.hip) --------------------------------------------------------------------
+constexpr uint64_t kSeqWindow = 0xFFFFFFF0ull;     // relative sequence numbers stay below this
+constexpr uint64_t kMaxFoldChunk = 1ull << 31;     // records per pass of the ingest loop: always fits a fresh window
+
+// Make room for `n` (<= kMaxFoldChunk) more sequence numbers. A table that holds the only copy of its flows rebases its tags in
+// place; a handle whose numbering is shared with other tables (local fold across GPUs) cannot: *blocked tells the caller.
+int ensure_seq_window(nfagg_handle* h, uint64_t n, bool* blocked) {
+    if (blocked) *blocked = false;
+    if (h->epoch_seq - h->seq_origin + n < kSeqWindow) return NFAGG_OK;
+    if (h->ext_sequenced) { if (blocked) *blocked = true; return NFAGG_OK; }
+    const hipError_t e = launch_rebase(h->tv, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "rebase launch failed: %s", hipGetErrorString(e));
+    h->seq_origin = h->epoch_seq - rebase_keep();
+    h->stats.sequence_rebases++;
+    h->mirror_fresh = h->mirror_fresh;                          // counters untouched: the live list and n_live stay as they are
+    return NFAGG_OK;
+}
 
 int snapshot_sketches(nfagg_handle* h, bool restore) {
     if (!h->sk.flags) return NFAGG_OK;
@@ -309,10 +331,11 @@ int opt_result(nfagg_handle* h, OptState& st, uint64_t chunk, bool* crossed, boo
     uint32_t split_seq = 0;
     HIP_TRY(h, hipMemcpyAsync(&split_seq, seqs + m + st.room, sizeof split_seq, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if ((uint64_t)split_seq < st.seq0 || (uint64_t)split_seq - st.seq0 >= chunk)
+    const uint64_t rel0 = st.seq0 - h->seq_origin;              // the slots carry window-relative numbers
+    if ((uint64_t)split_seq < rel0 || (uint64_t)split_seq - rel0 >= chunk)
         return fail(h, NFAGG_EDEVICE, "optimistic fold: split sequence %u outside the batch [%llu, %llu)", split_seq,
-                    (unsigned long long)st.seq0, (unsigned long long)(st.seq0 + chunk));
-    *split = (uint64_t)split_seq - st.seq0;
+                    (unsigned long long)rel0, (unsigned long long)(rel0 + chunk));
+    *split = (uint64_t)split_seq - rel0;
     return NFAGG_OK;
 }
 
@@ -368,18 +391,16 @@ int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t*
     const char* base = static_cast<const char*>(d_records);
     int rc = NFAGG_OK;
     if (h->must_evict || h->exported) { if (consumed_out) *consumed_out = 0; return n ? NFAGG_FULL : NFAGG_OK; }
-    constexpr uint64_t kSeqLimit = 0xFFFFFFF0ull;   // sequence numbers are epoch-relative and 32 bits wide
     while (consumed < n) {
         uint64_t rem = n - consumed;
-        if (h->epoch_seq + rem >= kSeqLimit) {
-            // The epoch's sequence space is nearly used up (the reference has no such limit): fold what still fits, then
-            // ask for an eviction as if the table were full — flows are exported a little early, nothing is lost or refused.
-            rem = h->epoch_seq < kSeqLimit - 1 ? kSeqLimit - 1 - h->epoch_seq : 0;
-            if (rem == 0) {
-                if ((rc = refresh_counters(h)) != NFAGG_OK) break;
-                h->must_evict = true; h->split_seq = ~0ull;
-                h->stats.seq_space_evictions++;
-                rc = NFAGG_FULL;
+        if (rem > kMaxFoldChunk) rem = kMaxFoldChunk;
+        {   // the epoch has no maximum length (account.go:58-100): when the 32-bit window of the tags is used up it is moved
+            bool blocked = false;
+            if ((rc = ensure_seq_window(h, rem, &blocked)) != NFAGG_OK) break;
+            if (blocked) {
+                // numbering shared with other tables (nfagg_set_sequence): the window can only move when the flows have been
+                // brought together at their owners (nfagg_window_restart_device; the in-process group does it by itself)
+                rc = fail(h, NFAGG_ERANGE, "sequence window used up on an externally sequenced handle: restart the window (nfagg_window_restart_device) or evict");
                 break;
             }
         }
@@ -451,8 +472,8 @@ int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t*
         const uint64_t chunk = rem < h->careful_chunk ? rem : h->careful_chunk;
         const uint64_t seq0 = h->epoch_seq;
         h->epoch_unclustered = true;
-        hipError_t e = launch_claim(h->tv, d, chunk, seq0, h->d_slot_idx, h->stream);
-        if (e == hipSuccess) e = launch_first_flags(h->tv, h->d_slot_idx, chunk, seq0, h->d_flags, h->d_block_counts, h->stream);
+        hipError_t e = launch_claim(h->tv, d, chunk, seq0 - h->seq_origin, h->d_slot_idx, h->stream);
+        if (e == hipSuccess) e = launch_first_flags(h->tv, h->d_slot_idx, chunk, seq0 - h->seq_origin, h->d_flags, h->d_block_counts, h->stream);
         if (e != hipSuccess) { rc = fail(h, NFAGG_EDEVICE, "claim launch failed: %s", hipGetErrorString(e)); break; }
         const uint64_t nblk = (chunk + kFlagBlock - 1) / kFlagBlock;
         h->h_block_counts.resize(nblk);
@@ -811,16 +832,9 @@ int nfagg_len(nfagg_handle* h, uint64_t* entries) {
     return NFAGG_OK;
 }
 
-// The bookkeeping that ends an eviction epoch (the kernels have been launched; the device counters are reset by them).
-static int finish_epoch(nfagg_handle* h, int reason, uint64_t flows) {
-    h->stats.evictions[reason]++;
-    h->stats.evicted_flows[reason] += flows;
-    h->epoch_seq = 0; h->live = 0; h->live_ub = 0; h->must_evict = false; h->split_seq = 0; h->exported = false;
-    h->counters_exact = true;          // k_reset_after_evict left n_live = 0
-    h->epoch_unclustered = false;
-    h->abort_cap = 0;                  // one batch with more new keys than the table takes does not cap the chunks of later epochs
-    // The table itself was not touched: the slots of the evicted flows simply belong to a past epoch now.
-    // Tags hold 16 bits of epoch; when they wrap (every 65 535 evictions) the tags are cleared once.
+// The table itself is never cleared: the slots of the flows that just left simply belong to a past epoch tag.
+// Tags hold 16 bits of epoch; when they wrap (every 65 535 bumps) the tags are cleared once.
+static int bump_epoch(nfagg_handle* h) {
     uint64_t next_epoch = (h->tv.epoch_bits >> 48) + 1;
     if (next_epoch > 0xFFFFull) {
         HIP_TRY(h, hipMemsetAsync(h->tv.hot, 0, h->slots * sizeof(SlotHot), h->stream));
@@ -828,6 +842,17 @@ static int finish_epoch(nfagg_handle* h, int reason, uint64_t flows) {
     }
     h->tv.epoch_bits = next_epoch << 48;
     return NFAGG_OK;
+}
+
+// The bookkeeping that ends an eviction epoch (the kernels have been launched; the device counters are reset by them).
+static int finish_epoch(nfagg_handle* h, int reason, uint64_t flows) {
+    h->stats.evictions[reason]++;
+    h->stats.evicted_flows[reason] += flows;
+    h->epoch_seq = 0; h->seq_origin = 0; h->live = 0; h->live_ub = 0; h->must_evict = false; h->split_seq = 0; h->exported = false;
+    h->counters_exact = true;          // k_reset_after_evict left n_live = 0
+    h->epoch_unclustered = false;
+    h->abort_cap = 0;                  // one batch with more new keys than the table takes does not cap the chunks of later epochs
+    return bump_epoch(h);
 }
 
 static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device, size_t cap, size_t* n_out) {
@@ -874,7 +899,7 @@ static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device
         if (es != hipSuccess) return fail(h, NFAGG_EDEVICE, "slot sort failed: %s", hipGetErrorString(es));
         tv.live_list = (uint32_t*)h->d_sort[0];
     }
-    hipError_t e = launch_evict(tv, claimed, h->must_evict ? h->split_seq : ~0ull, d_out, h->stream);
+    hipError_t e = launch_evict(tv, claimed, h->must_evict ? h->split_seq - h->seq_origin : ~0ull, d_out, h->stream);
     if (h->cfg.profile) prof_end(h, ep);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "evict launch failed: %s", hipGetErrorString(e));
     // counters and (host variant) the records come back in stream order behind the kernel: one wait for both
@@ -926,7 +951,7 @@ static int partials_export_core(nfagg_handle* h, uint32_t n_shards, uint32_t sel
     if (rc != NFAGG_OK) return rc;
     if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;
     const uint64_t claimed = h->h_ctr->n_live;
-    const uint64_t seq_limit = h->must_evict ? h->split_seq : ~0ull;
+    const uint64_t seq_limit = h->must_evict ? h->split_seq - h->seq_origin : ~0ull;
     unsigned long long* d_counts = (unsigned long long*)h->d_exp;
     unsigned long long* d_cursor = d_counts + 64;
     hipError_t e = launch_export_count(h->tv, claimed, seq_limit, n_shards, self_shard, d_counts, h->stream);
@@ -977,7 +1002,7 @@ static int owned_count_core(nfagg_handle* h, uint32_t n_shards, uint32_t shard_i
     TableView tv = h->tv;
     tv.n_shards = n_shards; tv.shard_id = shard_id;
     unsigned long long* d_owned = (unsigned long long*)h->d_exp + 128;
-    const hipError_t e = launch_count_owned(tv, claimed, h->must_evict ? h->split_seq : ~0ull, d_owned, h->stream);
+    const hipError_t e = launch_count_owned(tv, claimed, h->must_evict ? h->split_seq - h->seq_origin : ~0ull, d_owned, h->stream);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "owned count launch failed: %s", hipGetErrorString(e));
     HIP_TRY(h, hipMemcpyAsync(h->h_exp + 128, d_owned, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1003,7 +1028,7 @@ static int evict_owned_core(nfagg_handle* h, int reason, uint32_t n_shards, uint
     tv.n_shards = n_shards; tv.shard_id = shard_id;
     EventPair ep{};
     if (h->cfg.profile) prof_begin(h, ep, 1);
-    const hipError_t e = launch_evict_filtered(tv, claimed, h->must_evict ? h->split_seq : ~0ull, d_out, h->stream);
+    const hipError_t e = launch_evict_filtered(tv, claimed, h->must_evict ? h->split_seq - h->seq_origin : ~0ull, d_out, h->stream);
     if (h->cfg.profile) prof_end(h, ep);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "evict launch failed: %s", hipGetErrorString(e));
     HIP_TRY(h, hipMemcpyAsync(h->h_ctr, h->tv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
@@ -1029,9 +1054,51 @@ int nfagg_set_sequence(nfagg_handle* h, uint64_t next_seq) {
     if (!h) return NFAGG_EINVAL;
     if (next_seq < h->epoch_seq) return fail(h, NFAGG_EINVAL, "sequence numbers do not go backwards inside an epoch (%llu < %llu)",
                                              (unsigned long long)next_seq, (unsigned long long)h->epoch_seq);
-    if (next_seq >= 0xFFFFFFF0ull) return fail(h, NFAGG_ERANGE, "would pass the end of the epoch's sequence space");
     h->epoch_seq = next_seq;
+    h->ext_sequenced = true;                                    // other tables number their records in the same space
     return NFAGG_OK;
+}
+
+// ---- the sequence window of tables that share ONE numbering (local fold across GPUs) ---------------------------------
+// Such a table cannot rebase its tags on its own (nfagg_rebase.hip): the flows are first brought together at their owners —
+// every table exports ALL its flows as partials grouped by owner (nfagg_partials_export_device with NFAGG_SHARD_NONE),
+// empties itself (window_clear_core: the epoch tag, nothing is written), takes in what it owns (partials_merge_core, its own
+// segment included) and rebases the single copy it now holds (window_finish_core). No flow leaves the epoch, the sketches are
+// not touched; len(entries) of a table becomes the number of flows it owns.
+static int window_clear_core(nfagg_handle* h) {
+    if (h->must_evict) return fail(h, NFAGG_ESTATE, "an eviction on full is pending");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const hipError_t e = launch_reset_counters(h->tv, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "counter reset launch failed: %s", hipGetErrorString(e));
+    h->live = h->live_ub = 0; h->counters_exact = true; h->mirror_fresh = false;
+    h->epoch_unclustered = false; h->exported = false;
+    return bump_epoch(h);
+}
+
+static int window_finish_core(nfagg_handle* h, uint64_t next_seq) {
+    if (next_seq < h->epoch_seq || next_seq < rebase_keep()) return fail(h, NFAGG_EINVAL, "window restart: next sequence number %llu below what the handle has reached",
+                                                                         (unsigned long long)next_seq);
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipError_t e = launch_finalize(h->tv, nullptr, 0, 0, h->stream);          // the merges copied the identity dwords: everything is finalized
+    if (e == hipSuccess) e = launch_rebase(h->tv, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "window restart launch failed: %s", hipGetErrorString(e));
+    h->epoch_seq = next_seq; h->seq_origin = next_seq - rebase_keep();
+    h->exported = false; h->counters_exact = false; h->mirror_fresh = false;
+    h->stats.sequence_rebases++;
+    const int rc = refresh_counters(h);                                        // len(entries) = the flows this table owns now; reports refused claims
+    if (rc != NFAGG_OK) return rc;
+    if (h->h_ctr->aborted) return fail(h, NFAGG_EDEVICE, "table too small for the flows this shard owns (claims refused while merging)");
+    h->epoch_unclustered = true;
+    return NFAGG_OK;
+}
+
+int nfagg_window_restart_device(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id, const void* d_partials, size_t n, uint64_t next_seq) {
+    if (!h) return NFAGG_EINVAL;
+    int rc = window_clear_core(h);
+    if (rc != NFAGG_OK) return rc;
+    if ((rc = partials_merge_core(h, n_shards, shard_id, d_partials, n)) != NFAGG_OK) return rc;
+    h->ext_sequenced = true;
+    return window_finish_core(h, next_seq);
 }
 
 // ---------------------------------------------------------------- nfagg_account*: the record arm WITH its evictions on "full"
@@ -1041,7 +1108,7 @@ constexpr uint64_t kAccountFastMaxEntries = 32768;   // beyond that an epoch is 
 static bool account_fast_ok(const nfagg_handle* h, size_t n, size_t out_cap) {
     return h->cfg.mode == NFAGG_MODE_ACCOUNTER && h->cfg.max_entries <= kAccountFastMaxEntries && !h->must_evict && !h->exported &&
            h->cfg.max_entries + epoch_window() + 16 <= h->tv.claim_limit && out_cap >= h->cfg.max_entries &&
-           h->epoch_seq + n < 0xFFFFFFF0ull - epoch_window() && (h->tv.epoch_bits >> 48) < 0xFFFFull;
+           h->epoch_seq - h->seq_origin + n < kSeqWindow - epoch_window() && (h->tv.epoch_bits >> 48) < 0xFFFFull;
 }
 
 // One launch of the epoch kernel over d[0..n). *consumed / *n_ep / *n_out: records consumed, evictions performed, records written
@@ -1062,7 +1129,7 @@ static int account_fast_launch(nfagg_handle* h, const void* d, size_t n, void* d
         HIP_TRY(h, hipHostMalloc(&h->h_ep, hb + 4096, hipHostMallocDefault));
         h->h_ep_cap = hb + 4096;
     }
-    const uint64_t seq_start = h->epoch_seq, n_live0 = h->h_ctr->n_live;
+    const uint64_t seq_start = h->epoch_seq - h->seq_origin, n_live0 = h->h_ctr->n_live;     // window-relative, as the slots carry it
     epoch_ctl_fill(h->h_ep, seq_start, h->live, 0, n_live0, h->tv.epoch_bits);
     HIP_TRY(h, hipMemcpyAsync(h->d_ep[0], h->h_ep, epoch_ctl_bytes(), hipMemcpyHostToDevice, h->stream));
     EventPair ep{};
@@ -1091,7 +1158,8 @@ static int account_fast_launch(nfagg_handle* h, const void* d, size_t n, void* d
     const uint64_t first_rec = pos - (seq - seq_at_start);
     e = launch_finalize(h->tv, (const char*)d + first_rec * kRecordBytes, pos - first_rec, seq_at_start, h->stream);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "finalize launch failed: %s", hipGetErrorString(e));
-    h->epoch_seq = seq; h->live = h->live_ub = live;
+    if (n_epochs) h->seq_origin = 0;                            // an eviction inside the launch restarted the epoch: a fresh window
+    h->epoch_seq = h->seq_origin + seq; h->live = h->live_ub = live;
     h->counters_exact = true;                                   // n_live = live: k_ring_counters wrote it
     h->epoch_unclustered = true;
     h->stats.records_ingested += pos;
@@ -1591,8 +1659,7 @@ void* nfagg_stream(nfagg_handle* h) { return h ? (void*)h->stream : nullptr; }
 
 int nfagg_debug_skip_sequence(nfagg_handle* h, uint64_t records) {
     if (!h) return NFAGG_EINVAL;
-    if (h->epoch_seq + records >= 0xFFFFFFF0ull) return fail(h, NFAGG_ERANGE, "would pass the end of the epoch's sequence space");
-    h->epoch_seq += records;
+    h->epoch_seq += records;                                    // any amount: the window follows (nfagg_rebase.hip)
     return NFAGG_OK;
 }
 

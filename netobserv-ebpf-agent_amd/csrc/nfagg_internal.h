@@ -210,6 +210,11 @@ hipError_t launch_account_epochs(const TableView& t, const SketchView& sk, const
                                  uint64_t* d_epoch_end, uint32_t max_epochs, uint64_t max_entries, void* d_ctl, hipStream_t s);
 // the epoch in progress, ring positions [base, base + cnt) of the live list, to the front; device counters n_live / n_finalized
 hipError_t launch_ring_to_front(const TableView& t, uint64_t base, uint64_t cnt, uint64_t n_finalized, uint32_t* d_tmp, hipStream_t s);
+// The sequence window (nfagg_rebase.hip): the tags of the live slots rebased in place; the new window starts at rebase_keep().
+hipError_t launch_rebase(const TableView& t, hipStream_t s);
+uint32_t rebase_keep();
+// n_live = n_finalized = 0, aborted / max_probe cleared (what the eviction leaves behind), without an eviction
+hipError_t launch_reset_counters(const TableView& t, hipStream_t s);
 // Sketch update over a batch (nfagg_sketch.hip).
 hipError_t launch_sketch_update(const SketchView& sk, const TableView& t, const void* d_records, uint64_t n, hipStream_t s);
 hipError_t launch_cm_estimate(const uint64_t* d_cm, uint32_t depth, uint32_t log2w, int side, const void* d_records, uint64_t n,

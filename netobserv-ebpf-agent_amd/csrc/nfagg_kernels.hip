@@ -389,6 +389,11 @@ hipError_t launch_finalize(const TableView& t, const void* d_records, uint64_t n
     return hipGetLastError();
 }
 
+hipError_t launch_reset_counters(const TableView& t, hipStream_t s) {
+    (void)hipGetLastError(); hipLaunchKernelGGL(k_reset_after_evict, dim3(1), dim3(1), 0, s, t.ctr, 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_sort_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, void* d_temp, size_t* temp_bytes, hipStream_t s) {
     return hipcub::DeviceRadixSort::SortKeys(d_temp, *temp_bytes, d_in, d_out, (int)n, 0, 32, s);
 }

@@ -379,6 +379,9 @@ class FlowTable:
     def partials_merge_device(self, n_shards: int, shard_id: int, d_partials: int, n: int):
         self._check(L.lib.nfagg_partials_merge_device(self._h, n_shards, shard_id, C.c_void_p(d_partials or None), n))
 
+    def window_restart_device(self, n_shards: int, shard_id: int, d_partials: int, n: int, next_seq: int):
+        self._check(L.lib.nfagg_window_restart_device(self._h, n_shards, shard_id, C.c_void_p(d_partials or None), n, next_seq))
+
     def evict_owned_device(self, n_shards: int, shard_id: int, d_out: int, cap: int, reason=L.REASON_TIMEOUT):
         """Returns (rc, n): rc TRUNCATED = nothing evicted, n records needed."""
         n = C.c_size_t(0)
@@ -481,6 +484,9 @@ class FlowGroup:
 
     def merge_sketches(self):
         self._check(L.lib.nfagg_group_merge_sketches(self._g))
+
+    def debug_skip_sequence(self, records: int):
+        self._check(L.lib.nfagg_group_debug_skip_sequence(self._g, records))
 
     def evict(self, reason=L.REASON_TIMEOUT) -> np.ndarray:
         cap = max(len(self), 1)
