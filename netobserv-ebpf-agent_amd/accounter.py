@@ -174,15 +174,16 @@ class Accounter:
             self.metrics.buffer_size["accounter-entries"] = len(self.table)   # :98 (per batch, not per record)
 
     def account_batch(self, records: np.ndarray, out) -> bool:
-        """The record arm (:81-96) for a batch, in arrival order. Returns True if a
-        'full' eviction happened."""
+        """The record arm (:81-96) for a batch, in arrival order, WITH its evictions on full: nfagg_account evicts inline
+        whenever a record's new key finds len(c.entries) >= c.maxEntries (:85-94) and goes on — one call per batch whatever
+        CACHE_MAX_FLOWS is; every eviction is one put on `out`, as the reference's. Returns True if one happened."""
         evicted_full = False
         off = 0
         while off < len(records):
-            rc, consumed = self.table.ingest(records[off:])
+            rc, consumed, epochs = self.table.account(records[off:])
             off += consumed
-            if rc == L.FULL:                               # len(c.entries) >= c.maxEntries (:85)
-                self.evict(out, "full")
+            for raw in epochs:
+                self._send(out, raw, "full")
                 evicted_full = True
         return evicted_full
 
@@ -191,7 +192,12 @@ class Accounter:
         now = self.clock()
         monotonic_now = self.monoClock() & ((1 << 64) - 1)
         code = {"timeout": L.REASON_TIMEOUT, "full": L.REASON_FULL, "closing": L.REASON_CLOSING}[reason]
-        raw = self.table.evict(code)
+        self._send(out, self.table.evict(code), reason, now, monotonic_now)
+
+    def _send(self, out, raw, reason: str, now=None, monotonic_now=None):
+        if now is None:
+            now = self.clock()
+            monotonic_now = self.monoClock() & ((1 << 64) - 1)
         records = [NewRecord(r["id"], r["metrics"], now, monotonic_now) for r in raw]   # :116-119
         self.metrics.eviction("accounter", reason, len(records))                         # :120-121
         out.put(records)
