@@ -119,6 +119,8 @@ struct nfagg_handle {
     void* h_ep = nullptr;           // pinned: control block, then the epoch ends
     size_t h_ep_cap = 0;
     uint64_t ep_phase[8] = {};      // diagnostics: accumulated phase ticks of the epoch kernel
+    hipGraphExec_t ep_graph = nullptr;   // kChainBatch windows of the epoch kernel chain, captured once (their arguments never change)
+    void* ep_graph_key[3] = {};          // the buffers the captured launches point at: re-capture when one was re-allocated
     nfagg_stats stats{};
     std::vector<EventPair> ev_pending;
     std::vector<EventPair> ev_free;
@@ -704,6 +706,7 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->h_careful) hipHostFree(h->h_careful);
     if (h->h_exp) hipHostFree(h->h_exp);
     if (h->d_exp) hipFree(h->d_exp);
+    if (h->ep_graph) hipGraphExecDestroy(h->ep_graph);
     if (h->h_ep) hipHostFree(h->h_ep);
     if (h->d_ep_out) hipFree(h->d_ep_out);
     for (int k = 0; k < 3; k++) if (h->d_ep[k]) hipFree(h->d_ep[k]);
@@ -1169,6 +1172,79 @@ static int account_fast_launch(nfagg_handle* h, const void* d, size_t n, void* d
     return NFAGG_OK;
 }
 
+// The same through the kernel chain (nfagg_epoch_chain.hip): windows are enqueued kChainBatch at a time, the control block is
+// read back after each batch of launches.
+static int account_chain_launch(nfagg_handle* h, const void* d, size_t n, void* d_out, size_t out_cap, uint64_t* epoch_end, size_t max_epochs,
+                                size_t* consumed, size_t* n_ep, size_t* n_out, uint32_t* stop) {
+    constexpr int kChainBatch = 24;
+    int rc;
+    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;                       // exact len(entries), n_live, n_finalized
+    if (h->h_ctr->n_finalized != h->h_ctr->n_live) return fail(h, NFAGG_ESTATE, "account: unfinalized slots at the start of a batch");
+    const uint32_t me = max_epochs > 0xFFFFu ? 0xFFFFu : (uint32_t)max_epochs;
+    const size_t ctlb = (chain_ctl_bytes() + 63) & ~(size_t)63;
+    if ((rc = ensure_bytes(h, &h->d_ep[0], &h->d_ep_cap[0], ctlb)) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_ep[1], &h->d_ep_cap[1], (size_t)(me + 1) * sizeof(uint64_t))) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_ep[2], &h->d_ep_cap[2], (size_t)(h->cfg.max_entries + chain_window() + 64) * sizeof(uint32_t))) != NFAGG_OK) return rc;
+    const size_t hb = ctlb + (size_t)(me + 1) * sizeof(uint64_t);
+    if (h->h_ep_cap < hb) {
+        if (h->h_ep) { hipHostFree(h->h_ep); h->h_ep = nullptr; h->h_ep_cap = 0; }
+        HIP_TRY(h, hipHostMalloc(&h->h_ep, hb + 4096, hipHostMallocDefault));
+        h->h_ep_cap = hb + 4096;
+    }
+    const uint64_t seq_start = h->epoch_seq - h->seq_origin;                      // window-relative, as the slots carry it
+    chain_ctl_fill(h->h_ep, d, d_out, n, seq_start, h->live, h->h_ctr->n_live, out_cap, h->tv.epoch_bits, h->cfg.max_entries, me);
+    HIP_TRY(h, hipMemcpyAsync(h->d_ep[0], h->h_ep, chain_ctl_bytes(), hipMemcpyHostToDevice, h->stream));
+    // kChainBatch windows = 4 x kChainBatch launches whose arguments are the same in every call: captured into a graph once, one
+    // hipGraphLaunch per batch afterwards (eager launches cost the host ~8 us each here: the chain was host-bound)
+    if (!h->ep_graph || h->ep_graph_key[0] != h->d_ep[0] || h->ep_graph_key[1] != h->d_ep[1] || h->ep_graph_key[2] != h->d_ep[2]) {
+        if (h->ep_graph) { hipGraphExecDestroy(h->ep_graph); h->ep_graph = nullptr; }
+        hipGraph_t g = nullptr;
+        HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t ec = hipSuccess;
+        for (int k = 0; k < kChainBatch && ec == hipSuccess; k++)
+            ec = launch_epoch_chain_window(h->tv, h->sk, h->d_ep[0], (uint32_t*)h->d_ep[2], (uint64_t*)h->d_ep[1], h->stream);
+        const hipError_t ee = hipStreamEndCapture(h->stream, &g);
+        if (ec != hipSuccess || ee != hipSuccess) { if (g) hipGraphDestroy(g); return fail(h, NFAGG_EDEVICE, "epoch chain capture failed: %s", hipGetErrorString(ec != hipSuccess ? ec : ee)); }
+        const hipError_t ei = hipGraphInstantiate(&h->ep_graph, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (ei != hipSuccess) { h->ep_graph = nullptr; return fail(h, NFAGG_EDEVICE, "epoch chain graph instantiation failed: %s", hipGetErrorString(ei)); }
+        h->ep_graph_key[0] = h->d_ep[0]; h->ep_graph_key[1] = h->d_ep[1]; h->ep_graph_key[2] = h->d_ep[2];
+    }
+    EventPair ep{};
+    if (h->cfg.profile) prof_begin(h, ep, 0);
+    uint64_t v[9];
+    for (;;) {
+        HIP_TRY(h, hipGraphLaunch(h->ep_graph, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_ep, h->d_ep[0], chain_ctl_bytes(), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        chain_ctl_read(h->h_ep, v);
+        if (v[6] != 0) break;
+    }
+    if (h->cfg.profile) prof_end(h, ep);
+    const uint64_t pos = v[0], seq = v[1], live = v[2], out_pos = v[3], n_epochs = v[5];
+    if (n_epochs) HIP_TRY(h, hipMemcpyAsync((char*)h->h_ep + ctlb, h->d_ep[1], (size_t)n_epochs * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    h->counters_exact = false; h->mirror_fresh = false;
+    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;                       // synchronises: epoch ends, counters
+    if (h->h_ctr->n_live != live)
+        return fail(h, NFAGG_EDEVICE, "epoch chain: %llu claimed slots, len(entries) %llu", (unsigned long long)h->h_ctr->n_live, (unsigned long long)live);
+    for (uint64_t k = 0; k < n_epochs && k < max_epochs; k++) epoch_end[k] = ((const uint64_t*)((const char*)h->h_ep + ctlb))[k];
+    h->tv.epoch_bits = v[4];
+    // identity dwords of the slots the epoch in progress claimed in this call, from the batch
+    const bool began_here = v[8] != 0;
+    const uint64_t first_rec = began_here ? v[7] : 0, seq_at_first = began_here ? 0 : seq_start;
+    const hipError_t e = launch_finalize(h->tv, (const char*)d + first_rec * kRecordBytes, pos - first_rec, seq_at_first, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "finalize launch failed: %s", hipGetErrorString(e));
+    if (n_epochs) h->seq_origin = 0;                            // an eviction inside the call restarted the epoch: a fresh window
+    h->epoch_seq = h->seq_origin + seq; h->live = h->live_ub = live;
+    h->counters_exact = true;
+    h->epoch_unclustered = true;
+    h->stats.records_ingested += pos;
+    h->stats.evictions[NFAGG_REASON_FULL] += n_epochs;
+    h->stats.evicted_flows[NFAGG_REASON_FULL] += out_pos;
+    *consumed = (size_t)pos; *n_ep = (size_t)n_epochs; *n_out = (size_t)out_pos; *stop = (uint32_t)v[6];
+    return NFAGG_OK;
+}
+
 // d_out: DEVICE. epoch_end: HOST. Evictions append to d_out; *n_epochs of them, the e-th ends at record epoch_end[e].
 static int account_device_core(nfagg_handle* h, const void* d_records, size_t n, void* d_out, size_t out_cap, uint64_t* epoch_end,
                                size_t max_epochs, size_t* n_epochs_out, size_t* consumed_out) {
@@ -1189,8 +1265,9 @@ static int account_device_core(nfagg_handle* h, const void* d_records, size_t n,
     while (rc == NFAGG_OK && consumed < n) {
         if (account_fast_ok(h, n - consumed, out_cap - out_pos) && n_ep < max_epochs) {
             size_t c = 0, e = 0, o = 0; uint32_t stop = 0;
-            rc = account_fast_launch(h, base + consumed * kRecordBytes, n - consumed, obase + out_pos * kRecordBytes, out_cap - out_pos,
-                                     epoch_end + n_ep, max_epochs - n_ep, &c, &e, &o, &stop);
+            rc = (h->cfg.ingest_variant == 30 ? account_fast_launch : account_chain_launch)(
+                h, base + consumed * kRecordBytes, n - consumed, obase + out_pos * kRecordBytes, out_cap - out_pos,
+                epoch_end + n_ep, max_epochs - n_ep, &c, &e, &o, &stop);
             if (rc != NFAGG_OK) break;
             for (size_t k = 0; k < e; k++) epoch_end[n_ep + k] += out_pos;
             consumed += c; n_ep += e; out_pos += o;
@@ -1261,16 +1338,16 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
         if (ebuf) h->d_ep_out_cap = capb; else h->d_evict_cap = capb;
         if (rc != NFAGG_OK) break;
         size_t c = 0, e = 0;
-        int rc_helper = NFAGG_OK;
-        std::thread helper;
-        const bool use_helper = more || prev.has;
-        if (use_helper) helper = std::thread([&] {
-            (void)hipSetDevice(h->device);
-            rc_helper = bring_down();
-            if (rc_helper == NFAGG_OK && more) rc_helper = stage(b ^ 1, lo + m);
-        });
+        int rc_helper = NFAGG_OK, rc_helper2 = NFAGG_OK;
+        std::thread helper, helper2;                            // one brings chunk k-1's evictions down, one sends chunk k+1 up
+        const bool down = prev.has && prev.got != 0;
+        if (down) helper = std::thread([&] { (void)hipSetDevice(h->device); rc_helper = bring_down(); });
+        else prev.has = false;
+        if (more) helper2 = std::thread([&] { (void)hipSetDevice(h->device); rc_helper2 = stage(b ^ 1, lo + m); });
         rc = account_device_core(h, h->d_stage[b], m, *dbuf, room, epoch_end + n_ep, max_epochs - n_ep, &e, &c);
-        if (use_helper) helper.join();
+        if (down) helper.join();
+        if (more) helper2.join();
+        if (rc_helper == NFAGG_OK) rc_helper = rc_helper2;
         if (rc == NFAGG_OK && rc_helper != NFAGG_OK) rc = rc_helper;
         HIP_TRY(h, hipEventRecord(h->stage_free[b], h->stream));
         const size_t got = e ? (size_t)epoch_end[n_ep + e - 1] : 0;

@@ -208,6 +208,14 @@ void epoch_ctl_read(const void* h_ctl, uint64_t out[9]);
 void epoch_ctl_phases(const void* h_ctl, uint64_t out[8]);   // diagnostics: 100 MHz ticks per phase (lane 0)
 hipError_t launch_account_epochs(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, void* d_out, uint64_t out_cap,
                                  uint64_t* d_epoch_end, uint32_t max_epochs, uint64_t max_entries, void* d_ctl, hipStream_t s);
+// The same loop as a chain of four small kernels per window (nfagg_epoch_chain.hip; the default): control block helpers and one
+// window's launches. chain_ctl_read -> {pos, seq, live, out_pos, epoch_bits, n_epochs, stop, epoch_first, epoch_began_here}.
+size_t chain_ctl_bytes();
+uint32_t chain_window();
+void chain_ctl_fill(void* h_ctl, const void* d_records, void* d_out, uint64_t n, uint64_t seq, uint64_t live, uint64_t list_fin, uint64_t out_cap,
+                    uint64_t epoch_bits, uint64_t max_entries, uint32_t max_epochs);
+void chain_ctl_read(const void* h_ctl, uint64_t out[9]);
+hipError_t launch_epoch_chain_window(const TableView& t, const SketchView& sk, void* d_ctl, uint32_t* d_slot_idx, uint64_t* d_epoch_end, hipStream_t s);
 // the epoch in progress, ring positions [base, base + cnt) of the live list, to the front; device counters n_live / n_finalized
 hipError_t launch_ring_to_front(const TableView& t, uint64_t base, uint64_t cnt, uint64_t n_finalized, uint32_t* d_tmp, hipStream_t s);
 // The sequence window (nfagg_rebase.hip): the tags of the live slots rebased in place; the new window starts at rebase_keep().

@@ -38,13 +38,14 @@ def _check(nf, O, tab, recs, max_entries, batches, mode=0):
     return len(want)
 
 
+@pytest.mark.parametrize("variant", [0, 30])      # 0: the kernel chain (default); 30: the one persistent cooperative kernel
 @pytest.mark.parametrize("max_entries,keys,n", [(5000, 100_000, 400_000), (100, 3_000, 60_000), (2, 50, 3_000), (20_000, 400_000, 500_000),
                                                  (5000, 4_000, 100_000)])
-def test_account_equals_the_reference_loop(nf, O, max_entries, keys, n):
-    """Whole stream in one call (windows of 16 384 records inside the kernel; epochs from 3 records to longer than a window;
+def test_account_equals_the_reference_loop(nf, O, max_entries, keys, n, variant):
+    """Whole stream in one call (windows of 16 384 records on the device; epochs from 3 records to longer than a window;
     a map that never fills)."""
     recs = _stream(O, n, keys, seed=7 + max_entries)
-    with nf.FlowTable(max_entries=max_entries) as tab:
+    with nf.FlowTable(max_entries=max_entries, ingest_variant=variant) as tab:
         n_ev = _check(nf, O, tab, recs, max_entries, [n])
         if keys > max_entries:
             assert n_ev > 3
@@ -60,7 +61,8 @@ def test_account_ragged_batches_hot_flows_and_sketches(nf, O, seed):
     max_entries = int(rng.choice([7, 300, 5000]))
     recs = _stream(O, 250_000, int(rng.choice([2_000, 80_000])), seed=90 + seed, hot=int(rng.choice([0, 700])))
     batches = [int(rng.choice([1, 5, 999, 16_384, 16_385, 40_000, 100_000])) for _ in range(400)]
-    with nf.FlowTable(max_entries=max_entries, sketches=nf.SKETCH_CM | nf.SKETCH_HLL, cm_log2_width=12, hll_p=8) as tab:
+    with nf.FlowTable(max_entries=max_entries, sketches=nf.SKETCH_CM | nf.SKETCH_HLL, cm_log2_width=12, hll_p=8,
+                      ingest_variant=30 if seed == 4 else 0) as tab:
         _check(nf, O, tab, recs, max_entries, batches)
         cs, cd, hs, hd = O.sketches(recs, 4, 12, 8)
         assert np.array_equal(tab.sketch_snapshot(nf.CM_SRC), cs) and np.array_equal(tab.sketch_snapshot(nf.CM_DST), cd)

@@ -22,8 +22,8 @@ torch.cuda.synchronize()
 fn = L.lib.nfagg_debug_epoch_phases
 fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]
 names = ["P1 claim", "sync1", "P2 flags", "sync2", "P3 split(+sync)", "P4 fold", "sync4+P5 evict", "sync5"]
-for me in (5000, 500, 30000):
-    with nf.FlowTable(max_entries=me) as tab:
+for me, variant in ((5000, 0), (5000, 30), (500, 0), (500, 30), (30000, 0), (30000, 30)):
+    with nf.FlowTable(max_entries=me, ingest_variant=variant) as tab:
         for rep in range(2):
             t0 = time.perf_counter()
             rc, c, ends = tab.account_device(d.data_ptr(), n, out.data_ptr(), n + 70000, 65000)
@@ -32,5 +32,6 @@ for me in (5000, 500, 30000):
             ph = (C.c_uint64 * 8)()
             fn(tab._h, ph)
         ep = max(len(ends), 1)
-        print("max_entries %d: %d epochs, %.1f us per epoch, %.1f M records/s" % (me, len(ends), dt / ep * 1e6, n / dt / 1e6))
-        print("   " + ", ".join("%s %.1f" % (nm, ph[k] / 100.0 / ep) for k, nm in enumerate(names)) + "  (us per epoch)")
+        print("max_entries %d, %s: %d epochs, %.1f us per epoch, %.1f M records/s" % (me, "persistent kernel" if variant == 30 else "kernel chain", len(ends), dt / ep * 1e6, n / dt / 1e6))
+        if variant == 30:
+            print("   " + ", ".join("%s %.1f" % (nm, ph[k] / 100.0 / ep) for k, nm in enumerate(names)) + "  (us per epoch)")
