@@ -161,7 +161,8 @@ def rank_main(args):
     from netobserv_ebpf_agent_amd import synth
 
     n, keys = resolve_sizes(args, world)
-    local_fold = world > 1 and not args.presharded
+    local_fold = world > 1 and not args.presharded and not args.dedup   # the kernel-dedup slots do not merge across GPUs:
+                                                                        # --dedup at N > 1 runs the pre-sharded line (every flow on the GPU that owns it)
     sketches = args.sketches or (world > 1 and not args.no_sketches)
     keys_total = keys * world if local_fold else keys
     # ---- synthetic stream, generated in HBM (seed 2)
@@ -540,11 +541,13 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
     gen_stream(0, 0)
     m = min(20_000_000, n)
     host = d_recs[: m * 144].cpu().numpy().view(nf.FLOW_RECORD)
+    h_flows = np.empty(keys, dtype=nf.FLOW_RECORD)                # the caller's eviction buffer, reused tick after tick
+    h_flows.view(np.uint8)[::4096] = 0
     with nf.FlowTable(max_entries=DEFAULT_MAX_ENTRIES, device=torch.cuda.current_device()) as tab:
         def e2e():
             rc, c = tab.ingest(host)
             assert rc == nf.OK and c == m, (rc, c)
-            return len(tab.evict(nf.REASON_TIMEOUT, cap=keys))
+            return len(tab.evict(nf.REASON_TIMEOUT, out=h_flows))
         e2e()
         t0 = time.perf_counter()
         flows = e2e()

@@ -699,7 +699,9 @@ int nfagg_group_ingest_device(nfagg_group* g, uint32_t src_member, const void* d
 int nfagg_group_len(nfagg_group* g, uint64_t* entries);
 /* The per-tick collective: ncclAllReduce(sum, uint64) over each Count-Min array and ncclAllReduce(max, uint32) over each
  * HLL register array, in place on every member, on the members' streams. Afterwards every member answers
- * nfagg_hll_estimate / nfagg_cm_query / nfagg_cm_topk for the whole node. */
+ * nfagg_hll_estimate / nfagg_cm_query / nfagg_cm_topk for the whole node. IN PLACE means: call it ONCE per window, then
+ * nfagg_sketch_reset every member (nfagg_group_member) before the next window's records arrive — a second call, or the next
+ * tick's call without the reset, would sum N copies of the already merged counters (Count-Min inflated N x per call). */
 int nfagg_group_merge_sketches(nfagg_group* g);
 /* Accounter.evict (account.go:102-124) for every shard: the members' flows back to back in `out` (HOST memory). */
 int nfagg_group_evict(nfagg_group* g, int reason, void* out, size_t cap, size_t* n_out);

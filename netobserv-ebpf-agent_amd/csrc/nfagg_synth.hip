@@ -6,7 +6,7 @@
 // (pkg/model/bench_fixtures_test.go:19-50 benchFlowID / benchFlowMetrics) as
 // fixed in SURVEY.md §8(d); ranks are drawn Zipf(s) by inverse CDF over a
 // 64-bit fixed-point threshold table with a counter-based RNG, so that the CPU
-// generator in oracle/ reproduces every byte (tests/test_synth.py).
+// generator in oracle/ reproduces every byte (tests/test_device_path_gpu.py::test_device_generator_matches_host_generator).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>

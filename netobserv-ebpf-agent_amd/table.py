@@ -112,11 +112,15 @@ class FlowTable:
         return v.value
 
     # -- evict
-    def evict(self, reason=L.REASON_TIMEOUT, cap=None) -> np.ndarray:
-        """nfagg_evict: every live flow as one flow_record_t; table cleared."""
-        if cap is None:
+    def evict(self, reason=L.REASON_TIMEOUT, cap=None, out=None) -> np.ndarray:
+        """nfagg_evict: every live flow as one flow_record_t; table cleared. out: a FLOW_RECORD array to deliver into (a caller
+        that evicts tick after tick reuses one, as the cgo shim does)."""
+        if out is not None:
+            cap = len(out)
+        elif cap is None:
             cap = max(len(self), 1)
-        out = np.zeros(cap, dtype=FLOW_RECORD)
+        if out is None:
+            out = np.empty(cap, dtype=FLOW_RECORD)
         n = C.c_size_t(0)
         rc = L.lib.nfagg_evict(self._h, reason, out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
         self._check(rc, (L.OK, L.TRUNCATED))

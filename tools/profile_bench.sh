@@ -1,4 +1,5 @@
 #!/bin/bash
+exec < /dev/null
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run from the repo root via gpurun).
 # 1) kernel-trace + stats  2) PMC passes (each in its own run, no other trace domains)
 # 3) the same FETCH_SIZE / WRITE_SIZE passes over tools/pmc_calib (known byte counts) for calibration.
@@ -7,8 +8,8 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="${BENCH_ARGS:---steps 3 --warmup 1 --cpu-sample 0}"
-PMC_ARGS="${PMC_BENCH_ARGS:---steps 1 --warmup 0 --cpu-sample 0}"
+ARGS="${BENCH_ARGS:---steps 3 --warmup 1 --cpu-sample 0 --no-extras}"
+PMC_ARGS="${PMC_BENCH_ARGS:---steps 1 --warmup 0 --cpu-sample 0 --no-extras}"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py $ARGS > $OUT/trace_bench.json 2> $OUT/trace_err.txt
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
