@@ -238,7 +238,7 @@ typedef struct nfagg_config {
     uint32_t shard_id;
     uint32_t profile;            /* 1 -> bracket kernels with HIP events (stats) */
     uint32_t ingest_variant;     /* 0 -> default kernels by batch size (direct kernel below 6144 records,
-                                    single-pass LDS-cached kernel below 768 Ki, two-pass partitioned fold from
+                                    single-pass LDS-cached kernel below 384 Ki, two-pass partitioned fold from
                                     there); others are A/B and diagnostic builds, see DESIGN.md §4.1b */
     /* Optional caller-owned DEVICE buffers for the sketches (so that another
      * library, e.g. RCCL via torch.distributed, can all-reduce them in place).
@@ -365,8 +365,9 @@ int nfagg_evict_device(nfagg_handle* h, int reason, void* d_out, size_t cap, siz
  * for another eviction (out_cap - records written < live flows; keep out_cap >= max_entries) or max_epochs are used up:
  * drain `out`, then call again with the rest (a pending eviction is delivered first).
  * With a small CACHE_MAX_FLOWS (the reference ships 5000, pkg/config/config.go:146) the stream stops on "full" every few
- * thousand records; here that whole loop — split search, fold, eviction, next epoch — runs on the device in one persistent
- * kernel (max_entries <= 32768, NFAGG_MODE_ACCOUNTER), the host reads back one control block per call.
+ * thousand records; here that whole loop — split search, fold, eviction, next epoch — runs on the device (max_entries <= 32768,
+ * NFAGG_MODE_ACCOUNTER: a chain of small kernels driven by a control block in device memory, replayed from a hipGraph;
+ * ingest_variant 30 = one persistent cooperative kernel instead), the host reads the control block back once per 24 windows.
  * All pointers HOST memory: */
 int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, size_t out_cap, uint64_t* epoch_end,
                   size_t max_epochs, size_t* n_epochs, size_t* consumed);

@@ -1,4 +1,4 @@
-// nfagg_ingest_part.hip — two-pass partitioned ingest (the default from 768 Ki records per call; ingest_variant 10 forces it).
+// nfagg_ingest_part.hip — two-pass partitioned ingest (the default from 384 Ki records per call; ingest_variant 10 forces it).
 //
 // The single-pass cached kernel (nfagg_ingest_cached.hip) folds the hot head of a
 // Zipf stream in LDS, but every record of the cold tail (40 % of configs[1]) goes to

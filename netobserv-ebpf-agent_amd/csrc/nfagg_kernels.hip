@@ -288,13 +288,13 @@ static inline int grid_for(uint64_t n, int block, int max_blocks) {
 hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                                 int variant, hipStream_t s);  // nfagg_ingest_cached.hip
 
-// Default kernel by batch size, measured on configs[1]'s stream, per call (round 2: gpurun_out/r02_sweep -> profiles/r02_batch_size_sweep.txt;
-// round 1: profiles/r01e_batch_size_crossover.txt):
+// Default kernel by batch size, measured on configs[1]'s stream, per call (round 3: profiles/r03_batch_size_sweep.txt; round 2:
+// profiles/r02_batch_size_sweep.txt; round 1: profiles/r01e_batch_size_crossover.txt):
 //   below 6 144 records the direct kernel (one record per lane, HBM atomics; no LDS cache to set up and flush);
-//   below 768 Ki records the single-pass LDS-cached kernel: 0.050 ms per 65 536 records against 0.096 ms for the launches
-//     of the two-pass fold, 0.13 against 0.17 ms at 256 Ki;
-//   from there the two-pass partitioned fold: 0.28 against 0.40 ms at 1 Mi, 0.62 against 1.29 ms at 4 Mi (since pass 2 flushes
-//     with plain read-modify-writes the crossover lies at ~0.5 Mi; it was 3 Mi in round 1).
+//   below 384 Ki records (768 Ki in round 2) the single-pass LDS-cached kernel: 0.049 ms per 65 536 records against 0.063 ms for the launches
+//     of the two-pass fold, 0.130 against 0.120 ms at 256 Ki;
+//   from there the two-pass partitioned fold: 0.17 against 0.24 ms at 512 Ki, 0.26 against 0.41 ms at 1 Mi, 0.70 against 1.29 ms at
+//     4 Mi (partitions scaled to the batch and a cheaper flush moved the crossover from 768 Ki to ~300 Ki this round).
 constexpr uint64_t kDirectMaxBatch = 6144;
 constexpr uint64_t kPartMinBatch = 3u << 17;   // 384 Ki (round 3: 0.114 against 0.128 ms at 256 Ki, 0.18 against 0.23 at 512 Ki)
 constexpr uint64_t kDedupCachedMinBatch = 1u << 16;
