@@ -119,6 +119,11 @@ struct nfagg_handle {
     void* h_ep = nullptr;           // pinned: control block, then the epoch ends
     size_t h_ep_cap = 0;
     uint64_t ep_phase[8] = {};      // diagnostics: accumulated phase ticks of the epoch kernel
+    // device -> pageable host memory through two pinned bounce buffers (d2h_copy): a plain hipMemcpy to pageable memory runs at
+    // ~13 GB/s here, this at the PCIe rate
+    void* h_bounce[2] = {nullptr, nullptr};
+    hipStream_t d2h_stream = nullptr;
+    hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     hipGraphExec_t ep_graph = nullptr;   // kChainBatch windows of the epoch kernel chain, captured once (their arguments never change)
     void* ep_graph_key[3] = {};          // the buffers the captured launches point at: re-capture when one was re-allocated
     nfagg_stats stats{};
@@ -706,6 +711,8 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->h_careful) hipHostFree(h->h_careful);
     if (h->h_exp) hipHostFree(h->h_exp);
     if (h->d_exp) hipFree(h->d_exp);
+    for (int b = 0; b < 2; b++) { if (h->h_bounce[b]) hipHostFree(h->h_bounce[b]); if (h->bounce_ev[b]) hipEventDestroy(h->bounce_ev[b]); }
+    if (h->d2h_stream) hipStreamDestroy(h->d2h_stream);
     if (h->ep_graph) hipGraphExecDestroy(h->ep_graph);
     if (h->h_ep) hipHostFree(h->h_ep);
     if (h->d_ep_out) hipFree(h->d_ep_out);
@@ -748,6 +755,36 @@ static void staged_copy(void* dst, const void* src, size_t bytes, unsigned threa
     }
     memcpy(dst, src, per < bytes ? per : bytes);
     for (unsigned t = 0; t < started; t++) th[t].join();
+}
+
+// Device -> caller buffer (pageable). The data must be complete on the device (the caller synchronised the producing stream).
+// Chunks go down into two pinned bounce buffers in turn on a stream of their own; while chunk k travels, chunk k-1 is copied
+// out of its bounce buffer by cfg.copy_threads threads — the mirror image of the H2D staging ring.
+constexpr size_t kBounceBytes = 16u << 20;
+static int d2h_copy(nfagg_handle* h, void* dst, const void* d_src, size_t bytes) {
+    if (bytes == 0) return NFAGG_OK;
+    if (bytes < (4u << 20)) { HIP_TRY(h, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost)); return NFAGG_OK; }
+    if (!h->d2h_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIP_TRY(h, hipHostMalloc(&h->h_bounce[b], kBounceBytes, hipHostMallocDefault));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->bounce_ev[b], hipEventDisableTiming));
+        }
+    }
+    const size_t n_chunks = (bytes + kBounceBytes - 1) / kBounceBytes;
+    for (size_t k = 0; k <= n_chunks; k++) {
+        if (k < n_chunks) {
+            const size_t off = k * kBounceBytes, len = bytes - off < kBounceBytes ? bytes - off : kBounceBytes;
+            HIP_TRY(h, hipMemcpyAsync(h->h_bounce[k & 1], (const char*)d_src + off, len, hipMemcpyDeviceToHost, h->d2h_stream));
+            HIP_TRY(h, hipEventRecord(h->bounce_ev[k & 1], h->d2h_stream));
+        }
+        if (k > 0) {
+            const size_t off = (k - 1) * kBounceBytes, len = bytes - off < kBounceBytes ? bytes - off : kBounceBytes;
+            HIP_TRY(h, hipEventSynchronize(h->bounce_ev[(k - 1) & 1]));
+            staged_copy((char*)dst + off, h->h_bounce[(k - 1) & 1], len, h->cfg.copy_threads);
+        }
+    }
+    return NFAGG_OK;
 }
 
 // How much of a host buffer goes up in one piece. A stream that keeps stopping on "full" (small CACHE_MAX_FLOWS: the reference's
@@ -907,9 +944,8 @@ static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "evict launch failed: %s", hipGetErrorString(e));
     // counters and (host variant) the records come back in stream order behind the kernel: one wait for both
     HIP_TRY(h, hipMemcpyAsync(h->h_ctr, h->tv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
-    if (!out_is_device && legit)
-        HIP_TRY(h, hipMemcpyAsync(out, h->d_evict, (size_t)legit * kRecordBytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!out_is_device && legit && (rc = d2h_copy(h, out, h->d_evict, (size_t)legit * kRecordBytes)) != NFAGG_OK) return rc;
     h->mirror_fresh = true;
     if (h->h_ctr->error)
         return fail(h, NFAGG_EDEVICE, "flow table kernel bailed out (code %u: 1 = probe overflow / table too small, 2 = claim spin limit, 5 = spill overflow list full, 6 = claimed slot without a record, 7 = partial of another shard merged)", h->h_ctr->error);
@@ -1321,9 +1357,10 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
     // in turn; a chunk of m records delivers at most m + max_entries flows.
     struct { bool has = false; const void* d = nullptr; size_t got = 0, at = 0; } prev;
     auto bring_down = [&]() -> int {
-        if (prev.has && prev.got) HIP_TRY(h, hipMemcpy((char*)out + prev.at * kRecordBytes, prev.d, prev.got * kRecordBytes, hipMemcpyDeviceToHost));
+        int rd = NFAGG_OK;
+        if (prev.has && prev.got) rd = d2h_copy(h, (char*)out + prev.at * kRecordBytes, prev.d, prev.got * kRecordBytes);
         prev.has = false;
-        return NFAGG_OK;
+        return rd;
     };
     int ebuf = 0;
     while (rc == NFAGG_OK && consumed < n) {
