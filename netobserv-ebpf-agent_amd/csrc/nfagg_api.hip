@@ -201,6 +201,13 @@ int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t 
             h->tv.spill.ovf_cap = (uint32_t)((h->d_spill_cap - qbytes) / sizeof(uint32_t) > 0xfffffff0ull ? 0xfffffff0ull
                                              : ((h->d_spill_cap - qbytes) / sizeof(uint32_t)) & ~3ull);
         }
+        if (h->cfg.mode == NFAGG_MODE_KERNEL_DEDUP && !h->tv.spill.xp) {     // exported cache entries of the streaming pass (19 MB)
+            size_t cap = 0;
+            void* p = nullptr;
+            int rc = ensure_bytes(h, &p, &cap, (size_t)kDedupXpBytes);
+            if (rc != NFAGG_OK) return rc;
+            h->tv.spill.xp = (uint4*)p;
+        }
     }
     if (prof) { if (h->ev_pending.size() >= 8192) prof_resolve(h); prof_begin(h, ep, 0); }
     const uint64_t rel = seq_base - h->seq_origin;              // what the slots' 32-bit tags carry (callers keep rel + n inside the window)
@@ -692,6 +699,7 @@ void nfagg_destroy(nfagg_handle* h) {
     for (int k = 0; k < 3; k++) if (h->d_roll[k]) hipFree(h->d_roll[k]);
     if (h->d_hist) hipFree(h->d_hist);
     if (h->d_spill) hipFree(h->d_spill);
+    if (h->tv.spill.xp) hipFree(h->tv.spill.xp);
     for (int k = 0; k < 4; k++) if (h->d_opt[k]) hipFree(h->d_opt[k]);
     for (int k = 0; k < 15; k++) if (h->d_pb[k]) hipFree(h->d_pb[k]);
     for (int k = 0; k < 2; k++) if (h->d_sort[k]) hipFree(h->d_sort[k]);

@@ -107,7 +107,10 @@ NF_DEV void dedup_partial_from_record(const Rec& r, uint32_t seq32, DedupPartial
     p.ifx = r.d[21];
 }
 
-// update_existing_flow (flows.c:98-143) for a partial; x.id0 (exact: pass 1 is a previous kernel) gives F.
+// update_existing_flow (flows.c:98-143) for a partial; x.id0 (exact: every claim of the flow is done) gives F.
+// COHERENT: the claims were made earlier in THIS kernel (by the caller's workgroup, a barrier since): the candidate list is read
+// past the caches. Otherwise the claim pass is a previous kernel and plain loads see it.
+template <bool COHERENT = false>
 NF_DEV void dedup_merge(const TableView& t, uint32_t idx, const Hints& x, const DedupPartial& p) {
     SlotHot* H = &t.hot[idx];
     SlotAux* A = &t.aux[idx];
@@ -135,7 +138,7 @@ NF_DEV void dedup_merge(const TableView& t, uint32_t idx, const Hints& x, const 
         // side records: remember the two earliest distinct directions of their interface
         int pos = -1;
 #pragma unroll
-        for (int k = 0; k < kCand; k++) { const uint64_t c = A->cand[k]; if (c != 0 && (uint32_t)c == p.ifx) pos = k; }
+        for (int k = 0; k < kCand; k++) { const uint64_t c = COHERENT ? ald(&A->cand[k]) : A->cand[k]; if (c != 0 && (uint32_t)c == p.ifx) pos = k; }
         if (pos >= 0) {
             uint64_t* dw = A->dir[pos];
             const uint64_t d0 = dw[0], d1 = dw[1];               // stale copies are lower bounds per direction

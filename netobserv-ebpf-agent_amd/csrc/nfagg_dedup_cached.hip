@@ -1,23 +1,24 @@
-// nfagg_dedup_cached.hip — kernel-dedup mode with persistent LDS caches (default for
-// NFAGG_MODE_KERNEL_DEDUP; the direct kernels of nfagg_dedup.hip serve small batches).
+// nfagg_dedup_cached.hip — kernel-dedup mode, ONE streaming pass over the batch (default for NFAGG_MODE_KERNEL_DEDUP; the direct
+// kernels of nfagg_dedup.hip serve small batches).
 //
-// The direct passes touch the table once per record: on a hot flow (BASELINE configs[4]:
-// 90 % of the records are one flow seen on two interfaces) every record's atomics hit one
-// slot and serialise. Here each workgroup keeps a cache keyed by the SUB-FLOW
-// (flow key, if_index_first_seen) for its whole lifetime:
-//   pass 1  k_dedup_claim_cached : an entry only tracks the smallest sequence number of
-//           its sub-flow; the flush does the table work (claim, first record, earliest
-//           interfaces) once per entry.
-//   pass 2  k_dedup_fold_cached  : an entry is a DedupPartial (nfagg_dedup.h) — sums, ORs,
-//           "last value" tags and the two earliest distinct directions, folded with LDS
-//           atomics; whether the sub-flow is the counted one (if_index == F) or a side
-//           interface is decided at the flush, when the slot's first record is known.
-// Records whose sub-flow gets no entry are SPILLED to the queue of their flow's partition and folded by a second,
-// per-partition launch of the same kernel (QUEUE == true), exactly as in accounter mode (nfagg_ingest_part.hip); only
-// what finds no entry even there (probe window full) is merged record by record.
-// Merging DedupPartials is associative and commutative (everything is a sum, an OR, a
-// max over sequence-tagged words, or a top-2 over sequence-tagged words), so the result is
-// the same as the direct passes': bit-exact vs the oracle's sequential fold.
+// The merge of bpf/flows.c:98-143 needs the flow's first interface F before a record can be counted, and F is the interface of
+// the record with the smallest sequence number anywhere in the batch. Rounds 1-2 therefore streamed the batch twice (a claim pass
+// resolving F for every flow, then a fold pass): 2 x 14.4 GB per 100 M records. Here nothing that depends on F happens while the
+// batch is streamed:
+//   k_dedup_stream  streams the batch once. A workgroup folds the SUB-FLOWS (flow key, if_index_first_seen) it has LDS cache
+//                   entries for — an entry is a DedupPartial (nfagg_dedup.h: sums, ORs, "last value" tags, the two earliest
+//                   directions) plus the smallest sequence number of its records, everything kept for both roles (counted / side
+//                   interface). A record whose sub-flow gets no entry is spilled by index to the queue of its FLOW's partition
+//                   (nfagg_spill.h). At the end the entries themselves are exported (144 bytes each, the size of a record) and
+//                   queued the same way. The table is not touched.
+//   k_dedup_parts   one workgroup per partition, owner of the partition's flows: folds the queued records and exported entries
+//                   in its own sub-flow cache, then flushes in two phases with a barrier between them — phase A claims the slot and
+//                   resolves first record and earliest interfaces (dedup_claim) for EVERY sub-flow of the partition, phase B
+//                   merges the partials (dedup_merge), F now being final. What finds no cache entry is claimed at once and
+//                   retried in further rounds (in place, as in nfagg_ingest_part.hip).
+//   k_dedup_overflow  the (normally empty) overflow list: claims before k_dedup_parts, folds after it.
+// Merging DedupPartials is associative and commutative (sums, ORs, maxima over sequence-tagged words, top-2 over sequence-tagged
+// words), so the result is that of the direct passes: bit-exact vs the oracle's sequential fold.
 #include "nfagg_dedup.h"
 #include "nfagg_spill.h"
 
@@ -26,19 +27,13 @@ namespace dcache {
 
 constexpr int kBlock = 1024;
 constexpr int kProbe = 8;
+constexpr uint32_t kPad = 0xffffffffu;
+constexpr uint32_t kXpFlag = 0x80000000u;       // queue item: index of an exported entry, not of a record (batches hold < 2^31 records)
 
 NF_DEV uint64_t subflow_hash(uint64_t h, uint32_t ifx) {
     uint64_t z = (h ^ ((uint64_t)ifx * 0xD6E8FEB86659FD93ull)) * kMul;
     return (z ^ (z >> 32)) | 1ull;
 }
-
-template <int K>
-struct ClaimCache {
-    uint64_t h64[K];
-    uint64_t key[5][K];
-    uint32_t ifx[K];
-    uint32_t min_seq[K];
-};
 
 template <int K>
 struct FoldCache {
@@ -57,13 +52,21 @@ struct FoldCache {
     uint32_t min_seq[K];
 };
 
-// find or claim the entry of sub-flow hash hs; the creator writes key and interface. -1 = window full, or the
-// sub-flow is seen for the first time: entries are never evicted, so a sub-flow is admitted on its second
-// appearance (admission filter `door`, DOORBITS bits of LDS, as in nfagg_ingest_part.hip) — one-off sub-flows of
-// the cold tail do not take the entries of the hot ones. Exactly one of the lanes that meet a new sub-flow in
-// the same tile is turned away (the atomic's return value decides).
-template <typename Cache, int K, int DOORBITS>
-NF_DEV int claim(Cache& L, uint32_t* door, uint64_t hs, const uint64_t w[5], uint32_t ifx) {
+template <int K>
+NF_DEV void cache_init(FoldCache<K>& L, int tid) {
+    for (int e = tid; e < K; e += kBlock) {
+        L.h64[e] = 0; L.bytes[e] = 0; L.endl_lo[e] = 0; L.endl_hi[e] = 0; L.dscp_tag[e] = 0; L.samp_tag[e] = 0;
+        L.ssl_first[e] = 0; L.cs_tag[e] = 0; L.ks_tag[e] = 0; L.dir[0][e] = 0; L.dir[1][e] = 0;
+        L.packets[e] = 0; L.flags[e] = 0; L.ssl_max[e] = 0; L.ssl_minv[e] = 0; L.min_seq[e] = 0xffffffffu;
+    }
+}
+
+// find or claim the entry of sub-flow hash hs; the creator writes key and interface. -1 = window full, or (DOORBITS > 0) the
+// sub-flow is seen for the first time: entries are never evicted, so a sub-flow is admitted on its second appearance (admission
+// filter `door`, as in nfagg_ingest_part.hip) — one-off sub-flows of the cold tail do not take the entries of the hot ones.
+// Exactly one of the lanes that meet a new sub-flow in the same tile is turned away (the atomic's return value decides).
+template <int K, int DOORBITS>
+NF_DEV int claim(FoldCache<K>& L, uint32_t* door, uint64_t hs, const uint64_t w[5], uint32_t ifx) {
     uint32_t e = (uint32_t)(hs >> 40) & (K - 1);
 #pragma unroll 1
     for (int p = 0; p < kProbe; p++) {
@@ -87,8 +90,8 @@ NF_DEV int claim(Cache& L, uint32_t* door, uint64_t hs, const uint64_t w[5], uin
     return -1;
 }
 
-template <typename Cache>
-NF_DEV bool same_subflow(const Cache& L, int ent, const uint64_t w[5], uint32_t ifx) {
+template <int K>
+NF_DEV bool same_subflow(const FoldCache<K>& L, int ent, const uint64_t w[5], uint32_t ifx) {
     bool same = L.ifx[ent] == ifx;
 #pragma unroll
     for (int k = 0; k < 5; k++) same &= (L.key[k][ent] == w[k]);
@@ -108,281 +111,389 @@ NF_DEV void lds_dir_insert(FoldCache<K>& L, int ent, uint64_t v) {
     }
 }
 
-constexpr int kClaimEntries = 2048;
-constexpr int kFoldEntries = 1024;
-constexpr int kClaimDoorBits = 65536, kFoldDoorBits = 32768;   // 8 KiB / 4 KiB of LDS behind the caches
-
-// Tile source of both passes. QUEUE == false: pass 1, tiles of consecutive records, grid-strided. QUEUE == true: pass 2,
-// workgroup b walks the record indices pass 1 queued for partition b (0xffffffff = padding of a partial group).
-template <bool QUEUE>
-struct Tiles {
-    uint64_t count, n_tiles, tile0, step;
-    const uint32_t* queue;
-    NF_DEV bool setup(const SpillView& q, uint64_t n) {
-        if (QUEUE) {
-            const uint32_t tail = q.qtail[blockIdx.x];            // written by pass 1 (previous kernel)
-            count = tail < q.qcap ? tail : q.qcap;
-            queue = q.queue + (uint64_t)blockIdx.x * q.qcap;
-            tile0 = 0; step = 1;
-        } else {
-            count = n; queue = nullptr; tile0 = blockIdx.x; step = gridDim.x;
-        }
-        n_tiles = (count + kBlock - 1) / kBlock;
-        return count != 0;
+// a partial (one record, or an exported entry) into the entry of its sub-flow; ms = smallest sequence number it stands for
+template <int K>
+NF_DEV void fold_into(FoldCache<K>& L, int e, const DedupPartial& p, uint32_t ms) {
+    if (p.bytes) atomicAdd((unsigned long long*)&L.bytes[e], (unsigned long long)p.bytes);
+    if (p.packets) atomicAdd(&L.packets[e], p.packets);
+    if (p.flags & ~L.flags[e]) atomicOr(&L.flags[e], p.flags);
+    if (p.endl_lo > L.endl_lo[e]) atomicMax((unsigned long long*)&L.endl_lo[e], (unsigned long long)p.endl_lo);
+    if (p.endl_hi > L.endl_hi[e]) atomicMax((unsigned long long*)&L.endl_hi[e], (unsigned long long)p.endl_hi);
+    if (p.dscp_tag > L.dscp_tag[e]) atomicMax((unsigned long long*)&L.dscp_tag[e], (unsigned long long)p.dscp_tag);
+    if (p.samp_tag > L.samp_tag[e]) atomicMax((unsigned long long*)&L.samp_tag[e], (unsigned long long)p.samp_tag);
+    if (p.ssl_first) {
+        atomicMax((unsigned long long*)&L.ssl_first[e], (unsigned long long)p.ssl_first);
+        atomicMax(&L.ssl_max[e], p.ssl_max);
+        atomicMax(&L.ssl_minv[e], p.ssl_minv);
     }
-    // record index of this lane in `tile` (valid == false: nothing to do)
-    NF_DEV uint64_t index(uint64_t tile, int tid, bool& valid) const {
-        const uint64_t pos = tile * kBlock + tid;
-        valid = pos < count;
-        if (!QUEUE) return valid ? pos : 0;
-        const uint32_t qi = valid ? queue[pos] : 0xffffffffu;
-        valid = qi != 0xffffffffu;
-        return valid ? qi : 0;
-    }
-};
-
-// ---- pass 1 of the dedup merge (first record + earliest interfaces), LDS-cached; misses are spilled (QUEUE == false)
-// or, in the partition pass, claimed record by record (probe window full: rare)
-template <bool QUEUE>
-__global__ __launch_bounds__(kBlock) void k_dedup_claim_cached(TableView t, SpillView q, const void* __restrict__ recs, uint64_t n, uint64_t seq_base) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    ClaimCache<kClaimEntries>& L = *reinterpret_cast<ClaimCache<kClaimEntries>*>(lds_raw);
-    spill::Stage& S = *reinterpret_cast<spill::Stage*>(lds_raw + sizeof(ClaimCache<kClaimEntries>));                    // pass 1 only
-    uint32_t* door = reinterpret_cast<uint32_t*>(lds_raw + sizeof(ClaimCache<kClaimEntries>) + sizeof(spill::Stage));   // pass 1 only
-    const int tid = threadIdx.x;
-    Tiles<QUEUE> T;
-    if (!T.setup(q, n)) return;                                   // uniform for the workgroup
-    for (int e = tid; e < kClaimEntries; e += kBlock) { L.h64[e] = 0; L.min_seq[e] = 0xffffffffu; }
-    spill::Lane<kBlock> sp;
-    if (!QUEUE) {
-        for (int e = tid; e < kClaimDoorBits / 32; e += kBlock) door[e] = 0;
-        sp.init(S, tid);
-    }
-    __syncthreads();
-    if (QUEUE && tid == 0) q.qtail[blockIdx.x] = 0;               // every lane has read it: ready for the fold pass
-    unsigned long long skipped = 0, spilled = 0;
-    // software pipeline: the next tile's record is requested (unconditionally, on a clamped index) before this one is processed
-    bool valid;
-    uint64_t i = T.index(T.tile0, tid, valid);
-    Rec r;
-    load_record(recs, i, r);
-    for (uint64_t tile = T.tile0; tile < T.n_tiles; tile += T.step) {
-        bool valid_n = false;
-        uint64_t i_n = 0;
-        if (tile + T.step < T.n_tiles) i_n = T.index(tile + T.step, tid, valid_n);
-        Rec r_n;
-        load_record(recs, i_n, r_n);
-        uint64_t w[5], h = 0;
-        if (valid && !record_keys(t, r, w, h)) { valid = false; skipped++; }
-        const uint32_t seq32 = (uint32_t)(seq_base + i);
-        const uint32_t ifx = valid ? r.d[21] : 0;
-        int ent0 = -1;
-        if (valid) ent0 = QUEUE ? claim<ClaimCache<kClaimEntries>, kClaimEntries, 0>(L, nullptr, subflow_hash(h, ifx), w, ifx)
-                                : claim<ClaimCache<kClaimEntries>, kClaimEntries, kClaimDoorBits>(L, door, subflow_hash(h, ifx), w, ifx);
-        __syncthreads();
-        bool miss = false;
-        if (valid) {
-            if (ent0 >= 0 && same_subflow(L, ent0, w, ifx)) {
-                if (L.min_seq[ent0] > seq32) atomicMin(&L.min_seq[ent0], seq32);
-            } else if (QUEUE) {
-                dedup_claim_record(t, r, w, h, seq32);          // no entry even in the partition's cache
-            } else {
-                miss = true;
-            }
-        }
-        if (!QUEUE) {
-            sp.drain(S, q, tid);
-            __syncthreads();
-            if (miss) spilled++;
-            sp.append(S, q, miss, spill::part_of(h, q.part_shift), (uint32_t)i);
-        }
-        // the next tile's claims only write h64/key/ifx of NEW entries; min_seq reads/updates are ordered by its barrier
-        r = r_n; valid = valid_n; i = i_n;
-    }
-    if (!QUEUE) sp.finish(S, q, tid); else __syncthreads();
-    for (int e = tid; e < kClaimEntries; e += kBlock) {
-        if (L.h64[e] == 0 || L.min_seq[e] == 0xffffffffu) continue;
-        uint64_t w[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
-        const uint64_t h = key_hash(w);
-        Hints x;
-        uint32_t idx = probe_home(t, w, h, x);
-        if (idx == kNoSlot) {
-            idx = find_or_claim(t, w, h);
-            if (idx == kNoSlot) continue;
-            x.id0 = 0;
-        }
-        dedup_claim(t, idx, x.id0, L.ifx[e], L.min_seq[e]);
-    }
-    if (skipped) aadd(&t.ctr->n_skipped, skipped);
-    (void)spilled;                                                // the fold pass reports the bypass count (stats.records_bypassed)
+    if (p.cs_tag) atomicMax((unsigned long long*)&L.cs_tag[e], (unsigned long long)p.cs_tag);
+    if (p.ks_tag) atomicMax((unsigned long long*)&L.ks_tag[e], (unsigned long long)p.ks_tag);
+    if (p.dir0) lds_dir_insert(L, e, p.dir0);
+    if (p.dir1) lds_dir_insert(L, e, p.dir1);
+    if (L.min_seq[e] > ms) atomicMin(&L.min_seq[e], ms);
 }
 
-// ---- pass 2 of the dedup merge (sums, tags, directions), LDS-cached with K entries; misses as above
-template <bool QUEUE, int K>
-__global__ __launch_bounds__(kBlock) void k_dedup_fold_cached(TableView t, SpillView q, const void* __restrict__ recs, uint64_t n, uint64_t seq_base) {
+template <int K>
+NF_DEV void partial_of_entry(const FoldCache<K>& L, int e, DedupPartial& p) {
+    p.bytes = L.bytes[e]; p.packets = L.packets[e]; p.flags = L.flags[e];
+    p.endl_lo = L.endl_lo[e]; p.endl_hi = L.endl_hi[e]; p.dscp_tag = L.dscp_tag[e]; p.samp_tag = L.samp_tag[e];
+    p.ssl_first = L.ssl_first[e]; p.ssl_max = L.ssl_max[e]; p.ssl_minv = L.ssl_minv[e];
+    p.cs_tag = L.cs_tag[e]; p.ks_tag = L.ks_tag[e];
+    p.dir0 = L.dir[0][e]; p.dir1 = L.dir[1][e];
+    p.ifx = L.ifx[e];
+}
+
+// ---- an exported entry: 36 dwords, the size of a record (one load path for both kinds of queue item)
+//   0..9 key   10 if_index   11 min_seq   12,13 bytes   14 packets   15 flags | tls_types << 16   16..19 endl_lo, endl_hi
+//   20..23 dscp_tag, samp_tag   24,25 ssl_first   26 ssl_max   27 ssl_minv   28..31 cs_tag, ks_tag   32..35 dir0, dir1
+NF_DEV uint4 u4(uint64_t a, uint64_t b) { return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)); }
+
+template <int K>
+NF_DEV void export_entry(const FoldCache<K>& L, int e, uint4* dst) {
+    dst[0] = u4(L.key[0][e], L.key[1][e]);
+    dst[1] = u4(L.key[2][e], L.key[3][e]);
+    dst[2] = u4(L.key[4][e], (uint64_t)L.ifx[e] | ((uint64_t)L.min_seq[e] << 32));
+    dst[3] = u4(L.bytes[e], (uint64_t)L.packets[e] | ((uint64_t)L.flags[e] << 32));
+    dst[4] = u4(L.endl_lo[e], L.endl_hi[e]);
+    dst[5] = u4(L.dscp_tag[e], L.samp_tag[e]);
+    dst[6] = u4(L.ssl_first[e], (uint64_t)L.ssl_max[e] | ((uint64_t)L.ssl_minv[e] << 32));
+    dst[7] = u4(L.cs_tag[e], L.ks_tag[e]);
+    dst[8] = u4(L.dir[0][e], L.dir[1][e]);
+}
+
+// One queue item in registers: its flow key, interface, smallest sequence number and partial. `raw` holds the 144 bytes the
+// item names: a record of the batch (canonicalised here) or an exported entry.
+struct Item {
+    uint64_t w[5];
+    uint64_t h;                 // flow key hash
+    uint32_t ifx, ms;
+    DedupPartial p;
+};
+
+NF_DEV void decode_item(uint32_t it, Rec& raw, uint32_t seq_base32, Item& x) {
+    if (it & kXpFlag) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) x.w[k] = raw.q(k);
+        x.ifx = raw.d[10]; x.ms = raw.d[11];
+        DedupPartial& p = x.p;
+        p.bytes = raw.q(6); p.packets = raw.d[14]; p.flags = raw.d[15];
+        p.endl_lo = raw.q(8); p.endl_hi = raw.q(9); p.dscp_tag = raw.q(10); p.samp_tag = raw.q(11);
+        p.ssl_first = raw.q(12); p.ssl_max = raw.d[26]; p.ssl_minv = raw.d[27];
+        p.cs_tag = raw.q(14); p.ks_tag = raw.q(15); p.dir0 = raw.q(16); p.dir1 = raw.q(17);
+        p.ifx = x.ifx;
+    } else {
+        raw.canonicalize();
+        raw.key_words(x.w);
+        x.ifx = raw.d[21];
+        x.ms = seq_base32 + it;
+        dedup_partial_from_record(raw, x.ms, x.p);
+    }
+    x.h = key_hash(x.w);
+}
+
+NF_DEV void load_item(const SpillView& q, const void* recs, uint32_t it, Rec& raw) {
+    // padding loads record 0 (the batch is not empty): the pipeline requests unconditionally
+    const void* base = (it != kPad && (it & kXpFlag)) ? (const void*)q.xp : recs;
+    const uint64_t i = it == kPad ? 0 : (uint64_t)(it & ~kXpFlag);
+    load_record(base, i, raw);
+}
+
+// ---- straight on the table, for one item (cache misses, overflow list)
+NF_DEV void claim_item(const TableView& t, const Item& x) {
+    Hints hx;
+    uint32_t idx = probe_home(t, x.w, x.h, hx);
+    if (idx == kNoSlot) {
+        idx = find_or_claim(t, x.w, x.h);
+        if (idx == kNoSlot) return;
+        hx.id0 = 0;
+    }
+    dedup_claim(t, idx, hx.id0, x.ifx, x.ms);
+}
+
+// every claim of the flow is done (by this workgroup, or an earlier kernel): the slot's id0 is final — read it past the caches
+NF_DEV void merge_at(const TableView& t, uint32_t idx, const DedupPartial& p, uint32_t ms, const void* recs, uint32_t seq_base32) {
+    Hints hx;
+    hx.flags = 0;
+    hx.id0 = ald(&t.hot[idx].id0);
+    if ((uint32_t)(hx.id0 >> 32) == ~ms) {
+        // this sub-flow's earliest record is the flow's first record: fetch it again and store it whole
+        Rec r;
+        load_record(recs, (uint64_t)(ms - seq_base32), r);
+        r.canonicalize();
+        dedup_publish_first(t, idx, r, ms);
+    }
+    dedup_merge<true>(t, idx, hx, p);
+}
+
+NF_DEV void fold_item(const TableView& t, const Item& x, const void* recs, uint32_t seq_base32) {
+    Hints hx;
+    uint32_t idx = probe_home(t, x.w, x.h, hx);
+    if (idx == kNoSlot) {
+        idx = find_or_claim(t, x.w, x.h);          // claimed before: this only walks the probe sequence
+        if (idx == kNoSlot) return;
+    }
+    merge_at(t, idx, x.p, x.ms, recs, seq_base32);
+}
+
+constexpr int kStreamEntries = 512;             // the streaming pass shares the LDS with the spill staging (40 KiB) and the filter
+constexpr int kPartEntries = 1024;
+constexpr int kDoorBits = 32768;                // 4 KiB
+constexpr int kStreamGrid = 256;
+static_assert((uint64_t)kStreamGrid * kStreamEntries == kDedupXpEntries, "exported-entry area (nfagg_internal.h)");
+static_assert(kStreamEntries <= kBlock && kPartEntries == kBlock, "one cache entry per lane in the export / flush");
+
+// ---- the streaming pass ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_dedup_stream(TableView t, SpillView q, const void* __restrict__ recs, uint64_t n, uint64_t seq_base) {
+    constexpr int K = kStreamEntries;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     FoldCache<K>& L = *reinterpret_cast<FoldCache<K>*>(lds_raw);
-    spill::Stage& S = *reinterpret_cast<spill::Stage*>(lds_raw + sizeof(FoldCache<K>));                    // pass 1 only
-    uint32_t* door = reinterpret_cast<uint32_t*>(lds_raw + sizeof(FoldCache<K>) + sizeof(spill::Stage));   // pass 1 only
+    spill::Stage& S = *reinterpret_cast<spill::Stage*>(lds_raw + sizeof(FoldCache<K>));
+    uint32_t* door = reinterpret_cast<uint32_t*>(lds_raw + sizeof(FoldCache<K>) + sizeof(spill::Stage));
     const int tid = threadIdx.x;
-    Tiles<QUEUE> T;
-    if (!T.setup(q, n)) return;
-    for (int e = tid; e < K; e += kBlock) {
-        L.h64[e] = 0; L.bytes[e] = 0; L.endl_lo[e] = 0; L.endl_hi[e] = 0; L.dscp_tag[e] = 0; L.samp_tag[e] = 0;
-        L.ssl_first[e] = 0; L.cs_tag[e] = 0; L.ks_tag[e] = 0; L.dir[0][e] = 0; L.dir[1][e] = 0;
-        L.packets[e] = 0; L.flags[e] = 0; L.ssl_max[e] = 0; L.ssl_minv[e] = 0; L.min_seq[e] = 0xffffffffu;
-    }
+    const uint32_t seq_base32 = (uint32_t)seq_base;
+    cache_init(L, tid);
+    for (int e = tid; e < kDoorBits / 32; e += kBlock) door[e] = 0;
     spill::Lane<kBlock> sp;
-    if (!QUEUE) {
-        for (int e = tid; e < kFoldDoorBits / 32; e += kBlock) door[e] = 0;
-        sp.init(S, tid);
-    }
+    sp.init(S, tid);
     __syncthreads();
-    if (QUEUE && tid == 0) q.qtail[blockIdx.x] = 0;
-    unsigned long long spilled = 0;
-    bool valid;
-    uint64_t i = T.index(T.tile0, tid, valid);
-    Rec r;
-    load_record(recs, i, r);
-    for (uint64_t tile = T.tile0; tile < T.n_tiles; tile += T.step) {
-        bool valid_n = false;
-        uint64_t i_n = 0;
-        if (tile + T.step < T.n_tiles) i_n = T.index(tile + T.step, tid, valid_n);
-        Rec r_n;
-        load_record(recs, i_n, r_n);
+    unsigned long long skipped = 0, spilled = 0;
+    const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
+    // software pipeline: the next tile's record is requested (unconditionally, on a clamped index) before this one is processed
+    bool valid; uint64_t i; Rec r;
+    {
+        const uint64_t pos = (uint64_t)blockIdx.x * kBlock + tid;
+        valid = pos < n; i = valid ? pos : 0;
+        load_record(recs, i, r);
+    }
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        bool valid_n; uint64_t i_n; Rec r_n;
+        {
+            const uint64_t pos = (tile + gridDim.x) * kBlock + tid;
+            valid_n = pos < n; i_n = valid_n ? pos : 0;
+            load_record(recs, i_n, r_n);
+        }
         uint64_t w[5], h = 0;
-        if (valid && !record_keys(t, r, w, h)) valid = false;
-        const uint32_t seq32 = (uint32_t)(seq_base + i);
+        if (valid && !record_keys(t, r, w, h)) { valid = false; skipped++; }
+        const uint32_t seq32 = seq_base32 + (uint32_t)i;
         const uint32_t ifx = valid ? r.d[21] : 0;
-        int ent0 = -1;
-        if (valid) ent0 = QUEUE ? claim<FoldCache<K>, K, 0>(L, nullptr, subflow_hash(h, ifx), w, ifx)
-                                : claim<FoldCache<K>, K, kFoldDoorBits>(L, door, subflow_hash(h, ifx), w, ifx);
+        int ent = -1;
+        if (valid) ent = claim<K, kDoorBits>(L, door, subflow_hash(h, ifx), w, ifx);
         __syncthreads();
         bool miss = false;
         if (valid) {
-            if (ent0 >= 0 && same_subflow(L, ent0, w, ifx)) {
-                const int e = ent0;
+            if (ent >= 0 && same_subflow(L, ent, w, ifx)) {
                 DedupPartial p;
                 dedup_partial_from_record(r, seq32, p);
-                if (p.bytes) atomicAdd((unsigned long long*)&L.bytes[e], (unsigned long long)p.bytes);
-                if (p.packets) atomicAdd(&L.packets[e], p.packets);
-                if (p.flags & ~L.flags[e]) atomicOr(&L.flags[e], p.flags);
-                if (p.endl_lo > L.endl_lo[e]) atomicMax((unsigned long long*)&L.endl_lo[e], (unsigned long long)p.endl_lo);
-                if (p.endl_hi > L.endl_hi[e]) atomicMax((unsigned long long*)&L.endl_hi[e], (unsigned long long)p.endl_hi);
-                if (p.dscp_tag > L.dscp_tag[e]) atomicMax((unsigned long long*)&L.dscp_tag[e], (unsigned long long)p.dscp_tag);
-                if (p.samp_tag > L.samp_tag[e]) atomicMax((unsigned long long*)&L.samp_tag[e], (unsigned long long)p.samp_tag);
-                if (p.ssl_first) {
-                    atomicMax((unsigned long long*)&L.ssl_first[e], (unsigned long long)p.ssl_first);
-                    atomicMax(&L.ssl_max[e], p.ssl_max);
-                    atomicMax(&L.ssl_minv[e], p.ssl_minv);
-                }
-                if (p.cs_tag) atomicMax((unsigned long long*)&L.cs_tag[e], (unsigned long long)p.cs_tag);
-                if (p.ks_tag) atomicMax((unsigned long long*)&L.ks_tag[e], (unsigned long long)p.ks_tag);
-                lds_dir_insert(L, e, p.dir0);
-                if (L.min_seq[e] > seq32) atomicMin(&L.min_seq[e], seq32);
-            } else if (QUEUE) {
-                dedup_fold_record(t, r, w, h, seq32);            // no entry even in the partition's cache
+                fold_into(L, ent, p, seq32);
             } else {
                 miss = true;
             }
         }
-        if (!QUEUE) {
-            sp.drain(S, q, tid);
-            __syncthreads();
-            if (miss) spilled++;
-            sp.append(S, q, miss, spill::part_of(h, q.part_shift), (uint32_t)i);
-        }
+        sp.drain(S, q, tid);
+        __syncthreads();
+        if (miss) spilled++;
+        sp.append(S, q, miss, spill::part_of(h, q.part_shift), (uint32_t)i);
+        // the next tile's claims only write h64/key/ifx of NEW entries; everything else is ordered by its barrier
         r = r_n; valid = valid_n; i = i_n;
     }
-    if (!QUEUE) sp.finish(S, q, tid); else __syncthreads();
-    for (int e = tid; e < K; e += kBlock) {
-        if (L.h64[e] == 0 || L.min_seq[e] == 0xffffffffu) continue;
+    // ---- export: one more "tile" of the spill protocol, whose items are this workgroup's entries
+    __syncthreads();
+    bool used = false;
+    uint32_t item = 0, part = 0;
+    if (tid < K && L.h64[tid] != 0 && L.min_seq[tid] != 0xffffffffu) {
+        used = true;
+        const uint32_t at = (uint32_t)blockIdx.x * (uint32_t)K + (uint32_t)tid;
+        export_entry(L, tid, q.xp + (uint64_t)at * 9);
         uint64_t w[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
-        const uint64_t h = key_hash(w);
-        Hints x;
-        uint32_t idx = probe_home(t, w, h, x);
-        if (idx == kNoSlot) {
-            idx = find_or_claim(t, w, h);                        // pass 1 claimed it
-            if (idx == kNoSlot) continue;
-            load_hints(&t.hot[idx], x);
-        }
-        const uint32_t ms = L.min_seq[e];
-        if ((uint32_t)(x.id0 >> 32) == ~ms) {
-            // this sub-flow's earliest record is the flow's first record: fetch it again and store it whole
-            Rec r;
-            load_record(recs, (uint64_t)(ms - (uint32_t)seq_base), r);
-            r.canonicalize();
-            dedup_publish_first(t, idx, r, ms);
-        }
-        DedupPartial p;
-        p.bytes = L.bytes[e]; p.packets = L.packets[e]; p.flags = L.flags[e];
-        p.endl_lo = L.endl_lo[e]; p.endl_hi = L.endl_hi[e]; p.dscp_tag = L.dscp_tag[e]; p.samp_tag = L.samp_tag[e];
-        p.ssl_first = L.ssl_first[e]; p.ssl_max = L.ssl_max[e]; p.ssl_minv = L.ssl_minv[e];
-        p.cs_tag = L.cs_tag[e]; p.ks_tag = L.ks_tag[e];
-        p.dir0 = L.dir[0][e]; p.dir1 = L.dir[1][e];
-        p.ifx = L.ifx[e];
-        dedup_merge(t, idx, x, p);
+        for (int k = 0; k < 5; k++) w[k] = L.key[k][tid];
+        part = spill::part_of(key_hash(w), q.part_shift);
+        item = kXpFlag | at;
     }
+    sp.drain(S, q, tid);
+    __syncthreads();
+    sp.append(S, q, used, part, item);
+    sp.finish(S, q, tid);
+    if (skipped) aadd(&t.ctr->n_skipped, skipped);
     if (spilled) aadd(&t.ctr->n_bypassed, spilled);
 }
 
-// the (normally empty) overflow list of a pass: one record per lane, merged directly
+// ---- the partition pass ------------------------------------------------------------------------------------------------
+struct PartsLds { uint32_t retry_cnt, pad[3]; };
+
+// Fold the `count` items at `queue` into the cache. An item whose sub-flow gets no entry goes back to the front of the same
+// region (the write position never passes the read position: items are read two tiles ahead) and is retried in the next round
+// with a fresh cache; FIRST: its claim is made at once, so that after this round's flush every sub-flow of the partition has
+// been claimed. COHERENT: the items were written by this workgroup (read past L1).
+template <bool FIRST, bool COHERENT>
+NF_DEV void parts_round(const TableView& t, const SpillView& q, FoldCache<kPartEntries>& L, PartsLds& P, uint32_t* queue, uint32_t count,
+                        const void* recs, uint32_t seq_base32) {
+    constexpr int K = kPartEntries;
+    const int tid = threadIdx.x;
+    auto qload = [&](uint32_t pos) -> uint32_t { return COHERENT ? ald(&queue[pos]) : queue[pos]; };
+    const uint32_t n_tiles = (count + kBlock - 1) / kBlock;
+    uint32_t it_cur = kPad, it_next = kPad;
+    Rec raw;
+    {
+        const uint32_t pos = (uint32_t)tid;
+        if (pos < count) it_cur = qload(pos);
+        if (pos + kBlock < count) it_next = qload(pos + kBlock);
+        load_item(q, recs, it_cur, raw);
+    }
+    for (uint32_t tile = 0; tile < n_tiles; tile++) {
+        uint32_t it_nn = kPad;
+        Rec raw_n;
+        {
+            const uint64_t p2 = (uint64_t)(tile + 2) * kBlock + tid;
+            if (p2 < count) it_nn = qload((uint32_t)p2);
+            load_item(q, recs, it_next, raw_n);
+        }
+        const bool valid = it_cur != kPad;
+        Item x;
+        x.h = 0; x.ifx = 0; x.ms = 0;
+        int ent = -1;
+        if (valid) {
+            decode_item(it_cur, raw, seq_base32, x);
+            ent = claim<K, 0>(L, nullptr, subflow_hash(x.h, x.ifx), x.w, x.ifx);
+        }
+        __syncthreads();
+        if (valid) {
+            if (ent >= 0 && same_subflow(L, ent, x.w, x.ifx)) {
+                fold_into(L, ent, x.p, x.ms);
+            } else {
+                if (FIRST) claim_item(t, x);
+                queue[atomicAdd(&P.retry_cnt, 1u)] = it_cur;     // lands below (tile + 1) * kBlock
+            }
+        }
+        it_cur = it_next; it_next = it_nn;
+        raw = raw_n;
+    }
+    __syncthreads();
+}
+
+// Phase A: slot + first record + earliest interfaces for every entry. Barrier. Phase B: the merges (F is final: every sub-flow
+// of every flow of this partition has been claimed — by this flush, by parts_round<FIRST>, by the overflow kernel before this
+// launch, or in an earlier call).
+NF_DEV void parts_flush(const TableView& t, FoldCache<kPartEntries>& L, const void* recs, uint32_t seq_base32) {
+    const int e = threadIdx.x;
+    const bool used = L.h64[e] != 0 && L.min_seq[e] != 0xffffffffu;
+    uint32_t idx = kNoSlot;
+    if (used) {
+        uint64_t w[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
+        const uint64_t h = key_hash(w);
+        Hints hx;
+        idx = probe_home(t, w, h, hx);
+        if (idx == kNoSlot) {
+            idx = find_or_claim(t, w, h);
+            hx.id0 = 0;
+        }
+        if (idx != kNoSlot) dedup_claim(t, idx, hx.id0, L.ifx[e], L.min_seq[e]);
+    }
+    drain_stores();                                              // this lane's claims have reached the memory side
+    __syncthreads();
+    if (idx != kNoSlot) {
+        DedupPartial p;
+        partial_of_entry(L, e, p);
+        merge_at(t, idx, p, L.min_seq[e], recs, seq_base32);
+    }
+    __syncthreads();
+}
+
+constexpr int kMaxRounds = 16;
+
+__global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q, const void* __restrict__ recs, uint64_t n, uint64_t seq_base,
+                                                        int max_rounds) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    FoldCache<kPartEntries>& L = *reinterpret_cast<FoldCache<kPartEntries>*>(lds_raw);
+    PartsLds& P = *reinterpret_cast<PartsLds*>(lds_raw + sizeof(FoldCache<kPartEntries>));
+    const int tid = threadIdx.x;
+    const uint32_t seq_base32 = (uint32_t)seq_base;
+    const uint32_t tail = q.qtail[blockIdx.x];                    // written by the streaming pass (previous kernel)
+    uint32_t count = tail < q.qcap ? tail : q.qcap;
+    if (count == 0) return;                                       // uniform for the workgroup
+    uint32_t* my_queue = q.queue + (uint64_t)blockIdx.x * q.qcap;
+    cache_init(L, tid);
+    if (tid == 0) P.retry_cnt = 0;
+    __syncthreads();
+    if (tid == 0) q.qtail[blockIdx.x] = 0;                        // every lane has read it: ready for the next batch
+    parts_round<true, false>(t, q, L, P, my_queue, count, recs, seq_base32);
+    parts_flush(t, L, recs, seq_base32);
+    uint32_t m = P.retry_cnt;
+    for (int round = 1; m != 0; round++) {
+        drain_stores();
+        __syncthreads();                                          // everybody has read retry_cnt; the retry list is written
+        if (round >= max_rounds) {
+            // a partition with far more sub-flows than rounds x entries: what is left is merged item by item
+            for (uint32_t k = tid; k < m; k += kBlock) {
+                const uint32_t it = ald(&my_queue[k]);
+                Rec raw;
+                load_item(q, recs, it, raw);
+                Item x;
+                decode_item(it, raw, seq_base32, x);
+                fold_item(t, x, recs, seq_base32);
+            }
+            break;
+        }
+        cache_init(L, tid);
+        if (tid == 0) P.retry_cnt = 0;
+        __syncthreads();
+        parts_round<false, true>(t, q, L, P, my_queue, m, recs, seq_base32);
+        parts_flush(t, L, recs, seq_base32);
+        m = P.retry_cnt;
+    }
+    (void)n;
+}
+
+// the (normally empty) overflow list of the streaming pass: one item per lane, straight on the table
 template <bool FOLD>
 __global__ __launch_bounds__(256) void k_dedup_overflow(TableView t, SpillView q, const void* __restrict__ recs, uint64_t seq_base) {
     uint32_t count = *q.ovf_tail;
     if (count > q.ovf_cap) count = q.ovf_cap;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t i = q.ovf[k];
-        if (i == 0xffffffffu) continue;
-        Rec r; uint64_t w[5], h = 0;
-        if (!record_prologue(t, recs, i, r, w, h)) continue;
-        if (FOLD) dedup_fold_record(t, r, w, h, (uint32_t)(seq_base + i));
-        else dedup_claim_record(t, r, w, h, (uint32_t)(seq_base + i));
+        const uint32_t it = q.ovf[k];
+        if (it == kPad) continue;
+        Rec raw;
+        load_item(q, recs, it, raw);
+        Item x;
+        decode_item(it, raw, (uint32_t)seq_base, x);
+        if (FOLD) fold_item(t, x, recs, (uint32_t)seq_base);
+        else claim_item(t, x);
     }
 }
 
 }  // namespace dcache
 
-// Six launches: claim pass 1 / its partitions / its overflow, then the same for the fold — the fold needs every flow's first
-// record (F) resolved, i.e. the whole claim pass finished.
-hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s) {
+// Four launches: stream, overflow claims, partitions, overflow folds (+ the reset of the overflow tail).
+// variant 12 (A/B, tests): no retry rounds in the partition pass.
+hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, int variant, hipStream_t s) {
     using namespace dcache;
     if (n == 0) return hipSuccess;
     const SpillView& q = t.spill;
-    if (!t.aux || !q.queue || !q.qtail || !q.ovf || !q.ovf_tail || q.qcap < 4 || (q.qcap & 3u)) return hipErrorInvalidValue;
-    constexpr int kFoldEntries1 = 512;      // pass 1 shares the LDS with the spill staging
-    const size_t lds_c1 = sizeof(ClaimCache<kClaimEntries>) + sizeof(spill::Stage) + kClaimDoorBits / 8, lds_c2 = sizeof(ClaimCache<kClaimEntries>),
-                 lds_f1 = sizeof(FoldCache<kFoldEntries1>) + sizeof(spill::Stage) + kFoldDoorBits / 8, lds_f2 = sizeof(FoldCache<kFoldEntries>);
-    static_assert(sizeof(ClaimCache<kClaimEntries>) + sizeof(spill::Stage) + kClaimDoorBits / 8 <= 160 * 1024, "LDS of one CU");
-    static_assert(sizeof(FoldCache<kFoldEntries>) <= 160 * 1024 && sizeof(FoldCache<kFoldEntries1>) + sizeof(spill::Stage) + kFoldDoorBits / 8 <= 160 * 1024, "LDS of one CU");
+    if (!t.aux || !q.queue || !q.qtail || !q.ovf || !q.ovf_tail || !q.xp || q.qcap < 4 || (q.qcap & 3u) || n >= (uint64_t)kXpFlag) return hipErrorInvalidValue;
+    const size_t lds1 = sizeof(FoldCache<kStreamEntries>) + sizeof(spill::Stage) + kDoorBits / 8,
+                 lds2 = sizeof(FoldCache<kPartEntries>) + sizeof(PartsLds);
+    static_assert(sizeof(FoldCache<kStreamEntries>) + sizeof(spill::Stage) + kDoorBits / 8 <= 160 * 1024, "LDS of one CU");
+    static_assert(sizeof(FoldCache<kPartEntries>) + sizeof(PartsLds) <= 160 * 1024, "LDS of one CU");
     static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_claim_cached<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c1);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_claim_cached<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c2);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_fold_cached<false, kFoldEntries1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f1);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_fold_cached<true, kFoldEntries>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f2);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_parts), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const uint64_t tiles = (n + kBlock - 1) / kBlock;
-    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    const unsigned grid = (unsigned)(tiles < (uint64_t)kStreamGrid ? tiles : (uint64_t)kStreamGrid);
     hipError_t e;
 #define NF_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); e = hipGetLastError(); if (e != hipSuccess) return e; } while (0)
-    NF_LAUNCH((k_dedup_claim_cached<false>), dim3(grid), dim3(kBlock), lds_c1, s, t, q, d_records, n, seq_base);
-    NF_LAUNCH((k_dedup_claim_cached<true>), dim3(kSpillParts), dim3(kBlock), lds_c2, s, t, q, d_records, n, seq_base);
-    NF_LAUNCH((k_dedup_overflow<false>), dim3(256), dim3(256), 0, s, t, q, d_records, seq_base);
-    e = hipMemsetAsync(q.ovf_tail, 0, sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    NF_LAUNCH((k_dedup_fold_cached<false, kFoldEntries1>), dim3(grid), dim3(kBlock), lds_f1, s, t, q, d_records, n, seq_base);
-    NF_LAUNCH((k_dedup_fold_cached<true, kFoldEntries>), dim3(kSpillParts), dim3(kBlock), lds_f2, s, t, q, d_records, n, seq_base);
-    NF_LAUNCH((k_dedup_overflow<true>), dim3(256), dim3(256), 0, s, t, q, d_records, seq_base);
+    NF_LAUNCH(k_dedup_stream, dim3(grid), dim3(kBlock), lds1, s, t, q, d_records, n, seq_base);
+    NF_LAUNCH((k_dedup_overflow<false>), dim3(32), dim3(256), 0, s, t, q, d_records, seq_base);
+    NF_LAUNCH(k_dedup_parts, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, variant == 12 ? 1 : kMaxRounds);
+    NF_LAUNCH((k_dedup_overflow<true>), dim3(32), dim3(256), 0, s, t, q, d_records, seq_base);
 #undef NF_LAUNCH
     return hipMemsetAsync(q.ovf_tail, 0, sizeof(uint32_t), s);
 }

@@ -115,7 +115,10 @@ struct SpillView {
     uint32_t part_shift;           // partition of a key = (hash >> part_shift) & (n_parts - 1); see nfagg_create
     uint32_t n_parts;              // partitions in use (power of two, <= kSpillParts): the two-pass accounter fold scales them to the
                                    // batch (launch_ingest_part), the kernel-dedup passes always use kSpillParts
+    uint4* xp;                     // kernel-dedup mode: kDedupXpEntries exported cache entries of 144 bytes (nfagg_dedup_cached.hip)
 };
+constexpr uint64_t kDedupXpEntries = 256ull * 512ull;   // streaming workgroups x their cache entries
+constexpr uint64_t kDedupXpBytes = kDedupXpEntries * 144ull;
 
 struct TableView {
     SlotHot* hot;
@@ -151,7 +154,7 @@ hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const Sp
                               uint64_t seq_base, int variant, hipStream_t s);
 // Kernel-dedup mode (nfagg_dedup.hip): two passes over the batch (claim + earliest interfaces, then fold).
 hipError_t launch_ingest_dedup(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
-hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
+hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, int variant, hipStream_t s);
 hipError_t launch_evict_dedup(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);
 // Careful path, phase A: claim slots only; writes the slot index of every record.
 hipError_t launch_claim(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,

@@ -1,4 +1,4 @@
-"""NFAGG_MODE_KERNEL_DEDUP parity: the HIP two-pass dedup merge (csrc/nfagg_dedup.hip),
+"""NFAGG_MODE_KERNEL_DEDUP parity: the HIP dedup merge (csrc/nfagg_dedup.hip, csrc/nfagg_dedup_cached.hip),
 called through the C ABI, against the oracle's sequential restatement of
 bpf/flows.c:76-143 (update_existing_flow + add_observed_intf) — bit-exact on all
 144 bytes. The reference has no unit test for this merge (SURVEY.md §8(c):
@@ -65,6 +65,15 @@ def test_dedup_cached_passes_with_many_flows(nf, O):
     recs = dedup_stream(O, 300000, seed=17, n_keys=30000, thresholds=th, style=2)
     check_dedup(nf, O, recs, 1 << 17, 100_000)             # 0: batches >= 65536 records take the cached passes
     check_dedup(nf, O, recs, 1 << 17, 1 << 30, ingest_variant=10)
+
+
+@pytest.mark.parametrize("ingest_variant", [10, 12])   # 12: the partition pass makes no retry rounds (misses merged item by item)
+def test_dedup_partitions_with_more_subflows_than_cache_entries(nf, O, ingest_variant):
+    """~2.4 M sub-flows over 2048 partitions (1024 cache entries each): exported entries and spilled records of one flow meet in
+    the partition pass, sub-flows that find no entry are claimed at once and folded in retry rounds — the first interface of a
+    flow must still be the one of its earliest record in the whole batch. Two batches: the second meets claimed slots."""
+    recs = dedup_stream(O, 3_000_000, seed=23, n_keys=300_000, style=2)
+    check_dedup(nf, O, recs, 1 << 20, 2_000_000, ingest_variant=ingest_variant)
 
 
 @pytest.mark.parametrize("ingest_variant", [0, 10])
