@@ -201,7 +201,7 @@ int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t 
             h->tv.spill.ovf_cap = (uint32_t)((h->d_spill_cap - qbytes) / sizeof(uint32_t) > 0xfffffff0ull ? 0xfffffff0ull
                                              : ((h->d_spill_cap - qbytes) / sizeof(uint32_t)) & ~3ull);
         }
-        if (h->cfg.mode == NFAGG_MODE_KERNEL_DEDUP && !h->tv.spill.xp) {     // exported cache entries of the streaming pass (19 MB)
+        if (h->cfg.mode == NFAGG_MODE_KERNEL_DEDUP && !h->tv.spill.xp) {     // exported cache entries of the streaming pass (38 MB)
             size_t cap = 0;
             void* p = nullptr;
             int rc = ensure_bytes(h, &p, &cap, (size_t)kDedupXpBytes);

@@ -30,6 +30,8 @@ constexpr int kProbe = 8;
 constexpr uint32_t kPad = 0xffffffffu;
 constexpr uint32_t kXpFlag = 0x80000000u;       // queue item: index of an exported entry, not of a record (batches hold < 2^31 records)
 
+NF_DEV uint4 u4(uint64_t a, uint64_t b) { return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)); }
+
 NF_DEV uint64_t subflow_hash(uint64_t h, uint32_t ifx) {
     uint64_t z = (h ^ ((uint64_t)ifx * 0xD6E8FEB86659FD93ull)) * kMul;
     return (z ^ (z >> 32)) | 1ull;
@@ -65,8 +67,8 @@ NF_DEV void cache_init(FoldCache<K>& L, int tid) {
 // sub-flow is seen for the first time: entries are never evicted, so a sub-flow is admitted on its second appearance (admission
 // filter `door`, as in nfagg_ingest_part.hip) — one-off sub-flows of the cold tail do not take the entries of the hot ones.
 // Exactly one of the lanes that meet a new sub-flow in the same tile is turned away (the atomic's return value decides).
-template <int K, int DOORBITS>
-NF_DEV int claim(FoldCache<K>& L, uint32_t* door, uint64_t hs, const uint64_t w[5], uint32_t ifx) {
+template <int K, int DOORBITS, typename Cache>
+NF_DEV int claim(Cache& L, uint32_t* door, uint64_t hs, const uint64_t w[5], uint32_t ifx) {
     uint32_t e = (uint32_t)(hs >> 40) & (K - 1);
 #pragma unroll 1
     for (int p = 0; p < kProbe; p++) {
@@ -90,8 +92,8 @@ NF_DEV int claim(FoldCache<K>& L, uint32_t* door, uint64_t hs, const uint64_t w[
     return -1;
 }
 
-template <int K>
-NF_DEV bool same_subflow(const FoldCache<K>& L, int ent, const uint64_t w[5], uint32_t ifx) {
+template <typename Cache>
+NF_DEV bool same_subflow(const Cache& L, int ent, const uint64_t w[5], uint32_t ifx) {
     bool same = L.ifx[ent] == ifx;
 #pragma unroll
     for (int k = 0; k < 5; k++) same &= (L.key[k][ent] == w[k]);
@@ -99,8 +101,8 @@ NF_DEV bool same_subflow(const FoldCache<K>& L, int ent, const uint64_t w[5], ui
 }
 
 // LDS flavour of topk_insert<2, 0xff> (nfagg_dedup.h): two earliest distinct directions
-template <int K>
-NF_DEV void lds_dir_insert(FoldCache<K>& L, int ent, uint64_t v) {
+template <typename Cache>
+NF_DEV void lds_dir_insert(Cache& L, int ent, uint64_t v) {
     for (int trip = 0; trip < 64; trip++) {
         const uint64_t c0 = L.dir[0][ent], c1 = L.dir[1][ent];
         const bool m0 = c0 != 0 && ((c0 ^ v) & 0xffull) == 0, m1 = c1 != 0 && ((c1 ^ v) & 0xffull) == 0;
@@ -143,24 +145,67 @@ NF_DEV void partial_of_entry(const FoldCache<K>& L, int e, DedupPartial& p) {
     p.ifx = L.ifx[e];
 }
 
-// ---- an exported entry: 36 dwords, the size of a record (one load path for both kinds of queue item)
-//   0..9 key   10 if_index   11 min_seq   12,13 bytes   14 packets   15 flags | tls_types << 16   16..19 endl_lo, endl_hi
-//   20..23 dscp_tag, samp_tag   24,25 ssl_first   26 ssl_max   27 ssl_minv   28..31 cs_tag, ks_tag   32..35 dir0, dir1
-NF_DEV uint4 u4(uint64_t a, uint64_t b) { return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)); }
+// The streaming pass's entry: 108 bytes instead of 152, so that 1024 of them fit beside the spill staging (a 512-entry cache
+// holds the two interfaces of 256 flows: too few for a Zipf stream). What it leaves out:
+//   * the TLS words (ssl_first / ssl_max / ssl_minv / cs_tag / ks_tag): a record that carries TLS information (handshake
+//     packets: a few per connection) is spilled to the partition pass, whose entries have them;
+//   * the sequence tags of the "last value" fields (end, dscp, sampling: assigned by the LAST record, flows.c:108,110-111,128).
+//     A workgroup meets its records in sequence order, tile after tile, so the last record of an entry so far is in the current
+//     tile: the lanes of a tile agree on it with ONE atomic max (last_seq), and after the tile's second barrier the lane that
+//     holds it stores the three values plainly. (Round 2's entry took four 64-bit tagged atomic maxima per record for these,
+//     every one of them a winner — later records carry larger tags — and all lanes of the hot flow on the same address.)
+struct StreamCache {
+    static constexpr int K = 1024;
+    uint64_t h64[K];
+    uint64_t key[5][K];
+    uint64_t bytes[K];
+    uint64_t end[K];              // of the record last_seq names
+    uint64_t dir[2][K];
+    uint32_t ifx[K];
+    uint32_t packets[K];
+    uint32_t flags[K];
+    uint32_t min_seq[K];
+    uint32_t last_seq[K];         // largest sequence number folded, + 1 (0 = none)
+    uint32_t samp[K], dscp[K];    // of the record last_seq names
+};
+static_assert(sizeof(StreamCache) == 108 * 1024, "stream cache entry");
 
-template <int K>
-NF_DEV void export_entry(const FoldCache<K>& L, int e, uint4* dst) {
+NF_DEV void stream_init(StreamCache& L, int tid) {
+    for (int e = tid; e < StreamCache::K; e += kBlock) {
+        L.h64[e] = 0; L.bytes[e] = 0; L.dir[0][e] = 0; L.dir[1][e] = 0;
+        L.packets[e] = 0; L.flags[e] = 0; L.min_seq[e] = 0xffffffffu; L.last_seq[e] = 0;
+    }
+}
+
+// does the record carry TLS information (ssl_version, tls_cipher_suite, tls_key_share, tls_types: record dwords 33, 34)?
+NF_DEV bool has_tls(const Rec& r) { return (r.d[33] | (r.d[34] & 0x00ffffffu)) != 0; }
+
+// phase B of the streaming pass: what is a sum, an OR or a minimum — and the vote for "last record"
+NF_DEV void stream_fold(StreamCache& L, int e, const Rec& r, uint32_t seq32) {
+    if (r.bytes()) atomicAdd((unsigned long long*)&L.bytes[e], (unsigned long long)r.bytes());
+    if (r.packets()) atomicAdd(&L.packets[e], r.packets());
+    if (r.flags() & ~L.flags[e]) atomicOr(&L.flags[e], r.flags());
+    if (L.last_seq[e] < seq32 + 1u) atomicMax(&L.last_seq[e], seq32 + 1u);
+    lds_dir_insert(L, e, ((uint64_t)(~seq32) << 8) | (r.d[24] & 0xffu));
+    if (L.min_seq[e] > seq32) atomicMin(&L.min_seq[e], seq32);
+}
+
+NF_DEV void stream_export(const StreamCache& L, int e, uint4* dst) {
+    const uint64_t s1 = L.last_seq[e], end = L.end[e];
     dst[0] = u4(L.key[0][e], L.key[1][e]);
     dst[1] = u4(L.key[2][e], L.key[3][e]);
     dst[2] = u4(L.key[4][e], (uint64_t)L.ifx[e] | ((uint64_t)L.min_seq[e] << 32));
     dst[3] = u4(L.bytes[e], (uint64_t)L.packets[e] | ((uint64_t)L.flags[e] << 32));
-    dst[4] = u4(L.endl_lo[e], L.endl_hi[e]);
-    dst[5] = u4(L.dscp_tag[e], L.samp_tag[e]);
-    dst[6] = u4(L.ssl_first[e], (uint64_t)L.ssl_max[e] | ((uint64_t)L.ssl_minv[e] << 32));
-    dst[7] = u4(L.cs_tag[e], L.ks_tag[e]);
+    dst[4] = u4((s1 << 32) | (uint32_t)end, (s1 << 32) | (uint32_t)(end >> 32));
+    dst[5] = u4((s1 << 8) | L.dscp[e], (s1 << 32) | L.samp[e]);
+    dst[6] = u4(0, 0);
+    dst[7] = u4(0, 0);
     dst[8] = u4(L.dir[0][e], L.dir[1][e]);
 }
 
+// ---- an exported entry: 36 dwords, the size of a record (one load path for both kinds of queue item)
+//   0..9 key   10 if_index   11 min_seq   12,13 bytes   14 packets   15 flags | tls_types << 16   16..19 endl_lo, endl_hi
+//   20..23 dscp_tag, samp_tag   24,25 ssl_first   26 ssl_max   27 ssl_minv   28..31 cs_tag, ks_tag   32..35 dir0, dir1
 // One queue item in registers: its flow key, interface, smallest sequence number and partial. `raw` holds the 144 bytes the
 // item names: a record of the batch (canonicalised here) or an exported entry.
 struct Item {
@@ -235,7 +280,7 @@ NF_DEV void fold_item(const TableView& t, const Item& x, const void* recs, uint3
     merge_at(t, idx, x.p, x.ms, recs, seq_base32);
 }
 
-constexpr int kStreamEntries = 512;             // the streaming pass shares the LDS with the spill staging (40 KiB) and the filter
+constexpr int kStreamEntries = StreamCache::K;  // the streaming pass shares the LDS with the spill staging (40 KiB) and the filter
 constexpr int kPartEntries = 1024;
 constexpr int kDoorBits = 32768;                // 4 KiB
 constexpr int kStreamGrid = 256;
@@ -246,12 +291,12 @@ static_assert(kStreamEntries <= kBlock && kPartEntries == kBlock, "one cache ent
 __global__ __launch_bounds__(kBlock) void k_dedup_stream(TableView t, SpillView q, const void* __restrict__ recs, uint64_t n, uint64_t seq_base) {
     constexpr int K = kStreamEntries;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    FoldCache<K>& L = *reinterpret_cast<FoldCache<K>*>(lds_raw);
-    spill::Stage& S = *reinterpret_cast<spill::Stage*>(lds_raw + sizeof(FoldCache<K>));
-    uint32_t* door = reinterpret_cast<uint32_t*>(lds_raw + sizeof(FoldCache<K>) + sizeof(spill::Stage));
+    StreamCache& L = *reinterpret_cast<StreamCache*>(lds_raw);
+    spill::Stage& S = *reinterpret_cast<spill::Stage*>(lds_raw + sizeof(StreamCache));
+    uint32_t* door = reinterpret_cast<uint32_t*>(lds_raw + sizeof(StreamCache) + sizeof(spill::Stage));
     const int tid = threadIdx.x;
     const uint32_t seq_base32 = (uint32_t)seq_base;
-    cache_init(L, tid);
+    stream_init(L, tid);
     for (int e = tid; e < kDoorBits / 32; e += kBlock) door[e] = 0;
     spill::Lane<kBlock> sp;
     sp.init(S, tid);
@@ -277,20 +322,15 @@ __global__ __launch_bounds__(kBlock) void k_dedup_stream(TableView t, SpillView 
         const uint32_t seq32 = seq_base32 + (uint32_t)i;
         const uint32_t ifx = valid ? r.d[21] : 0;
         int ent = -1;
-        if (valid) ent = claim<K, kDoorBits>(L, door, subflow_hash(h, ifx), w, ifx);
+        if (valid && !has_tls(r)) ent = claim<K, kDoorBits>(L, door, subflow_hash(h, ifx), w, ifx);
         __syncthreads();
-        bool miss = false;
-        if (valid) {
-            if (ent >= 0 && same_subflow(L, ent, w, ifx)) {
-                DedupPartial p;
-                dedup_partial_from_record(r, seq32, p);
-                fold_into(L, ent, p, seq32);
-            } else {
-                miss = true;
-            }
-        }
+        bool hit = false;
+        if (valid && ent >= 0 && same_subflow(L, ent, w, ifx)) { hit = true; stream_fold(L, ent, r, seq32); }
+        const bool miss = valid && !hit;
         sp.drain(S, q, tid);
         __syncthreads();
+        // the last record of the entry so far is in this tile: its lane stores the "last value" fields
+        if (hit && L.last_seq[ent] == seq32 + 1u) { L.end[ent] = r.end(); L.samp[ent] = r.sampling(); L.dscp[ent] = r.dscp(); }
         if (miss) spilled++;
         sp.append(S, q, miss, spill::part_of(h, q.part_shift), (uint32_t)i);
         // the next tile's claims only write h64/key/ifx of NEW entries; everything else is ordered by its barrier
@@ -303,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void k_dedup_stream(TableView t, SpillView 
     if (tid < K && L.h64[tid] != 0 && L.min_seq[tid] != 0xffffffffu) {
         used = true;
         const uint32_t at = (uint32_t)blockIdx.x * (uint32_t)K + (uint32_t)tid;
-        export_entry(L, tid, q.xp + (uint64_t)at * 9);
+        stream_export(L, tid, q.xp + (uint64_t)at * 9);
         uint64_t w[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) w[k] = L.key[k][tid];
@@ -472,9 +512,9 @@ hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records,
     if (n == 0) return hipSuccess;
     const SpillView& q = t.spill;
     if (!t.aux || !q.queue || !q.qtail || !q.ovf || !q.ovf_tail || !q.xp || q.qcap < 4 || (q.qcap & 3u) || n >= (uint64_t)kXpFlag) return hipErrorInvalidValue;
-    const size_t lds1 = sizeof(FoldCache<kStreamEntries>) + sizeof(spill::Stage) + kDoorBits / 8,
+    const size_t lds1 = sizeof(StreamCache) + sizeof(spill::Stage) + kDoorBits / 8,
                  lds2 = sizeof(FoldCache<kPartEntries>) + sizeof(PartsLds);
-    static_assert(sizeof(FoldCache<kStreamEntries>) + sizeof(spill::Stage) + kDoorBits / 8 <= 160 * 1024, "LDS of one CU");
+    static_assert(sizeof(StreamCache) + sizeof(spill::Stage) + kDoorBits / 8 <= 160 * 1024, "LDS of one CU");
     static_assert(sizeof(FoldCache<kPartEntries>) + sizeof(PartsLds) <= 160 * 1024, "LDS of one CU");
     static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
     int dev_ = 0;

@@ -117,7 +117,7 @@ struct SpillView {
                                    // batch (launch_ingest_part), the kernel-dedup passes always use kSpillParts
     uint4* xp;                     // kernel-dedup mode: kDedupXpEntries exported cache entries of 144 bytes (nfagg_dedup_cached.hip)
 };
-constexpr uint64_t kDedupXpEntries = 256ull * 512ull;   // streaming workgroups x their cache entries
+constexpr uint64_t kDedupXpEntries = 256ull * 1024ull;   // streaming workgroups x their cache entries
 constexpr uint64_t kDedupXpBytes = kDedupXpEntries * 144ull;
 
 struct TableView {
