@@ -365,7 +365,9 @@ struct PartsLds { uint32_t retry_cnt, pad[3]; };
 // region (the write position never passes the read position: items are read two tiles ahead) and is retried in the next round
 // with a fresh cache; FIRST: its claim is made at once, so that after this round's flush every sub-flow of the partition has
 // been claimed. COHERENT: the items were written by this workgroup (read past L1).
-template <bool FIRST, bool COHERENT>
+// ABL (libnfagg_diag.so only, ingest_variant 13..15: timing experiments, results are WRONG): bit 0 = no flush, bit 1 = no fold
+// into the entry, bit 2 = no cache claim either (every item only gathered and decoded).
+template <bool FIRST, bool COHERENT, int ABL = 0>
 NF_DEV void parts_round(const TableView& t, const SpillView& q, FoldCache<kPartEntries>& L, PartsLds& P, uint32_t* queue, uint32_t count,
                         const void* recs, uint32_t seq_base32) {
     constexpr int K = kPartEntries;
@@ -394,12 +396,13 @@ NF_DEV void parts_round(const TableView& t, const SpillView& q, FoldCache<kPartE
         int ent = -1;
         if (valid) {
             decode_item(it_cur, raw, seq_base32, x);
-            ent = claim<K, 0>(L, nullptr, subflow_hash(x.h, x.ifx), x.w, x.ifx);
+            if (!(ABL & 4)) ent = claim<K, 0>(L, nullptr, subflow_hash(x.h, x.ifx), x.w, x.ifx);
+            if (ABL & 4) asm volatile("" :: "v"(x.h), "v"(x.p.bytes), "v"(x.p.dir0));
         }
         __syncthreads();
-        if (valid) {
+        if (valid && !(ABL & 4)) {
             if (ent >= 0 && same_subflow(L, ent, x.w, x.ifx)) {
-                fold_into(L, ent, x.p, x.ms);
+                if (!(ABL & 2)) fold_into(L, ent, x.p, x.ms);
             } else {
                 if (FIRST) claim_item(t, x);
                 queue[atomicAdd(&P.retry_cnt, 1u)] = it_cur;     // lands below (tile + 1) * kBlock
@@ -424,12 +427,16 @@ NF_DEV void parts_flush(const TableView& t, FoldCache<kPartEntries>& L, const vo
         for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
         const uint64_t h = key_hash(w);
         Hints hx;
+        bool fresh = false;
         idx = probe_home(t, w, h, hx);
         if (idx == kNoSlot) {
-            idx = find_or_claim(t, w, h);
+            // a lane that claims the slot plants its own first-record tag and candidate interface with the slot's first values
+            Partial first{};
+            first.first_inv = ~L.min_seq[e]; first.ident0 = L.ifx[e];
+            idx = find_or_claim(t, w, h, &fresh, &hx.home_tag, &first);
             hx.id0 = 0;
         }
-        if (idx != kNoSlot) dedup_claim(t, idx, hx.id0, L.ifx[e], L.min_seq[e]);
+        if (idx != kNoSlot && !fresh) dedup_claim(t, idx, hx.id0, L.ifx[e], L.min_seq[e]);
     }
     drain_stores();                                              // this lane's claims have reached the memory side
     __syncthreads();
@@ -443,6 +450,7 @@ NF_DEV void parts_flush(const TableView& t, FoldCache<kPartEntries>& L, const vo
 
 constexpr int kMaxRounds = 16;
 
+template <int ABL = 0>
 __global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q, const void* __restrict__ recs, uint64_t n, uint64_t seq_base,
                                                         int max_rounds) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -458,7 +466,11 @@ __global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q
     if (tid == 0) P.retry_cnt = 0;
     __syncthreads();
     if (tid == 0) q.qtail[blockIdx.x] = 0;                        // every lane has read it: ready for the next batch
-    parts_round<true, false>(t, q, L, P, my_queue, count, recs, seq_base32);
+    parts_round<true, false, ABL>(t, q, L, P, my_queue, count, recs, seq_base32);
+    if (ABL) {
+        if (!(ABL & 1)) parts_flush(t, L, recs, seq_base32);
+        return;
+    }
     parts_flush(t, L, recs, seq_base32);
     uint32_t m = P.retry_cnt;
     for (int round = 1; m != 0; round++) {
@@ -522,7 +534,12 @@ hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records,
     bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_parts), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_parts<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+#ifdef NFAGG_DIAG
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_parts<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_parts<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_parts<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+#endif
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -532,7 +549,13 @@ hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records,
 #define NF_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); e = hipGetLastError(); if (e != hipSuccess) return e; } while (0)
     NF_LAUNCH(k_dedup_stream, dim3(grid), dim3(kBlock), lds1, s, t, q, d_records, n, seq_base);
     NF_LAUNCH((k_dedup_overflow<false>), dim3(32), dim3(256), 0, s, t, q, d_records, seq_base);
-    NF_LAUNCH(k_dedup_parts, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, variant == 12 ? 1 : kMaxRounds);
+#ifdef NFAGG_DIAG
+    if (variant == 13) NF_LAUNCH(k_dedup_parts<1>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, 1);
+    else if (variant == 14) NF_LAUNCH(k_dedup_parts<3>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, 1);
+    else if (variant == 15) NF_LAUNCH(k_dedup_parts<7>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, 1);
+    else
+#endif
+    NF_LAUNCH(k_dedup_parts<0>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, variant == 12 ? 1 : kMaxRounds);
     NF_LAUNCH((k_dedup_overflow<true>), dim3(32), dim3(256), 0, s, t, q, d_records, seq_base);
 #undef NF_LAUNCH
     return hipMemsetAsync(q.ovf_tail, 0, sizeof(uint32_t), s);

@@ -247,8 +247,11 @@ NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t 
                     for (int k = 0; k < 5; k++) ast16(&hw[6 + 2 * k], v[2 * k], v[2 * k + 1]);
                     ast16(&t.cold[idx], ch[0], ch[1]);
                     if (t.aux) {
+                        // kernel-dedup mode: a claimer that brings its first-record tag (init: first_inv, ident0 = the
+                        // interface; everything else zero) is also the first candidate interface (nfagg_dedup.h dedup_claim)
                         uint64_t* aw = reinterpret_cast<uint64_t*>(&t.aux[idx]);
-                        for (int k = 0; k < (int)(sizeof(SlotAux) / 8); k += 2) ast16(&aw[k], 0, 0);
+                        ast16(&aw[0], (init && init->ident0) ? tagged(init->first_inv, init->ident0) : 0ull, 0);
+                        for (int k = 2; k < (int)(sizeof(SlotAux) / 8); k += 2) ast16(&aw[k], 0, 0);
                     }
                     t.live_list[pos] = (uint32_t)idx;   // read by the finalize / evict kernels only (kernel boundary)
                     drain_stores();
