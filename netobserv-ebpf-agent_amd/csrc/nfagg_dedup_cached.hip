@@ -29,6 +29,14 @@ constexpr int kBlock = 1024;
 constexpr int kProbe = 8;
 constexpr uint32_t kPad = 0xffffffffu;
 constexpr uint32_t kXpFlag = 0x80000000u;       // queue item: index of an exported entry, not of a record (batches hold < 2^31 records)
+// Batches of up to 2^28 - 1 records (always, in practice): three more bits of the flow's key hash ride above the index, its
+// SUB-PARTITION — the partition pass sorts what its cache could not take by them (as nfagg_ingest_part.hip does).
+constexpr int kSubBits = 3, kSubs = 1 << kSubBits;
+constexpr uint32_t kIdxBits = 31 - kSubBits, kIdxMask = (1u << kIdxBits) - 1u, kIdxMaskUntagged = ~kXpFlag;
+NF_DEV uint32_t sub_tag(uint64_t h, const SpillView& q, bool tag_on) {
+    const uint32_t sh = q.part_shift >= (uint32_t)kSubBits ? q.part_shift - kSubBits : 0;
+    return tag_on ? ((uint32_t)(h >> sh) & (uint32_t)(kSubs - 1)) << kIdxBits : 0u;
+}
 
 NF_DEV uint4 u4(uint64_t a, uint64_t b) { return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)); }
 
@@ -215,7 +223,7 @@ struct Item {
     DedupPartial p;
 };
 
-NF_DEV void decode_item(uint32_t it, Rec& raw, uint32_t seq_base32, Item& x) {
+NF_DEV void decode_item(uint32_t it, uint32_t idx_mask, Rec& raw, uint32_t seq_base32, Item& x) {
     if (it & kXpFlag) {
 #pragma unroll
         for (int k = 0; k < 5; k++) x.w[k] = raw.q(k);
@@ -230,16 +238,16 @@ NF_DEV void decode_item(uint32_t it, Rec& raw, uint32_t seq_base32, Item& x) {
         raw.canonicalize();
         raw.key_words(x.w);
         x.ifx = raw.d[21];
-        x.ms = seq_base32 + it;
+        x.ms = seq_base32 + (it & idx_mask);
         dedup_partial_from_record(raw, x.ms, x.p);
     }
     x.h = key_hash(x.w);
 }
 
-NF_DEV void load_item(const SpillView& q, const void* recs, uint32_t it, Rec& raw) {
+NF_DEV void load_item(const SpillView& q, const void* recs, uint32_t it, uint32_t idx_mask, Rec& raw) {
     // padding loads record 0 (the batch is not empty): the pipeline requests unconditionally
     const void* base = (it != kPad && (it & kXpFlag)) ? (const void*)q.xp : recs;
-    const uint64_t i = it == kPad ? 0 : (uint64_t)(it & ~kXpFlag);
+    const uint64_t i = it == kPad ? 0 : (uint64_t)(it & idx_mask);
     load_record(base, i, raw);
 }
 
@@ -303,6 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_dedup_stream(TableView t, SpillView 
     __syncthreads();
     unsigned long long skipped = 0, spilled = 0;
     const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
+    const bool tag_on = n <= (uint64_t)kIdxMask;
     // software pipeline: the next tile's record is requested (unconditionally, on a clamped index) before this one is processed
     bool valid; uint64_t i; Rec r;
     {
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_dedup_stream(TableView t, SpillView 
         // the last record of the entry so far is in this tile: its lane stores the "last value" fields
         if (hit && L.last_seq[ent] == seq32 + 1u) { L.end[ent] = r.end(); L.samp[ent] = r.sampling(); L.dscp[ent] = r.dscp(); }
         if (miss) spilled++;
-        sp.append(S, q, miss, spill::part_of(h, q.part_shift), (uint32_t)i);
+        sp.append(S, q, miss, spill::part_of(h, q.part_shift), (uint32_t)i | sub_tag(h, q, tag_on));
         // the next tile's claims only write h64/key/ifx of NEW entries; everything else is ordered by its barrier
         r = r_n; valid = valid_n; i = i_n;
     }
@@ -347,8 +356,9 @@ __global__ __launch_bounds__(kBlock) void k_dedup_stream(TableView t, SpillView 
         uint64_t w[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) w[k] = L.key[k][tid];
-        part = spill::part_of(key_hash(w), q.part_shift);
-        item = kXpFlag | at;
+        const uint64_t h = key_hash(w);
+        part = spill::part_of(h, q.part_shift);
+        item = kXpFlag | at | sub_tag(h, q, tag_on);
     }
     sp.drain(S, q, tid);
     __syncthreads();
@@ -359,7 +369,13 @@ __global__ __launch_bounds__(kBlock) void k_dedup_stream(TableView t, SpillView 
 }
 
 // ---- the partition pass ------------------------------------------------------------------------------------------------
-struct PartsLds { uint32_t retry_cnt, pad[3]; };
+struct PartsLds {
+    uint32_t retry_cnt;             // items written back for a further round
+    uint32_t sub_cnt[kSubs];        // ... of the first round, per sub-partition
+    uint32_t sub_off[kSubs + 1];    // counting sort: start of every sub-partition's segment
+    uint32_t sub_fill[kSubs];
+};
+constexpr uint32_t kPackItems = 768;   // consecutive sub-partitions share a round while their items (>= sub-flows) surely fit a cache
 
 // Fold the `count` items at `queue` into the cache. An item whose sub-flow gets no entry goes back to the front of the same
 // region (the write position never passes the read position: items are read two tiles ahead) and is retried in the next round
@@ -369,7 +385,7 @@ struct PartsLds { uint32_t retry_cnt, pad[3]; };
 // into the entry, bit 2 = no cache claim either (every item only gathered and decoded).
 template <bool FIRST, bool COHERENT, int ABL = 0>
 NF_DEV void parts_round(const TableView& t, const SpillView& q, FoldCache<kPartEntries>& L, PartsLds& P, uint32_t* queue, uint32_t count,
-                        const void* recs, uint32_t seq_base32) {
+                        const void* recs, uint32_t seq_base32, uint32_t idx_mask) {
     constexpr int K = kPartEntries;
     const int tid = threadIdx.x;
     auto qload = [&](uint32_t pos) -> uint32_t { return COHERENT ? ald(&queue[pos]) : queue[pos]; };
@@ -380,7 +396,7 @@ NF_DEV void parts_round(const TableView& t, const SpillView& q, FoldCache<kPartE
         const uint32_t pos = (uint32_t)tid;
         if (pos < count) it_cur = qload(pos);
         if (pos + kBlock < count) it_next = qload(pos + kBlock);
-        load_item(q, recs, it_cur, raw);
+        load_item(q, recs, it_cur, idx_mask, raw);
     }
     for (uint32_t tile = 0; tile < n_tiles; tile++) {
         uint32_t it_nn = kPad;
@@ -388,14 +404,14 @@ NF_DEV void parts_round(const TableView& t, const SpillView& q, FoldCache<kPartE
         {
             const uint64_t p2 = (uint64_t)(tile + 2) * kBlock + tid;
             if (p2 < count) it_nn = qload((uint32_t)p2);
-            load_item(q, recs, it_next, raw_n);
+            load_item(q, recs, it_next, idx_mask, raw_n);
         }
         const bool valid = it_cur != kPad;
         Item x;
         x.h = 0; x.ifx = 0; x.ms = 0;
         int ent = -1;
         if (valid) {
-            decode_item(it_cur, raw, seq_base32, x);
+            decode_item(it_cur, idx_mask, raw, seq_base32, x);
             if (!(ABL & 4)) ent = claim<K, 0>(L, nullptr, subflow_hash(x.h, x.ifx), x.w, x.ifx);
             if (ABL & 4) asm volatile("" :: "v"(x.h), "v"(x.p.bytes), "v"(x.p.dir0));
         }
@@ -404,7 +420,10 @@ NF_DEV void parts_round(const TableView& t, const SpillView& q, FoldCache<kPartE
             if (ent >= 0 && same_subflow(L, ent, x.w, x.ifx)) {
                 if (!(ABL & 2)) fold_into(L, ent, x.p, x.ms);
             } else {
-                if (FIRST) claim_item(t, x);
+                if (FIRST) {
+                    claim_item(t, x);
+                    atomicAdd(&P.sub_cnt[(it_cur & ~kXpFlag) >> kIdxBits], 1u);      // (untagged items: all in sub-partition 0..7 of the index bits; unused then)
+                }
                 queue[atomicAdd(&P.retry_cnt, 1u)] = it_cur;     // lands below (tile + 1) * kBlock
             }
         }
@@ -450,6 +469,36 @@ NF_DEV void parts_flush(const TableView& t, FoldCache<kPartEntries>& L, const vo
 
 constexpr int kMaxRounds = 16;
 
+// Rounds over the items at list[0..m) (written by this workgroup) until none is left: every round takes what fits a fresh cache
+// and writes the rest back to the front of the list. Every item's sub-flow has been claimed on the table (first round).
+NF_DEV void parts_drain(const TableView& t, const SpillView& q, FoldCache<kPartEntries>& L, PartsLds& P, uint32_t* list, uint32_t m,
+                        const void* recs, uint32_t seq_base32, uint32_t idx_mask, int max_rounds) {
+    const int tid = threadIdx.x;
+    for (int round = 1; m != 0; round++) {
+        if (round >= max_rounds) {
+            // far more sub-flows than rounds x entries: what is left is merged item by item
+            for (uint32_t k = tid; k < m; k += kBlock) {
+                const uint32_t it = ald(&list[k]);
+                Rec raw;
+                load_item(q, recs, it, idx_mask, raw);
+                Item x;
+                decode_item(it, idx_mask, raw, seq_base32, x);
+                fold_item(t, x, recs, seq_base32);
+            }
+            break;
+        }
+        cache_init(L, tid);
+        if (tid == 0) P.retry_cnt = 0;
+        __syncthreads();
+        parts_round<false, true>(t, q, L, P, list, m, recs, seq_base32, idx_mask);
+        parts_flush(t, L, recs, seq_base32);
+        m = P.retry_cnt;
+        drain_stores();
+        __syncthreads();                                          // everybody has read retry_cnt; the retry list is written
+    }
+}
+
+
 template <int ABL = 0>
 __global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q, const void* __restrict__ recs, uint64_t n, uint64_t seq_base,
                                                         int max_rounds) {
@@ -459,57 +508,66 @@ __global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q
     const int tid = threadIdx.x;
     const uint32_t seq_base32 = (uint32_t)seq_base;
     const uint32_t tail = q.qtail[blockIdx.x];                    // written by the streaming pass (previous kernel)
-    uint32_t count = tail < q.qcap ? tail : q.qcap;
+    const uint32_t count = tail < q.qcap ? tail : q.qcap;
     if (count == 0) return;                                       // uniform for the workgroup
     uint32_t* my_queue = q.queue + (uint64_t)blockIdx.x * q.qcap;
+    const bool tag_on = n <= (uint64_t)kIdxMask;                  // the streaming pass put the sub-partition bits above the index
+    const uint32_t idx_mask = tag_on ? kIdxMask : kIdxMaskUntagged;
     cache_init(L, tid);
     if (tid == 0) P.retry_cnt = 0;
+    if (tid < kSubs) { P.sub_cnt[tid] = 0; P.sub_fill[tid] = 0; }
     __syncthreads();
     if (tid == 0) q.qtail[blockIdx.x] = 0;                        // every lane has read it: ready for the next batch
-    parts_round<true, false, ABL>(t, q, L, P, my_queue, count, recs, seq_base32);
+    parts_round<true, false, ABL>(t, q, L, P, my_queue, count, recs, seq_base32, idx_mask);
     if (ABL) {
         if (!(ABL & 1)) parts_flush(t, L, recs, seq_base32);
         return;
     }
     parts_flush(t, L, recs, seq_base32);
-    uint32_t m = P.retry_cnt;
-    for (int round = 1; m != 0; round++) {
-        drain_stores();
-        __syncthreads();                                          // everybody has read retry_cnt; the retry list is written
-        if (round >= max_rounds) {
-            // a partition with far more sub-flows than rounds x entries: what is left is merged item by item
-            for (uint32_t k = tid; k < m; k += kBlock) {
-                const uint32_t it = ald(&my_queue[k]);
-                Rec raw;
-                load_item(q, recs, it, raw);
-                Item x;
-                decode_item(it, raw, seq_base32, x);
-                fold_item(t, x, recs, seq_base32);
-            }
-            break;
-        }
-        cache_init(L, tid);
-        if (tid == 0) P.retry_cnt = 0;
-        __syncthreads();
-        parts_round<false, true>(t, q, L, P, my_queue, m, recs, seq_base32);
-        parts_flush(t, L, recs, seq_base32);
-        m = P.retry_cnt;
+    const uint32_t m = P.retry_cnt;
+    if (m == 0) return;
+    drain_stores();
+    __syncthreads();                                              // everybody has read retry_cnt; the retry list is written
+    // More sub-flows in the partition than the cache has entries. Sort what is left by sub-partition into the free tail of this
+    // workgroup's queue region (counting sort, counts kept during the first round) and give every run of sub-partitions that
+    // surely fits a cache one round of its own; a run that does not fit after all is drained in further rounds.
+    const uint32_t sorted_at = (count + 3u) & ~3u;
+    if (!tag_on || (uint64_t)sorted_at + m > q.qcap) {
+        parts_drain(t, q, L, P, my_queue, m, recs, seq_base32, idx_mask, max_rounds);
+        return;
     }
-    (void)n;
+    if (tid == 0) { uint32_t o = 0; for (int s = 0; s < kSubs; s++) { P.sub_off[s] = o; o += P.sub_cnt[s]; } P.sub_off[kSubs] = o; }
+    __syncthreads();
+    uint32_t* sorted = my_queue + sorted_at;
+    for (uint32_t k = tid; k < m; k += kBlock) {
+        const uint32_t it = ald(&my_queue[k]);
+        const uint32_t s = (it & ~kXpFlag) >> kIdxBits;
+        sorted[P.sub_off[s] + atomicAdd(&P.sub_fill[s], 1u)] = it;
+    }
+    drain_stores();
+    __syncthreads();
+    for (int s = 0; s < kSubs;) {
+        uint32_t c = P.sub_cnt[s];
+        int e = s + 1;
+        while (e < kSubs && c + P.sub_cnt[e] <= kPackItems) { c += P.sub_cnt[e]; e++; }
+        if (c) parts_drain(t, q, L, P, sorted + P.sub_off[s], c, recs, seq_base32, idx_mask, max_rounds);
+        s = e;
+    }
 }
 
 // the (normally empty) overflow list of the streaming pass: one item per lane, straight on the table
 template <bool FOLD>
-__global__ __launch_bounds__(256) void k_dedup_overflow(TableView t, SpillView q, const void* __restrict__ recs, uint64_t seq_base) {
+__global__ __launch_bounds__(256) void k_dedup_overflow(TableView t, SpillView q, const void* __restrict__ recs, uint64_t n, uint64_t seq_base) {
+    const uint32_t idx_mask = n <= (uint64_t)kIdxMask ? kIdxMask : kIdxMaskUntagged;
     uint32_t count = *q.ovf_tail;
     if (count > q.ovf_cap) count = q.ovf_cap;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t it = q.ovf[k];
         if (it == kPad) continue;
         Rec raw;
-        load_item(q, recs, it, raw);
+        load_item(q, recs, it, idx_mask, raw);
         Item x;
-        decode_item(it, raw, (uint32_t)seq_base, x);
+        decode_item(it, idx_mask, raw, (uint32_t)seq_base, x);
         if (FOLD) fold_item(t, x, recs, (uint32_t)seq_base);
         else claim_item(t, x);
     }
@@ -548,7 +606,7 @@ hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records,
     hipError_t e;
 #define NF_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); e = hipGetLastError(); if (e != hipSuccess) return e; } while (0)
     NF_LAUNCH(k_dedup_stream, dim3(grid), dim3(kBlock), lds1, s, t, q, d_records, n, seq_base);
-    NF_LAUNCH((k_dedup_overflow<false>), dim3(32), dim3(256), 0, s, t, q, d_records, seq_base);
+    NF_LAUNCH((k_dedup_overflow<false>), dim3(32), dim3(256), 0, s, t, q, d_records, n, seq_base);
 #ifdef NFAGG_DIAG
     if (variant == 13) NF_LAUNCH(k_dedup_parts<1>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, 1);
     else if (variant == 14) NF_LAUNCH(k_dedup_parts<3>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, 1);
@@ -556,7 +614,7 @@ hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records,
     else
 #endif
     NF_LAUNCH(k_dedup_parts<0>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, variant == 12 ? 1 : kMaxRounds);
-    NF_LAUNCH((k_dedup_overflow<true>), dim3(32), dim3(256), 0, s, t, q, d_records, seq_base);
+    NF_LAUNCH((k_dedup_overflow<true>), dim3(32), dim3(256), 0, s, t, q, d_records, n, seq_base);
 #undef NF_LAUNCH
     return hipMemsetAsync(q.ovf_tail, 0, sizeof(uint32_t), s);
 }
