@@ -167,7 +167,7 @@ void orc_rollup(int kind, const void* partials, size_t n_flows, size_t n_cpu,
 }
 
 /* ================================================================== */
-/* bpf/flows.c:76-143 — kernel "dedup" merge (mode 1). PARITY UNPINNED. */
+/* bpf/flows.c:76-143 — kernel "dedup" merge (mode 1). Pinned to oracle/_ref */
 /* The incoming record plays the role of one observation (pkt + ifindex */
 /* + direction + tls): what flow_monitor would have put in new_flow.    */
 /* ================================================================== */

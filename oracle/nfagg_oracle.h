@@ -12,14 +12,18 @@
  *   193-347), Accounter (pkg/flow/account_test.go:47-217), AccumulateDNS/Drops/
  *   NetworkEvents/Xlat/Additional/Quic and base-from-additional
  *   (pkg/model/flow_content_test.go:11-380).
+ *   PINNED to the reference's own C compiled in place (oracle/_ref, built by
+ *   `make -C oracle ref` from /root/reference/bpf/flows.c:76-143 + bpf/types.h;
+ *   tests/test_oracle_ref.py): the kernel dedup merge (mode 1).
  *   PARITY UNPINNED (no reference test exercises them; the oracle follows the
  *   source text): AccumulateBase's order-dependent fields (eth_protocol/dscp/
- *   sampling last-non-zero, MAC first-non-zero), u32/u64 wrap-around, the
- *   kernel dedup merge (bpf/flows.c:76-143), and the Count-Min / HyperLogLog
- *   sketches (which do not exist in the reference at all — our own spec).
+ *   sampling last-non-zero, MAC first-non-zero), u32/u64 wrap-around, and the
+ *   Count-Min / HyperLogLog sketches (which do not exist in the reference at
+ *   all — our own spec).
  *
- * The Go toolchain is absent, so the reference itself cannot be built here
- * (no oracle/_ref).
+ * The Go toolchain is absent, so the Go side of the reference cannot be built
+ * here; tools/go/accounter_parity_test.go dumps the reference Accounter's
+ * evictions on the seeded streams for anyone with a toolchain.
  */
 #ifndef NFAGG_ORACLE_H
 #define NFAGG_ORACLE_H

@@ -1,8 +1,9 @@
 """NFAGG_MODE_KERNEL_DEDUP parity: the HIP dedup merge (csrc/nfagg_dedup.hip, csrc/nfagg_dedup_cached.hip),
 called through the C ABI, against the oracle's sequential restatement of
 bpf/flows.c:76-143 (update_existing_flow + add_observed_intf) — bit-exact on all
-144 bytes. The reference has no unit test for this merge (SURVEY.md §8(c):
-parity unpinned); the oracle follows the source text line by line."""
+144 bytes. The reference has no unit test for this merge; the
+oracle follows the source text line by line and is itself pinned to the reference's
+own C compiled in place (oracle/_ref, tests/test_oracle_ref.py)."""
 import numpy as np
 import pytest
 
