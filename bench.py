@@ -555,6 +555,22 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
     ex["e2e"] = {"what": "host buffer (pageable) -> nfagg_ingest -> nfagg_evict to host memory: PCIe-inclusive, %d M records, 1 timed pass after 1 warm-up" % (m // 1_000_000),
                  "ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m / dt / 1e6, 1), "GBs_host_to_device": round(m * 144 / dt / 1e9, 1),
                  "evicted_flows": int(flows), "bound": "PCIe Gen5 x16 + host memcpy into the pinned ring"}
+    # the same with the caller's two buffers in page-locked memory (nfagg_host_alloc): DMA straight from / into them
+    pin_in, pin_out = nf.PinnedRecords(m), nf.PinnedRecords(keys)
+    pin_in.records[:] = host
+    with nf.FlowTable(max_entries=DEFAULT_MAX_ENTRIES, device=torch.cuda.current_device()) as tab:
+        def e2e_pinned():
+            rc, c = tab.ingest(pin_in.records)
+            assert rc == nf.OK and c == m, (rc, c)
+            return len(tab.evict(nf.REASON_TIMEOUT, out=pin_out.records))
+        e2e_pinned()
+        t0 = time.perf_counter()
+        flows_p = e2e_pinned()
+        dt = time.perf_counter() - t0
+    assert flows_p == flows, (flows_p, flows)
+    ex["e2e_page_locked"] = {"what": "the same from / into page-locked caller buffers (nfagg_host_alloc): no host copy into the staging ring",
+                             "ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m / dt / 1e6, 1), "GBs_host_to_device": round(m * 144 / dt / 1e9, 1),
+                             "evicted_flows": int(flows_p), "bound": "PCIe Gen5 x16"}
 
     # ---- the reference's default CACHE_MAX_FLOWS = 5000 (pkg/config/config.go:146): the stream stops on "full" every few
     # thousand records. nfagg_account runs that loop on the device (one persistent kernel per staged chunk); next to it the
@@ -566,24 +582,28 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
         d_ev = torch.empty((m2 + 8192) * 144, dtype=torch.uint8, device="cuda")
         h_ev = np.empty(m2 // 2 + 8192, dtype=nf.FLOW_RECORD)       # the caller's buffer for the evicted flows, reused call after call
         h_ev.view(np.uint8)[::4096] = 0                             # touched once: a long-lived buffer has its pages
+        pin_ev = nf.PinnedRecords(m2 // 2 + 8192)
         def account(dev):
-            if dev:
+            if dev == 1:
                 rc, c, ends = tab.account_device(d_recs.data_ptr(), m2, d_ev.data_ptr(), m2 + 8192, ends_cap)
                 n_ep, flows = len(ends), (ends[-1] if ends else 0)
             else:
-                rc, c, epochs = tab.account(host[:m2], out=h_ev, max_epochs=ends_cap)
+                rc, c, epochs = (tab.account(host[:m2], out=h_ev, max_epochs=ends_cap) if dev == 0 else
+                                 tab.account(pin_in.records[:m2], out=pin_ev.records, max_epochs=ends_cap))
                 n_ep, flows = len(epochs), sum(len(e) for e in epochs)
             assert rc == nf.OK and c == m2, (rc, c)
             flows += len(tab.evict(nf.REASON_CLOSING, cap=8192))
             return n_ep + 1, flows
-        for dev in (False, True):
+        for dev in (0, 2, 1):
             account(dev)
             t0 = time.perf_counter()
             evs, flows = account(dev)
             dt = time.perf_counter() - t0
-            res["account_device_resident" if dev else "account_host_path"] = {
+            res[("account_host_path", "account_device_resident", "account_host_path_page_locked")[dev]] = {
                 "ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m2 / dt / 1e6, 1), "evictions": evs, "evicted_flows": int(flows), "us_per_epoch": round(dt / evs * 1e6, 1)}
         del d_ev
+        pin_ev.close()
+    pin_in.close(); pin_out.close()
     m3 = min(2_000_000, m2)
     with nf.FlowTable(max_entries=5000, device=torch.cuda.current_device()) as tab:
         def small(dev):

@@ -323,6 +323,13 @@ int nfagg_ingest(nfagg_handle* h, const void* records, size_t n, size_t* consume
  * variants copy into the library's own staging ring and have no such requirement.) */
 int nfagg_ingest_device(nfagg_handle* h, const void* d_records, size_t n, size_t* consumed);
 
+/* Page-locked host memory (hipHostMalloc). Record buffers handed to nfagg_ingest / nfagg_account and output buffers handed to
+ * nfagg_evict / nfagg_account that lie in page-locked memory — from here, or registered by the caller (hipHostRegister) — cross
+ * PCIe by DMA straight from / into them; pageable buffers go through the library's pinned staging ring (one more host copy:
+ * ~30 GB/s instead of the link's ~50). A Go caller keeps its batch in such a buffer instead of a Go slice. */
+int nfagg_host_alloc(size_t bytes, void** p);
+void nfagg_host_free(void* p);
+
 /* Zero-copy producer path: borrow the next pinned staging buffer
  * (capacity = cfg.staging_records), fill it (e.g. straight from the eBPF ring,
  * pkg/flow/tracer_ringbuf.go:112-134), then commit the first n records.

@@ -104,6 +104,8 @@ SIGNATURES = {
     "nfagg_last_error": (C.c_char_p, [_vp]),
     "nfagg_ingest": (C.c_int, [_vp, _vp, _sz, _psz]),
     "nfagg_ingest_device": (C.c_int, [_vp, _vp, _sz, _psz]),
+    "nfagg_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
+    "nfagg_host_free": (None, [_vp]),
     "nfagg_staging_acquire": (C.c_int, [_vp, C.POINTER(_vp), _psz]),
     "nfagg_staging_commit": (C.c_int, [_vp, _sz, _psz]),
     "nfagg_len": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),

@@ -768,10 +768,19 @@ static void staged_copy(void* dst, const void* src, size_t bytes, unsigned threa
 // Device -> caller buffer (pageable). The data must be complete on the device (the caller synchronised the producing stream).
 // Chunks go down into two pinned bounce buffers in turn on a stream of their own; while chunk k travels, chunk k-1 is copied
 // out of its bounce buffer by cfg.copy_threads threads — the mirror image of the H2D staging ring.
+// Is p page-locked host memory the device can read or write directly (nfagg_host_alloc, hipHostMalloc, hipHostRegister)? Such
+// a buffer needs no trip through the library's own pinned buffers: the DMA engine takes it as it is.
+static bool host_is_pinned(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc memory: "invalid value"
+    return a.type == hipMemoryTypeHost;
+}
+
 constexpr size_t kBounceBytes = 16u << 20;
 static int d2h_copy(nfagg_handle* h, void* dst, const void* d_src, size_t bytes) {
     if (bytes == 0) return NFAGG_OK;
-    if (bytes < (4u << 20)) { HIP_TRY(h, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost)); return NFAGG_OK; }
+    if (bytes < (4u << 20) || host_is_pinned(dst)) { HIP_TRY(h, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost)); return NFAGG_OK; }
     if (!h->d2h_stream) {
         HIP_TRY(h, hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking));
         for (int b = 0; b < 2; b++) {
@@ -819,15 +828,17 @@ int nfagg_ingest(nfagg_handle* h, const void* records, size_t n, size_t* consume
     size_t consumed = 0;
     const char* src = static_cast<const char*>(records);
     const size_t cap = (size_t)h->cfg.staging_records;
+    const bool pinned_src = host_is_pinned(records);            // page-locked caller buffer: sent up as it is, no host copy
     // pinned ring, double buffered: the CPU fills buffer b+1 while the GPU
     // copies/folds buffer b (tracer_ringbuf.go:112-134 forwards one record at a time)
     while (consumed < n) {
         const size_t m = stage_chunk(h, n - consumed, cap);
         const int b = h->stage_next;
         HIP_TRY(h, hipEventSynchronize(h->stage_free[b]));
-        staged_copy(h->pinned[b], src + consumed * kRecordBytes, m * kRecordBytes, h->cfg.copy_threads);
+        const void* up = src + consumed * kRecordBytes;
+        if (!pinned_src) { staged_copy(h->pinned[b], up, m * kRecordBytes, h->cfg.copy_threads); up = h->pinned[b]; }
         // the copy runs on its own stream: the fold of the previous chunk (other buffer) is still busy on h->stream
-        HIP_TRY(h, hipMemcpyAsync(h->d_stage[b], h->pinned[b], m * kRecordBytes, hipMemcpyHostToDevice, h->copy_stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_stage[b], up, m * kRecordBytes, hipMemcpyHostToDevice, h->copy_stream));
         HIP_TRY(h, hipEventRecord(h->stage_up[b], h->copy_stream));
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->stage_up[b], 0));
         size_t c = 0;
@@ -837,6 +848,7 @@ int nfagg_ingest(nfagg_handle* h, const void* records, size_t n, size_t* consume
         consumed += c;
         if (rc != NFAGG_OK) break;
     }
+    if (pinned_src) HIP_TRY(h, hipStreamSynchronize(h->copy_stream));   // the caller's buffer is its own again when the call returns
     if (consumed_out) *consumed_out = consumed;
     return rc;
 }
@@ -1349,11 +1361,13 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
     // Pinned ring, double buffered as in nfagg_ingest: chunk k+1 is copied into its pinned buffer and sent up on the copy
     // stream while the epoch kernel works on chunk k. A chunk that stops early (no room for another eviction) ends the call.
     size_t staged_lo[2] = {0, 0}, staged_n[2] = {0, 0};
+    const bool pinned_src = host_is_pinned(records);            // page-locked caller buffer: sent up as it is, no host copy
     auto stage = [&](int b, size_t lo) -> int {
         const size_t m = (n - lo) < cap ? (n - lo) : cap;
         HIP_TRY(h, hipEventSynchronize(h->stage_free[b]));
-        staged_copy(h->pinned[b], src + lo * kRecordBytes, m * kRecordBytes, h->cfg.copy_threads);
-        HIP_TRY(h, hipMemcpyAsync(h->d_stage[b], h->pinned[b], m * kRecordBytes, hipMemcpyHostToDevice, h->copy_stream));
+        const void* up = src + lo * kRecordBytes;
+        if (!pinned_src) { staged_copy(h->pinned[b], up, m * kRecordBytes, h->cfg.copy_threads); up = h->pinned[b]; }
+        HIP_TRY(h, hipMemcpyAsync(h->d_stage[b], up, m * kRecordBytes, hipMemcpyHostToDevice, h->copy_stream));
         HIP_TRY(h, hipEventRecord(h->stage_up[b], h->copy_stream));
         staged_lo[b] = lo; staged_n[b] = m;
         return NFAGG_OK;
@@ -1408,9 +1422,20 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
         const int rc_down = bring_down();
         if (rc == NFAGG_OK || rc == NFAGG_TRUNCATED) { if (rc_down != NFAGG_OK) rc = rc_down; }
     }
+    if (pinned_src) (void)hipStreamSynchronize(h->copy_stream);       // a chunk staged ahead may still be on its way: the caller's buffer is its own again
     *n_epochs_out = n_ep; *consumed_out = consumed;
     return rc;
 }
+
+// Page-locked host memory for record / eviction buffers: what nfagg_ingest, nfagg_account and nfagg_evict are handed in such a
+// buffer crosses PCIe by DMA straight from / into it (no copy through the library's staging ring).
+int nfagg_host_alloc(size_t bytes, void** p) {
+    if (!p || bytes == 0) return NFAGG_EINVAL;
+    *p = nullptr;
+    if (hipHostMalloc(p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return NFAGG_ENOMEM; }
+    return NFAGG_OK;
+}
+void nfagg_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 // pkg/model/record.go:90-97
 void nfagg_record_times(int64_t now_unix_ns, uint64_t mono_now_ns, const nfagg_flow_metrics* m,

@@ -17,6 +17,31 @@ class NfaggError(RuntimeError):
         self.code = code
 
 
+class PinnedRecords:
+    """Room for n 144-byte records in page-locked host memory (nfagg_host_alloc): `.records` is a numpy view. Buffers like this
+    are sent to / filled by the GPU by DMA directly (include/nfagg.h nfagg_host_alloc); pageable arrays take one more host copy."""
+
+    def __init__(self, n: int):
+        p = C.c_void_p()
+        rc = L.lib.nfagg_host_alloc(max(int(n), 1) * 144, C.byref(p))
+        if rc != L.OK or not p:
+            raise NfaggError(rc, "nfagg_host_alloc failed")
+        self._p = p
+        self.records = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(int(n), 1) * 144,)).view(FLOW_RECORD)[:n]
+
+    def close(self):
+        if self._p:
+            self.records = None
+            L.lib.nfagg_host_free(self._p)
+            self._p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 _ROLLUP_FN = {
     "additional": L.lib.nfagg_rollup_additional, "dns": L.lib.nfagg_rollup_dns, "drops": L.lib.nfagg_rollup_drops,
     "network_events": L.lib.nfagg_rollup_network_events, "xlat": L.lib.nfagg_rollup_xlat, "quic": L.lib.nfagg_rollup_quic,

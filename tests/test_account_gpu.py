@@ -148,3 +148,28 @@ def test_account_dedup_mode_and_large_tables_take_the_host_loop(nf, O):
     recs = _stream(O, 300_000, 200_000, seed=13)
     with nf.FlowTable(max_entries=40_000) as tab:
         _check(nf, O, tab, recs, 40_000, [120_000] * 5)
+
+
+def test_page_locked_caller_buffers_take_the_direct_path(nf, O):
+    """Records in / evictions into page-locked memory (nfagg_host_alloc): DMA straight from / into the caller's buffers, no copy
+    through the staging ring — nfagg_account, nfagg_ingest and nfagg_evict deliver what they deliver from pageable arrays."""
+    max_entries = 3000
+    recs = _stream(O, 300_000, 60_000, seed=21)
+    want = O.run_accounter(recs, max_entries)
+    with nf.PinnedRecords(len(recs)) as pin, nf.PinnedRecords(len(recs) + max_entries) as pout:
+        pin.records[:] = recs.view(nf.FLOW_RECORD)
+        with nf.FlowTable(max_entries=max_entries, staging_records=50_000) as tab:
+            rc, c, epochs = tab.account(pin.records, out=pout.records)
+            assert (rc, c) == (nf.OK, len(recs)) and len(epochs) == len(want) - 1
+            for e, (_, w) in zip(epochs, want):
+                assert_records_equal(nf.sort_by_key(e.copy()), w)
+            last = tab.evict(nf.REASON_CLOSING, out=pout.records)
+            assert_records_equal(nf.sort_by_key(last.copy()), want[-1][1])
+        # nfagg_ingest + a large nfagg_evict (above the 4 MiB the bounce path starts at) through the same buffers
+        want1 = O.run_accounter(recs, 1 << 20)[0][1]
+        with nf.FlowTable(max_entries=1 << 20, staging_records=50_000) as tab:
+            assert tab.ingest(pin.records) == (nf.OK, len(recs))
+            got = tab.evict(nf.REASON_TIMEOUT, out=pout.records)
+            assert_records_equal(nf.sort_by_key(got.copy()), want1)
+            got2 = tab.evict(nf.REASON_TIMEOUT)                    # nothing since
+            assert len(got2) == 0
