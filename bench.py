@@ -663,7 +663,7 @@ def group_main(args, torch):
         outs = [torch.empty((2 * keys // D + 4096) * 144, dtype=torch.uint8, device="cuda:%d" % d) for d in devs]
     grp = nf.FlowGroup(devs, max_entries=max_entries, sketches=sk_flags, profile=True, local_fold=args.group_local_fold)
     out_cap = [o.numel() // 144 for o in outs]
-    threads = args.group_threads and args.group_local_fold
+    threads = args.group_threads
 
     def feed(i):
         rc, c = grp.ingest_device(i, slices[i].data_ptr(), n)

@@ -701,7 +701,12 @@ nfagg_handle* nfagg_group_member(nfagg_group* g, uint32_t i);
 int nfagg_group_ingest(nfagg_group* g, const void* records, size_t n, size_t* consumed);
 /* Same, records already in DEVICE memory of member `src_member`'s device (16-byte aligned, < 2^31 records). In local-fold
  * mode the chunk is folded by that member, asynchronously: the buffer must stay valid until the group synchronises
- * (nfagg_group_len, nfagg_group_evict*), as for nfagg_ingest_device. */
+ * (nfagg_group_len, nfagg_group_evict*), as for nfagg_ingest_device.
+ * THREADS: distinct source members may be fed concurrently, one host thread per source member (how N PCIe links are kept
+ * busy from one process). Routed mode partitions every chunk on its source's own stream — the partitions of concurrent calls
+ * overlap — and folds the buckets one call at a time (arrival order between concurrent calls = the order in which they get
+ * there); local-fold mode reserves the chunk's sequence numbers and folds concurrently. Every other group call needs the
+ * ingest threads to have returned. */
 int nfagg_group_ingest_device(nfagg_group* g, uint32_t src_member, const void* d_records, size_t n, size_t* consumed);
 /* len(c.entries) over all shards. */
 int nfagg_group_len(nfagg_group* g, uint64_t* entries);

@@ -108,6 +108,42 @@ def test_group_device_resident_input(nf, O):
     assert_records_equal(got, O.run_accounter(recs, 1 << 20)[0][1])
 
 
+@pytest.mark.parametrize("local_fold", [False, True])
+def test_group_fed_by_one_host_thread_per_source_member(nf, O, local_fold):
+    """include/nfagg.h: distinct source members may be fed concurrently. Four threads feed four members with chunk after
+    chunk of THEIR OWN flows (thread t owns the flows of key-hash class t of 4, so the order in which concurrent calls are
+    served cannot change any flow's result); routed mode partitions the chunks concurrently and folds them one call at a
+    time, local-fold mode folds concurrently. Result = ONE Accounter over the stream."""
+    import threading
+    import torch
+    recs = _zipf(O, 1_200_000, 80_000, seed=71)
+    cls = nf.distributed.shard_ids(recs.view(nf.FLOW_RECORD), 4)
+    parts = [np.ascontiguousarray(recs[cls == t]) for t in range(4)]
+    dev = [torch.from_numpy(p.view(np.uint8).reshape(-1).copy()).cuda() for p in parts]
+    torch.cuda.synchronize()
+    errors = []
+    with nf.FlowGroup([0, 0, 0, 0], max_entries=1 << 20, local_fold=local_fold, sketches=nf.SKETCH_CM, cm_log2_width=12) as grp:
+        def feed(t):
+            try:
+                off, n = 0, len(parts[t])
+                while off < n:
+                    c = min(n - off, 37_000 + 5_000 * t)
+                    rc, took = grp.ingest_device(t, dev[t].data_ptr() + off * 144, c)
+                    assert (rc, took) == (nf.OK, c), (t, off, rc, took)
+                    off += c
+            except BaseException as exc:       # surfaced in the main thread
+                errors.append(exc)
+        ths = [threading.Thread(target=feed, args=(t,)) for t in range(4)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert not errors, errors
+        assert sum(m.stats().records_ingested for m in grp.members) == len(recs)
+        got = nf.sort_by_key(grp.evict(nf.REASON_CLOSING))
+    assert_records_equal(got, O.run_accounter(recs, 1 << 20)[0][1])
+
+
 def test_one_member_group_goes_through_rccl(nf, O):
     """Distinct devices -> the RCCL path (communicator + all-reduce), here with the one GPU the box has."""
     recs = _zipf(O, 100_000, 5_000, seed=34)
