@@ -99,13 +99,14 @@ def test_dedup_epochs_and_ragged_sizes(nf, O):
             assert len(tab) == 0
 
 
+@pytest.mark.parametrize("ingest_variant", [0, 10])    # 20 000 records: 0 = the direct kernels, 10 = streaming + partition passes
 @pytest.mark.parametrize("n_shards", [2, 8])
-def test_dedup_sharded(nf, O, n_shards):
+def test_dedup_sharded(nf, O, n_shards, ingest_variant):
     th = O.zipf_thresholds(500, 1.1)
     recs = dedup_stream(O, 20000, seed=8, n_keys=500, thresholds=th, style=2)
     parts = []
     for s in range(n_shards):
-        with nf.FlowTable(max_entries=4096, mode=nf.MODE_KERNEL_DEDUP, n_shards=n_shards, shard_id=s) as tab:
+        with nf.FlowTable(max_entries=4096, mode=nf.MODE_KERNEL_DEDUP, n_shards=n_shards, shard_id=s, ingest_variant=ingest_variant) as tab:
             assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
             parts.append(tab.evict())
     assert_records_equal(nf.sort_by_key(np.concatenate(parts)), O.run_accounter(recs, 1 << 20, mode=1)[0][1])

@@ -19,7 +19,7 @@ def _zipf(O, n, keys, seed):
     return O.gen_stream(n, seed=seed, n_keys=keys, thresholds=O.zipf_thresholds(keys, 1.1), variant=1)
 
 
-def reference_group(nf, O, recs, n_shards, max_entries):
+def reference_group(nf, O, recs, n_shards, max_entries, mode=0):
     """The group's contract restated with the oracle: shard j = nfagg_shard_of(key); one sequential Accounter per shard
     with ceil(max_entries / N) entries; the first record (in arrival order) whose new key finds its shard full stops the
     group, everything is evicted, the stream goes on."""
@@ -29,7 +29,7 @@ def reference_group(nf, O, recs, n_shards, max_entries):
     shard = np.fromiter((fn(base + 40 * i, n_shards) for i in range(len(ids))), dtype=np.int64, count=len(ids))
     out, off = [], 0
     while True:
-        accs = [O.Accounter(share) for _ in range(n_shards)]
+        accs = [O.Accounter(share, mode) for _ in range(n_shards)]
         stop = len(recs)
         for j in range(n_shards):
             mine = np.nonzero(shard[off:] == j)[0] + off
@@ -42,7 +42,7 @@ def reference_group(nf, O, recs, n_shards, max_entries):
             return out
         for a in accs:
             a.close()
-        accs = [O.Accounter(share) for _ in range(n_shards)]          # redo the epoch up to the stop
+        accs = [O.Accounter(share, mode) for _ in range(n_shards)]    # redo the epoch up to the stop
         for j in range(n_shards):
             mine = np.nonzero(shard[off:stop] == j)[0] + off
             assert accs[j].ingest(recs[mine]) == len(mine)
@@ -106,6 +106,22 @@ def test_group_device_resident_input(nf, O):
             assert grp.ingest_device(src, d.data_ptr() + a * 144, b - a) == (nf.OK, b - a)
         got = nf.sort_by_key(grp.evict(nf.REASON_CLOSING))
     assert_records_equal(got, O.run_accounter(recs, 1 << 20)[0][1])
+
+
+@pytest.mark.parametrize("n_members,max_entries,batch", [(3, 1 << 20, 1 << 30), (2, 6_000, 1 << 30), (4, 6_000, 70_000), (8, 1 << 20, 90_000)])
+def test_routed_group_in_kernel_dedup_mode(nf, O, n_members, max_entries, batch):
+    """NFAGG_MODE_KERNEL_DEDUP across members (BASELINE configs[4] names it for 8 GPUs): routed — every flow on its owner, which
+    sees all its records in arrival order (the stable partition keeps it), so the merge of bpf/flows.c:76-143 is exact; buckets
+    of 65 536 records or more take the streaming + partition passes, smaller ones the direct kernels. Against the group's
+    contract restated with per-shard oracle Accounters in dedup mode, stop-on-full included."""
+    from conftest import dedup_stream
+    recs = dedup_stream(O, 300_000, seed=47, n_keys=40_000, thresholds=O.zipf_thresholds(40_000, 1.1), style=2)
+    want = reference_group(nf, O, recs, n_members, max_entries, mode=1)
+    with nf.FlowGroup([0] * n_members, max_entries=max_entries, mode=nf.MODE_KERNEL_DEDUP) as grp:
+        got = drive_group(nf, grp, recs.view(nf.FLOW_RECORD), batch)
+    assert [r for r, _ in got] == [r for r, _ in want]
+    for k, ((_, g), (_, w)) in enumerate(zip(got, want)):
+        assert_records_equal(g, w, f"group eviction #{k}")
 
 
 @pytest.mark.parametrize("local_fold", [False, True])
