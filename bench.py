@@ -535,6 +535,9 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
     device_leg("configs4_shape", nf.MODE_KERNEL_DEDUP, False, 2, 900,
                "configs[4] shape on one GPU: 90 % of the records one flow (two interfaces), NFAGG_MODE_KERNEL_DEDUP (bpf/flows.c:76-143 merge), "
                "one ingest call + eviction per step, device-resident")
+    device_leg("dedup_zipf", nf.MODE_KERNEL_DEDUP, False, 2, 0,
+               "the configs[1] stream with every flow seen on two interfaces (stream variant 2), NFAGG_MODE_KERNEL_DEDUP, one ingest call + "
+               "eviction per step, device-resident")
 
     # ---- host path (PCIe-inclusive): the route the cgo shim takes. 20 M records from pageable host memory through
     # nfagg_ingest (pinned double-buffered ring, H2D on its own stream) + nfagg_evict (records back to host memory)

@@ -73,7 +73,7 @@ if f_read and f_write:
         bench = json.load(open(f"{src}/pmc_FETCH_SIZE_bench.json"))
     except Exception:
         bench = None
-    ingest = [k for k in per_kernel if any(s in k for s in ("k_fold", "k_pass1", "k_pass2", "k_merge_overflow", "k_ingest", "k_dedup_claim", "k_dedup_fold", "k_finalize"))]
+    ingest = [k for k in per_kernel if any(s in k for s in ("k_fold", "k_pass1", "k_pass2", "k_merge_overflow", "k_ingest", "k_dedup_claim", "k_dedup_fold", "k_dedup_stream", "k_dedup_parts", "k_dedup_overflow", "k_finalize"))]
     evict = [k for k in per_kernel if "k_evict" in k]
     ev_calls = max((per_kernel[k].get("FETCH_SIZE", (1, 0))[0] for k in evict), default=1)
     ev_traffic = (sum(per_kernel[k].get("FETCH_SIZE", (0, 0))[1] for k in evict) * f_read +
