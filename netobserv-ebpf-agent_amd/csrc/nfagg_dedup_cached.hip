@@ -363,6 +363,13 @@ __global__ __launch_bounds__(kBlock) void k_dedup_stream(TableView t, SpillView 
     sp.drain(S, q, tid);
     __syncthreads();
     sp.append(S, q, used, part, item);
+    // one more (empty) tile: an entry that found its staging group full — the groups hold what the last tiles left in them — is
+    // carried, and a carried item only gets in after a drain; finish() alone would send it to the overflow list, whose items
+    // are claimed and merged one by one (~115 per workgroup: 30 k per call, 0.17 ms in the two overflow kernels)
+    __syncthreads();
+    sp.drain(S, q, tid);
+    __syncthreads();
+    sp.append(S, q, false, 0, 0);
     sp.finish(S, q, tid);
     if (skipped) aadd(&t.ctr->n_skipped, skipped);
     if (spilled) aadd(&t.ctr->n_bypassed, spilled);
@@ -561,6 +568,7 @@ __global__ __launch_bounds__(256) void k_dedup_overflow(TableView t, SpillView q
     const uint32_t idx_mask = n <= (uint64_t)kIdxMask ? kIdxMask : kIdxMaskUntagged;
     uint32_t count = *q.ovf_tail;
     if (count > q.ovf_cap) count = q.ovf_cap;
+    unsigned long long direct = 0;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t it = q.ovf[k];
         if (it == kPad) continue;
@@ -568,9 +576,10 @@ __global__ __launch_bounds__(256) void k_dedup_overflow(TableView t, SpillView q
         load_item(q, recs, it, idx_mask, raw);
         Item x;
         decode_item(it, idx_mask, raw, (uint32_t)seq_base, x);
-        if (FOLD) fold_item(t, x, recs, (uint32_t)seq_base);
+        if (FOLD) { fold_item(t, x, recs, (uint32_t)seq_base); direct++; }
         else claim_item(t, x);
     }
+    if (direct) aadd(&t.ctr->phase[7], direct);                 // diagnostics (nfagg_debug_phase_cycles[7] of libnfagg_diag.so): items through the overflow list
 }
 
 }  // namespace dcache

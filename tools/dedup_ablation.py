@@ -4,6 +4,7 @@ time? Runs the bench's dedup stream through libnfagg_diag.so with ingest_variant
 13 (no flush), 14 (no flush, no fold into the entry), 15 (gather + decode only); results of 13..15 are wrong by construction.
 Run on the GPU box under rocprofv3 --kernel-trace --stats (the per-kernel averages are what is read), or alone (wall times).
     python tools/dedup_ablation.py [flows] [records] [hot_permille]"""
+import ctypes as C
 import os
 import sys
 import time
@@ -39,5 +40,9 @@ for variant in (10, 13, 14, 15):
         ms.append((time.perf_counter() - t0) * 1e3)
         tab.evict_device(out.data_ptr(), flows + 4096)
     st = tab.stats()
-    print("variant %d: ingest call %.3f ms (min of 3), bypassed %.3f of the records" % (variant, min(ms), st.records_bypassed / (3 * n)), flush=True)
+    ph = (C.c_uint64 * 8)()
+    nf._lib.lib.nfagg_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    nf._lib.lib.nfagg_debug_phase_cycles(tab._h, ph)
+    print("variant %d: ingest call %.3f ms (min of 3), bypassed %.3f of the records, %d items per call through the overflow list"
+          % (variant, min(ms), st.records_bypassed / (3 * n), ph[7] // 3), flush=True)
     tab.close()
