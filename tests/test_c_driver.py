@@ -28,14 +28,15 @@ def test_c_driver_builds_and_needs_only_libnfagg_and_hip(nf, driver):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("max_entries,batch", [(1 << 16, 70_000), (700, 5_000)])
-def test_c_driver_matches_oracle(nf, O, driver, tmp_path, max_entries, batch):
+@pytest.mark.parametrize("max_entries,batch,how", [(1 << 16, 70_000, ""), (700, 5_000, ""), (700, 40_000, "account"), (1 << 16, 70_000, "account")])
+def test_c_driver_matches_oracle(nf, O, driver, tmp_path, max_entries, batch, how):
+    """how = "account": nfagg_account from / into nfagg_host_alloc buffers (the cgo shim's flush), else nfagg_ingest + nfagg_evict."""
     th = O.zipf_thresholds(4000, 1.1)
     recs = O.gen_stream(150_000, seed=17, n_keys=4000, thresholds=th, variant=1)
     recs["metrics"]["if_index_first_seen"] = 2 + (np.arange(len(recs)) % 3)           # eth0 / eth1+udn / unknown
     src = tmp_path / "records.bin"
     recs.tofile(src)
-    out = subprocess.check_output([driver, str(src), str(tmp_path / "out"), str(max_entries), str(batch), "1"], text=True).split("\n")
+    out = subprocess.check_output([driver, str(src), str(tmp_path / "out"), str(max_entries), str(batch), "1"] + ([how] if how else []), text=True).split("\n")
     want = O.run_accounter(recs, max_entries)
     lines = [l.split() for l in out if l and not l.startswith("hll_src")]
     assert [(r, len(b)) for r, b in want] == [(l[0], int(l[1])) for l in lines]

@@ -5,7 +5,9 @@
  *   <out>.records : every evicted batch back to back (144-byte records)
  *   <out>.pb      : the pbflow.Records frames of the LAST eviction
  *   stdout        : one line per eviction "reason n_flows", then "hll_src <estimate>" when sketches are on.
- * usage: nfagg_cdriver <records.bin> <out-prefix> <max_entries> <batch_records> <sketches 0|1>
+ * With a sixth argument "account" the batches go through nfagg_account instead — the evict-on-full loop runs inside the library —
+ * from / into page-locked buffers (nfagg_host_alloc): the control flow of INTEGRATION.md section 3's GPUAccounter.flush.
+ * usage: nfagg_cdriver <records.bin> <out-prefix> <max_entries> <batch_records> <sketches 0|1> [account]
  *   cc -std=c11 -O2 -I include tools/c/nfagg_cdriver.c -o nfagg_cdriver -L <libdir> -lnfagg -Wl,-rpath,<libdir> */
 #include <inttypes.h>
 #include <stdio.h>
@@ -19,13 +21,16 @@ static void die(nfagg_handle* h, const char* what, int rc) {
 }
 
 int main(int argc, char** argv) {
-    if (argc != 6) { fprintf(stderr, "usage: %s records.bin out-prefix max_entries batch sketches\n", argv[0]); return 1; }
+    if (argc != 6 && argc != 7) { fprintf(stderr, "usage: %s records.bin out-prefix max_entries batch sketches [account]\n", argv[0]); return 1; }
+    const int account = argc == 7 && strcmp(argv[6], "account") == 0;
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 1; }
     fseek(f, 0, SEEK_END);
     const size_t n = (size_t)ftell(f) / sizeof(nfagg_flow_record);
     fseek(f, 0, SEEK_SET);
-    nfagg_flow_record* recs = malloc(n ? n * sizeof *recs : 1);
+    nfagg_flow_record* recs = 0;
+    if (account) { if (nfagg_host_alloc((n ? n : 1) * sizeof *recs, (void**)&recs) != NFAGG_OK) { fprintf(stderr, "nfagg_host_alloc failed\n"); return 1; } }
+    else recs = malloc(n ? n * sizeof *recs : 1);
     if (fread(recs, sizeof *recs, n, f) != n) { fprintf(stderr, "short read\n"); return 1; }
     fclose(f);
     const uint64_t max_entries = strtoull(argv[3], 0, 10);
@@ -44,8 +49,26 @@ int main(int argc, char** argv) {
     char path[4096];
     snprintf(path, sizeof path, "%s.records", argv[2]);
     FILE* fo = fopen(path, "wb");
-    nfagg_flow_record* out = malloc((size_t)(max_entries ? max_entries : 1) * sizeof *out);
+    const size_t out_cap = (size_t)(max_entries ? max_entries : 1) + (account ? batch : 0);   /* account: a batch's evictions on full, too */
+    nfagg_flow_record* out = 0;
+    if (account) { if (nfagg_host_alloc(out_cap * sizeof *out, (void**)&out) != NFAGG_OK) die(h, "nfagg_host_alloc", NFAGG_ENOMEM); }
+    else out = malloc(out_cap * sizeof *out);
     size_t n_out = 0, off = 0;
+    const size_t max_epochs = batch / (size_t)(max_entries ? max_entries : 1) + 2;
+    uint64_t* epoch_end = malloc(max_epochs * sizeof *epoch_end);
+    while (account && off < n) {                                 /* GPUAccounter.flush: one call per batch, every eviction on full delivered */
+        const size_t m = n - off < batch ? n - off : batch;
+        size_t consumed = 0, n_epochs = 0;
+        rc = nfagg_account(h, recs + off, m, out, out_cap, epoch_end, max_epochs, &n_epochs, &consumed);
+        if (rc < 0) die(h, "nfagg_account", rc);
+        off += consumed;
+        uint64_t lo = 0;
+        for (size_t e = 0; e < n_epochs; e++) {
+            fwrite(out + lo, sizeof *out, (size_t)(epoch_end[e] - lo), fo);
+            printf("full %zu\n", (size_t)(epoch_end[e] - lo));
+            lo = epoch_end[e];
+        }
+    }
     while (off < n) {                                            /* the record arm of Accounter.Account, batched */
         const size_t m = n - off < batch ? n - off : batch;
         size_t consumed = 0;
@@ -88,5 +111,6 @@ int main(int argc, char** argv) {
         printf("hll_src %.17g\n", est);
     }
     nfagg_destroy(h);
+    if (account) { nfagg_host_free(recs); nfagg_host_free(out); }
     return 0;
 }
