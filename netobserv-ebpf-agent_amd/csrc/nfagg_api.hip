@@ -1432,7 +1432,7 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
 int nfagg_host_alloc(size_t bytes, void** p) {
     if (!p || bytes == 0) return NFAGG_EINVAL;
     *p = nullptr;
-    if (hipHostMalloc(p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return NFAGG_ENOMEM; }
+    if (hipHostMalloc(p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return NFAGG_ENOMEM; }
     return NFAGG_OK;
 }
 void nfagg_host_free(void* p) { if (p) (void)hipHostFree(p); }
