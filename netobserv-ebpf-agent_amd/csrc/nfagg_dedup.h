@@ -1,5 +1,5 @@
 // nfagg_dedup.h — device functions shared by the kernel-dedup kernels (nfagg_dedup.hip:
-// direct per-record passes + evict; nfagg_dedup_cached.hip: the LDS-cached passes).
+// direct per-record passes + evict; nfagg_dedup_cached.hip: the LDS-cached streaming + partition passes).
 // Semantics and the two-pass scheme are described at the top of nfagg_dedup.hip.
 #pragma once
 #include "nfagg_device.h"

@@ -11,7 +11,8 @@
 //   r.if_index != F, != 0 ("side"): end = r.end, flags |=, add_observed_intf(if_index, direction)
 //   r.if_index == 0 != F          : ignored
 // Everything is resolved from per-record sequence numbers with order-free
-// operations, in two passes over a batch:
+// operations, in two steps — here (the direct kernels, small batches) two passes over the batch; batches of 65 536 records or
+// more take ONE streaming pass + a partition pass that does both steps per partition (nfagg_dedup_cached.hip):
 //   pass 1 k_dedup_claim : claim the slot, resolve the first record (tagged max, as in
 //                          accounter mode) and the seven interfaces that appear earliest;
 //   pass 2 k_dedup_fold  : F and the first record are now known exactly — sums, ORs,

@@ -152,7 +152,7 @@ bool ingest_variant_supported(int variant);
 bool ingest_needs_spill(int mode, int variant, uint64_t n);
 hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                               uint64_t seq_base, int variant, hipStream_t s);
-// Kernel-dedup mode (nfagg_dedup.hip): two passes over the batch (claim + earliest interfaces, then fold).
+// Kernel-dedup mode: nfagg_dedup.hip (direct: a claim pass, then a fold pass) / nfagg_dedup_cached.hip (one streaming pass + partitions).
 hipError_t launch_ingest_dedup(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
 hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, int variant, hipStream_t s);
 hipError_t launch_evict_dedup(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);
