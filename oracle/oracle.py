@@ -6,6 +6,7 @@ leg. The product package never imports this module.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -16,7 +17,7 @@ _SO = os.path.join(_HERE, "libnfagg_oracle.so")
 def build(force=False):
     src = [os.path.join(_HERE, f) for f in ("nfagg_oracle.c", "nfagg_oracle_pb.c", "nfagg_oracle_maps.c", "nfagg_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src if os.path.exists(s)):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=sys.stderr)   # never on stdout: bench.py prints one JSON line there
     return _SO
 
 
