@@ -116,6 +116,23 @@ def main(argv=None):
     return rank_main(args)
 
 
+class _QuietStdout:
+    """stdout carries ONE JSON line (the driver's contract). Whatever libraries print there while the bench runs — RCCL's
+    version banner at communicator creation, a compiler invoked by ensure_built() — is sent to stderr instead: file
+    descriptor 1 points at stderr until emit() restores it for the line."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        print(line, flush=True)
+        os.dup2(2, 1)
+
+
 def resolve_sizes(args, world):
     n = args.records or (100_000_000 if world == 1 else 125_000_000)
     keys = args.flows or (1_000_000 if world == 1 else 1_250_000)
@@ -133,6 +150,7 @@ def rank_main(args):
     import torch
     import torch.distributed as dist
 
+    quiet = _QuietStdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -441,7 +459,7 @@ def rank_main(args):
         except Exception as exc:                      # a diagnostic, never a reason to lose the bench line
             out["roofline"]["hbm_copy_measured_GBs"] = None
             out["roofline"]["hbm_copy_error"] = str(exc)[:100]
-        print(json.dumps(out), flush=True)
+        quiet.emit(json.dumps(out))
     if tab is not None:
         tab.close()
     if world > 1:
@@ -641,6 +659,7 @@ def group_main(args, torch):
     enters through nfagg_group_ingest_device(i, ...): stable device partition by key-hash shard, buckets to their owners
     (hipMemcpyPeerAsync over xGMI between distinct devices), per-member folds; per step one sketch merge (RCCL all-reduce when
     the devices are distinct) and one eviction of every shard."""
+    quiet = _QuietStdout()
     import __graft_entry__
     __graft_entry__.ensure_built()
     import netobserv_ebpf_agent_amd as nf
@@ -725,7 +744,7 @@ def group_main(args, torch):
             "member_records_ingested": [int(st.records_ingested) for st in sts],
         },
     }
-    print(json.dumps(out), flush=True)
+    quiet.emit(json.dumps(out))
     grp.close()
     return 0
 
