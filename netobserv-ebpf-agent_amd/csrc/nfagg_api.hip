@@ -781,12 +781,10 @@ constexpr size_t kBounceBytes = 16u << 20;
 static int d2h_copy(nfagg_handle* h, void* dst, const void* d_src, size_t bytes) {
     if (bytes == 0) return NFAGG_OK;
     if (bytes < (4u << 20) || host_is_pinned(dst)) { HIP_TRY(h, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost)); return NFAGG_OK; }
-    if (!h->d2h_stream) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking));
-        for (int b = 0; b < 2; b++) {
-            HIP_TRY(h, hipHostMalloc(&h->h_bounce[b], kBounceBytes, hipHostMallocDefault));
-            HIP_TRY(h, hipEventCreateWithFlags(&h->bounce_ev[b], hipEventDisableTiming));
-        }
+    if (!h->d2h_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {                                // created on first use; a failure part-way is picked up by the next call
+        if (!h->h_bounce[b]) HIP_TRY(h, hipHostMalloc(&h->h_bounce[b], kBounceBytes, hipHostMallocDefault));
+        if (!h->bounce_ev[b]) HIP_TRY(h, hipEventCreateWithFlags(&h->bounce_ev[b], hipEventDisableTiming));
     }
     const size_t n_chunks = (bytes + kBounceBytes - 1) / kBounceBytes;
     for (size_t k = 0; k <= n_chunks; k++) {
