@@ -158,3 +158,23 @@ def test_bench_gpus_n_as_a_plain_process_spawns_its_ranks():
     a = bench.parse_args(["--gpus", "8"])
     assert bench.resolve_sizes(a, 8) == (125_000_000, 1_250_000)         # BASELINE.json configs[3]: 1 B records, 10 M flows over 8 GPUs
     assert bench.resolve_sizes(bench.parse_args([]), 1) == (100_000_000, 1_000_000)   # configs[1]
+
+
+def test_bench_stdout_carries_the_json_line_only():
+    """bench.py's stdout is the driver's contract: ONE JSON line. Whatever else is written to file descriptor 1 while the bench
+    runs (RCCL's banner, a compiler started by ensure_built()) must end up on stderr (bench._QuietStdout)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "q = bench._QuietStdout()\n"
+            "print('python-level chatter')\n"
+            "os.write(1, b'library-level chatter on fd 1\\n')\n"
+            "import subprocess; subprocess.check_call(['echo', 'a child process'])\n"
+            "q.emit('{\"value\": 1}')\n"
+            "print('after the line')\n") % root
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True)
+    assert p.stdout == '{"value": 1}\n'
+    for s in ("python-level chatter", "library-level chatter on fd 1", "a child process", "after the line"):
+        assert s in p.stderr
