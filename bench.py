@@ -43,7 +43,6 @@ ALG_BYTES_EVICT = 296       # per evicted flow
 DEFAULT_MAX_ENTRIES = 1 << 21   # CACHE_MAX_FLOWS of the bench table: SURVEY.md §8(d) config 2 sizing (2^22 slots = 768 MiB); tests/test_full_size_gpu.py uses the same
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 METRIC = "flow-records/s ingested + evictions/s, 1/2/4/8 GPU; % HBM roofline"
-PARTIAL_BYTES = 192
 
 
 def parse_args(argv=None):
@@ -179,8 +178,9 @@ def rank_main(args):
     from netobserv_ebpf_agent_amd import synth
 
     n, keys = resolve_sizes(args, world)
-    local_fold = world > 1 and not args.presharded and not args.dedup   # the kernel-dedup slots do not merge across GPUs:
-                                                                        # --dedup at N > 1 runs the pre-sharded line (every flow on the GPU that owns it)
+    # N > 1: ONE common stream, local fold — in both modes. With --dedup (configs[4]) the ranks' tables are keyed by (flow,
+    # interface) and the flows are put together at their owners when the epoch ends (nfagg_config.local_fold, DESIGN.md §7 a')
+    local_fold = world > 1 and not args.presharded
     sketches = args.sketches or (world > 1 and not args.no_sketches)
     keys_total = keys * world if local_fold else keys
     # ---- synthetic stream, generated in HBM (seed 2)
@@ -208,7 +208,9 @@ def rank_main(args):
     # (one fold, then the proof that no record found the table full: n_live <= max_entries) — DESIGN.md §2.
     # Local fold: a rank may see any flow of the stream (5.4 M of 10 M at N = 8), and its table also takes the flows it owns
     # from the other ranks.
-    max_entries = args.max_entries or (DEFAULT_MAX_ENTRIES if not local_fold else max(DEFAULT_MAX_ENTRIES, min(next_pow2(keys_total), 1 << 23)))
+    # (kernel-dedup local fold: the table holds one slot per (flow, interface), two interfaces per flow in stream variant 2)
+    max_entries = args.max_entries or (DEFAULT_MAX_ENTRIES if not local_fold else
+                                       max(DEFAULT_MAX_ENTRIES, min(next_pow2(keys_total * (2 if args.dedup else 1)), 1 << (24 if args.dedup else 23))))
     sk_flags = (nf.SKETCH_CM | nf.SKETCH_HLL) if sketches else 0
     ext = None
     cm_t = hll_t = None
@@ -219,7 +221,9 @@ def rank_main(args):
         torch.cuda.synchronize()
     tab = nf.FlowTable(max_entries=max_entries, device=local_rank, sketches=sk_flags, profile=True,
                        mode=nf.MODE_KERNEL_DEDUP if args.dedup else nf.MODE_ACCOUNTER,
-                       ingest_variant=args.variant, n_shards=1 if local_fold else world, shard_id=0 if local_fold else rank, ext_sketch=ext)
+                       ingest_variant=args.variant, n_shards=1 if local_fold else world, shard_id=0 if local_fold else rank, ext_sketch=ext,
+                       local_fold=local_fold)
+    PARTIAL_BYTES = tab.partial_bytes           # 192; 256 for the sub-flow partials of the kernel-dedup mode
     out_cap = (keys_total if local_fold else keys) + 4096
     d_out = torch.empty(min(out_cap, max_entries + 4096) * 144 + 16, dtype=torch.uint8, device="cuda")
     out_cap = (d_out.numel() - 16) // 144
@@ -341,7 +345,14 @@ def rank_main(args):
         alg_bytes = ALG_BYTES_INGEST + (ALG_BYTES_SKETCH if sketches else 0)   # 392 B/record, 522 with the sketches
         achieved = alg_bytes * recs_per_launch / (ingest_ms * 1e-3) / 1e9 if ingest_ms > 0 else 0.0
         cfg_no = 4 if args.dedup else (3 if world > 1 else (2 if sketches else 1))
-        if local_fold:
+        if local_fold and args.dedup:
+            workload = ("configs[4]: ONE %dM-record stream, %d permille of the records one flow alternating over two interfaces, the rest "
+                        "Zipf(%.1f) over %dk unique flows on two interfaces each, %dM records per GPU resident on the GPU they arrived at, "
+                        "kernel-dedup merge on (bpf/flows.c:76-143), local fold over sub-flow tables (no per-record routing: the hot flow "
+                        "is folded by every GPU)%s + per step: sub-flow partials to the owners of their flows (all-to-all), merge, join, eviction"
+                        % (n * world // 1_000_000, args.hot_permille, args.zipf, keys_total // 1000, n // 1_000_000,
+                           ", RCCL all-reduce of CM+HLL" if sketches else ""))
+        elif local_fold:
             workload = ("configs[3]: ONE %dM-record Zipf(%.1f) stream over %dk unique flows, %dM records per GPU resident on the GPU they "
                         "arrived at, local fold (no per-record routing) + per step: RCCL all-reduce of CM(d=4,w=2^20)+HLL(p=14), flow "
                         "partials to their key-hash owners (all-to-all), merge, eviction"
@@ -376,7 +387,7 @@ def rank_main(args):
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("k_dedup_claim + k_dedup_fold (one ingest call)" if args.dedup else
+                "kernel": ("k_dedup_stream + k_dedup_parts (+ overflow kernels + k_finalize) = one kernel-dedup ingest call" if args.dedup else
                            "part::k_pass1 + part::k_pass2 (+ k_merge_overflow + k_finalize) = one hash-insert/fold call" if args.variant == 0 else
                            "ingest variant %d" % args.variant),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

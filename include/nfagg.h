@@ -248,6 +248,21 @@ typedef struct nfagg_config {
     uint32_t copy_threads;       /* host threads that copy a caller buffer into the pinned staging ring in
                                     nfagg_ingest (one core moves ~28 GB/s, PCIe Gen5 x16 takes ~50); 0 -> 4, 1 -> inline */
     uint32_t group_flags;        /* nfagg_group_create only: NFAGG_GROUP_* */
+    uint32_t local_fold;         /* nfagg_create only (a NFAGG_GROUP_LOCAL_FOLD group sets it for its members): 1 = this handle is
+                                    one rank of a local-fold job (nfagg_set_sequence / nfagg_partials_* below): it folds whatever
+                                    part of ONE record stream arrives at it and other tables hold other records of the same flows.
+                                    NFAGG_MODE_ACCOUNTER: no effect (a slot is a mergeable partial as it is).
+                                    NFAGG_MODE_KERNEL_DEDUP: what a table counts for a flow depends on the flow's FIRST interface
+                                    (bpf/flows.c:100-126), and that is the interface of the earliest record anywhere in the job —
+                                    so the table is keyed by the SUB-FLOW (flow key, if_index_first_seen) and keeps, per
+                                    interface, both what a counted and what a side interface needs; the flow itself is put
+                                    together when the epoch ends (the sub-flows of all ranks having met at the flow's owner):
+                                    nfagg_evict* / nfagg_evict_owned_device deliver exactly what ONE table over all the records
+                                    would. Differences on such a handle: max_entries and nfagg_len count (flow, interface) pairs
+                                    — NFAGG_FULL comes when a NEW pair finds max_entries of them; partials are
+                                    NFAGG_PARTIAL_BYTES_DEDUP bytes; the 32-bit sequence window does not move: an epoch ends
+                                    (NFAGG_FULL) once 2^32 - 16 sequence numbers have gone by in the job, and
+                                    nfagg_window_restart_device is refused. */
 } nfagg_config;
 
 enum {
@@ -263,7 +278,11 @@ enum {
      * N x max_entries flows); use it where evictions are timeout-driven (CACHE_ACTIVE_TIMEOUT) and max_entries is the
      * safety net. nfagg_group_len is an upper bound (a flow counts once per member that saw it). After an eviction call
      * that returned NFAGG_TRUNCATED the group only accepts the repeated eviction (ingest returns NFAGG_FULL): the members'
-     * slots have been merged already. NFAGG_MODE_ACCOUNTER only. */
+     * slots have been merged already. Both modes: in NFAGG_MODE_KERNEL_DEDUP the members are created with
+     * nfagg_config.local_fold (tables keyed by (flow, interface), see there), every eviction is bit-identical to ONE
+     * kernel-dedup table (bpf/flows.c:76-143) over the same records — BASELINE configs[4]'s hot flow alternating over two
+     * interfaces is counted on the interface of its earliest record whichever member saw that record — and an epoch ends
+     * (NFAGG_FULL) after 2^32 - 16 records. */
     NFAGG_GROUP_LOCAL_FOLD = 1u,
 };
 
@@ -744,9 +763,17 @@ int nfagg_group_evict_device(nfagg_group* g, int reason, void* const* d_out, con
 /* The union of the ranks' evictions is bit-identical to ONE sequential   */
 /* Accounter (pkg/flow/account.go:58-124) over the records folded since   */
 /* the last eviction, in the order of their sequence numbers.             */
-/* NFAGG_MODE_ACCOUNTER only.                                             */
+/* NFAGG_MODE_KERNEL_DEDUP (bpf/flows.c:76-143): the handle must have been  */
+/* created with nfagg_config.local_fold = 1; its partials are SUB-FLOWS      */
+/* (flow, interface) of NFAGG_PARTIAL_BYTES_DEDUP bytes, owned by the owner  */
+/* of their FLOW; step 4 joins the sub-flows of each flow (first interface = */
+/* interface of the earliest record in the job) and the union of the ranks'  */
+/* evictions is bit-identical to ONE kernel-dedup table over those records.  */
 /* ------------------------------------------------------------------ */
 #define NFAGG_PARTIAL_BYTES 192u
+#define NFAGG_PARTIAL_BYTES_DEDUP 256u
+/* Bytes per partial on this handle: NFAGG_PARTIAL_BYTES, or NFAGG_PARTIAL_BYTES_DEDUP in kernel-dedup mode. */
+size_t nfagg_partial_bytes(const nfagg_handle* h);
 #define NFAGG_SHARD_NONE 0xFFFFFFFFu
 
 /* The next record folded by this handle carries sequence number next_seq (epoch-relative: every eviction restarts the
@@ -754,7 +781,7 @@ int nfagg_group_evict_device(nfagg_group* g, int reason, void* const* d_out, con
  * matters. Marks the handle as sharing its numbering with other tables (see nfagg_window_restart_device). */
 int nfagg_set_sequence(nfagg_handle* h, uint64_t next_seq);
 
-/* Step 1. d_out: DEVICE memory, 64-byte aligned, room for `cap` partials of NFAGG_PARTIAL_BYTES. Segment o (the flows shard
+/* Step 1. d_out: DEVICE memory, 64-byte aligned, room for `cap` partials of nfagg_partial_bytes(h). Segment o (the flows shard
  * o owns) starts at partial sum(counts[0..o)) and holds counts[o] partials; counts: HOST array of n_shards (<= 64) words.
  * The flows of self_shard stay in the table and are not exported (counts[self_shard] = 0); NFAGG_SHARD_NONE exports all.
  * *n_out = partials written. NFAGG_TRUNCATED (nothing written, nothing changed, *n_out = partials needed; an upper bound
@@ -769,7 +796,8 @@ int nfagg_partials_export_device(nfagg_handle* h, uint32_t n_shards, uint32_t se
  * for the flows it receives: size it with table_log2_slots (about 4 slots per max_entries, as the group does). */
 int nfagg_partials_merge_device(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id, const void* d_partials, size_t n);
 /* Step 4. nfagg_evict_device restricted to the flows shard_id of n_shards owns; ends the epoch of the whole table.
- * NFAGG_TRUNCATED (nothing evicted, *n_out = records needed) when cap is too small. */
+ * NFAGG_TRUNCATED (nothing evicted, *n_out = records needed) when cap is too small. (Kernel-dedup mode: *n_out counts FLOWS,
+ * which only the join of the sub-flows tells: call with cap = 0 first, or keep cap >= nfagg_len.) */
 int nfagg_evict_owned_device(nfagg_handle* h, int reason, uint32_t n_shards, uint32_t shard_id, void* d_out, size_t cap,
                              size_t* n_out);
 
@@ -780,7 +808,7 @@ int nfagg_evict_owned_device(nfagg_handle* h, int reason, uint32_t n_shards, uin
  * rank knows the job's position — all ranks bring the flows together at their owners WITHOUT evicting:
  *   nfagg_partials_export_device(h, n_shards, NFAGG_SHARD_NONE, ...)   every flow, the rank's own included
  *   exchange: segment o to rank o (the own segment stays)
- *   nfagg_window_restart_device(h, n_shards, shard_id, d_partials, n, next_seq)
+ *   nfagg_window_restart_device(h, n_shards, shard_id, d_partials, n, next_seq)     (NFAGG_MODE_ACCOUNTER only)
  * which empties the table (the epoch tag; nothing is written), merges the n partials this rank owns and rebases their tags;
  * the next record folded carries next_seq (>= every number used in the job so far). The epoch goes on: sketches untouched,
  * nfagg_len = the flows this rank owns. The in-process group (NFAGG_GROUP_LOCAL_FOLD) does all of this by itself. */

@@ -31,6 +31,7 @@ REASON_NAMES = {0: "timeout", 1: "full", 2: "closing"}
 MODE_ACCOUNTER, MODE_KERNEL_DEDUP = 0, 1
 GROUP_LOCAL_FOLD = 1
 PARTIAL_BYTES = 192
+PARTIAL_BYTES_DEDUP = 256
 SHARD_NONE = 0xFFFFFFFF
 SKETCH_CM, SKETCH_HLL = 1, 2
 CM_SRC, CM_DST, HLL_SRC, HLL_DST = 0, 1, 2, 3
@@ -43,7 +44,7 @@ class Config(C.Structure):
         ("cm_depth", C.c_uint32), ("cm_log2_width", C.c_uint32), ("hll_p", C.c_uint32),
         ("staging_records", C.c_uint64), ("n_shards", C.c_uint32), ("shard_id", C.c_uint32),
         ("profile", C.c_uint32), ("ingest_variant", C.c_uint32), ("ext_sketch", C.c_void_p * 4),
-        ("copy_threads", C.c_uint32), ("group_flags", C.c_uint32),
+        ("copy_threads", C.c_uint32), ("group_flags", C.c_uint32), ("local_fold", C.c_uint32),
     ]
 
 
@@ -145,6 +146,7 @@ SIGNATURES = {
     "nfagg_stream": (_vp, [_vp]),
     "nfagg_debug_skip_sequence": (C.c_int, [_vp, C.c_uint64]),
     "nfagg_set_sequence": (C.c_int, [_vp, C.c_uint64]),
+    "nfagg_partial_bytes": (C.c_size_t, [_vp]),
     "nfagg_partials_export_device": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _sz, C.POINTER(C.c_uint64), _psz]),
     "nfagg_partials_merge_device": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _sz]),
     "nfagg_window_restart_device": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _sz, C.c_uint64]),

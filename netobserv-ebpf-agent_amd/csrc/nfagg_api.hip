@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <set>
 #include <string>
@@ -126,9 +127,17 @@ struct nfagg_handle {
     hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     hipGraphExec_t ep_graph = nullptr;   // kChainBatch windows of the epoch kernel chain, captured once (their arguments never change)
     void* ep_graph_key[3] = {};          // the buffers the captured launches point at: re-capture when one was re-allocated
+    // sub-flow table (kernel-dedup mode of a local-fold rank, nfagg_dedup.h): the flow-keyed table its epochs are joined into
+    // (nfagg_dedup_join.hip), allocated at the first eviction; scratch; the join that has been made and not yet evicted
+    TableView jv{};
+    DevCounters* h_jctr = nullptr;  // pinned mirror of jv.ctr
+    void* d_join = nullptr;         // slot_of[]: the J slot of every live sub-flow
+    size_t d_join_cap = 0;
+    struct { bool valid = false; uint32_t n_shards = 0, shard_id = 0; uint64_t flows = 0, claimed = 0; } join;
     nfagg_stats stats{};
     std::vector<EventPair> ev_pending;
     std::vector<EventPair> ev_free;
+    std::mutex err_mu;              // nfagg_account's helper threads report through fail() too
     std::string err;
 };
 
@@ -140,7 +149,7 @@ int fail(nfagg_handle* h, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (h) h->err = buf; else g_create_error = buf;
+    if (h) { std::lock_guard<std::mutex> lk(h->err_mu); h->err = buf; } else g_create_error = buf;
     return code;
 }
 
@@ -264,7 +273,8 @@ constexpr uint64_t kMaxFoldChunk = 1ull << 31;     // records per pass of the in
 int ensure_seq_window(nfagg_handle* h, uint64_t n, bool* blocked) {
     if (blocked) *blocked = false;
     if (h->epoch_seq - h->seq_origin + n < kSeqWindow) return NFAGG_OK;
-    if (h->ext_sequenced) { if (blocked) *blocked = true; return NFAGG_OK; }
+    // (a sub-flow table cannot either: the order BETWEEN the slots of one flow matters until the join, ranks inside a slot lose it)
+    if (h->ext_sequenced || h->tv.subflow) { if (blocked) *blocked = true; return NFAGG_OK; }
     const hipError_t e = launch_rebase(h->tv, h->stream);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "rebase launch failed: %s", hipGetErrorString(e));
     h->seq_origin = h->epoch_seq - rebase_keep();
@@ -398,6 +408,8 @@ int fold_optimistic(nfagg_handle* h, const void* d, uint64_t chunk, uint64_t* fo
     return NFAGG_OK;
 }
 
+int subflow_join_discard(nfagg_handle* h);
+
 // The record arm of Accounter.Account (account.go:81-96) for a device-resident batch.
 int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t* consumed_out) {
     size_t consumed = 0;
@@ -405,12 +417,20 @@ int ingest_device_core(nfagg_handle* h, const void* d_records, size_t n, size_t*
     const char* base = static_cast<const char*>(d_records);
     int rc = NFAGG_OK;
     if (h->must_evict || h->exported) { if (consumed_out) *consumed_out = 0; return n ? NFAGG_FULL : NFAGG_OK; }
+    if (n && (rc = subflow_join_discard(h)) != NFAGG_OK) { if (consumed_out) *consumed_out = 0; return rc; }
     while (consumed < n) {
         uint64_t rem = n - consumed;
         if (rem > kMaxFoldChunk) rem = kMaxFoldChunk;
         {   // the epoch has no maximum length (account.go:58-100): when the 32-bit window of the tags is used up it is moved
             bool blocked = false;
             if ((rc = ensure_seq_window(h, rem, &blocked)) != NFAGG_OK) break;
+            if (blocked && h->tv.subflow) {
+                // kernel-dedup mode of a local-fold rank: the window does not move (include/nfagg.h, nfagg_config.local_fold) —
+                // the epoch ends here, as it does when the table is full: the caller evicts and resubmits the rest
+                h->must_evict = true; h->split_seq = h->epoch_seq;
+                rc = NFAGG_FULL;
+                break;
+            }
             if (blocked) {
                 // numbering shared with other tables (nfagg_set_sequence): the window can only move when the flows have been
                 // brought together at their owners (nfagg_window_restart_device; the in-process group does it by itself)
@@ -552,6 +572,72 @@ int ensure_bytes(nfagg_handle* h, void** p, size_t* cap, size_t need) {
     return NFAGG_OK;
 }
 
+// ---- sub-flow tables (kernel-dedup mode of a local-fold rank): the join that ends an epoch (nfagg_dedup_join.hip) ----------------
+// J: a flow-keyed table of the ordinary kernel-dedup layout, as large as the sub-flow table (a join claims at most one slot per
+// live sub-flow). It lives from the first eviction on and is emptied, like the main table, by its epoch tag.
+int subflow_join_table(nfagg_handle* h) {
+    TableView& J = h->jv;
+    if (J.ctr) return NFAGG_OK;
+    const uint64_t slots = h->slots;
+    if (!J.hot) HIP_TRY(h, hipMalloc((void**)&J.hot, slots * sizeof(SlotHot)));
+    if (!J.cold) HIP_TRY(h, hipMalloc((void**)&J.cold, slots * sizeof(SlotCold)));
+    if (!J.aux) HIP_TRY(h, hipMalloc((void**)&J.aux, slots * sizeof(SlotAux)));
+    if (!J.live_list) HIP_TRY(h, hipMalloc((void**)&J.live_list, slots * sizeof(uint32_t)));
+    if (!h->h_jctr) HIP_TRY(h, hipHostMalloc((void**)&h->h_jctr, sizeof(DevCounters), hipHostMallocDefault));
+    DevCounters* c = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&c, sizeof(DevCounters)));
+    hipError_t e = hipMemsetAsync(c, 0, sizeof(DevCounters), h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(J.hot, 0, slots * sizeof(SlotHot), h->stream);       // the tags: every slot free
+    if (e != hipSuccess) { hipFree(c); return fail(h, NFAGG_EDEVICE, "join table: %s", hipGetErrorString(e)); }
+    J.mask = slots - 1; J.claim_limit = h->tv.claim_limit; J.epoch_bits = 1ull << 48;
+    J.n_shards = 1; J.shard_id = 0; J.defer_claims = 0; J.subflow = 0;
+    J.ctr = c;                                                  // last: marks the table as complete
+    h->stats.table_bytes += slots * (sizeof(SlotHot) + sizeof(SlotCold) + sizeof(SlotAux));
+    return NFAGG_OK;
+}
+
+// J's slots belong to a past epoch from now on (nothing is written); its counters are reset by the launches that emptied it
+int subflow_join_table_next_epoch(nfagg_handle* h) {
+    uint64_t next_epoch = (h->jv.epoch_bits >> 48) + 1;
+    if (next_epoch > 0xFFFFull) {
+        HIP_TRY(h, hipMemsetAsync(h->jv.hot, 0, h->slots * sizeof(SlotHot), h->stream));
+        next_epoch = 1;
+    }
+    h->jv.epoch_bits = next_epoch << 48;
+    return NFAGG_OK;
+}
+
+// A join that was made and not delivered (the caller's buffer was too small) is void once the table changes again.
+int subflow_join_discard(nfagg_handle* h) {
+    if (!h->join.valid) return NFAGG_OK;
+    h->join.valid = false;
+    const hipError_t e = launch_reset_counters(h->jv, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "join table reset failed: %s", hipGetErrorString(e));
+    return subflow_join_table_next_epoch(h);
+}
+
+// Join the live sub-flows that (n_shards, shard_id) owns (n_shards = 1: all of them) into J. Synchronises; h->join holds the outcome.
+int subflow_join(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id) {
+    int rc;
+    if (h->join.valid && h->join.n_shards == n_shards && h->join.shard_id == shard_id) return NFAGG_OK;
+    if ((rc = subflow_join_discard(h)) != NFAGG_OK) return rc;
+    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;
+    if (h->h_ctr->aborted) return fail(h, NFAGG_EDEVICE, "table too small for the flows this shard owns (claims refused while merging)");
+    const uint64_t claimed = h->h_ctr->n_live;
+    if ((rc = subflow_join_table(h)) != NFAGG_OK) return rc;
+    if ((rc = ensure_bytes(h, &h->d_join, &h->d_join_cap, (size_t)claimed * sizeof(uint32_t) + 16)) != NFAGG_OK) return rc;
+    const uint64_t seq_limit = h->must_evict ? h->split_seq - h->seq_origin : ~0ull;
+    const hipError_t e = launch_subflow_join(h->tv, h->jv, claimed, seq_limit, n_shards, shard_id, (uint32_t*)h->d_join, h->stream);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "sub-flow join launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync(h->h_jctr, h->jv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->h_jctr->error || h->h_jctr->aborted)
+        return fail(h, NFAGG_EDEVICE, "sub-flow join bailed out (code %u, aborted %u)", h->h_jctr->error, h->h_jctr->aborted);
+    h->join.valid = true; h->join.n_shards = n_shards; h->join.shard_id = shard_id;
+    h->join.flows = h->h_jctr->n_live; h->join.claimed = claimed;
+    return NFAGG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -591,6 +677,8 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
     if (cfg.copy_threads > 64) return fail(nullptr, NFAGG_EINVAL, "copy_threads > 64");
     if (cfg.n_shards == 0) cfg.n_shards = 1;
     if (cfg.shard_id >= cfg.n_shards) return fail(nullptr, NFAGG_EINVAL, "shard_id %u >= n_shards %u", cfg.shard_id, cfg.n_shards);
+    if (cfg.local_fold > 1) return fail(nullptr, NFAGG_EINVAL, "local_fold must be 0 or 1");
+    if (cfg.local_fold && cfg.n_shards > 1) return fail(nullptr, NFAGG_EINVAL, "a local-fold rank folds whatever arrives at it: n_shards must be 0 or 1");
     uint64_t slots = cfg.table_log2_slots ? (1ull << cfg.table_log2_slots) : next_pow2(2 * cfg.max_entries);
     if (slots < (1ull << 16)) slots = 1ull << 16;
     if (slots < 2 * cfg.max_entries) return fail(nullptr, NFAGG_EINVAL, "table_log2_slots too small: need >= 2*max_entries slots");
@@ -626,6 +714,8 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
     CREATE_TRY(hipHostMalloc((void**)&h->h_ctr, sizeof(DevCounters), hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc((void**)&h->h_careful, kCarefulCountsBytes + kCarefulMaxBatch, hipHostMallocDefault));
     h->tv.mask = slots - 1; h->tv.n_shards = cfg.n_shards; h->tv.shard_id = cfg.shard_id;
+    // a local-fold rank in kernel-dedup mode keys its table by (flow, interface): nfagg_dedup.h, include/nfagg.h (local_fold)
+    h->tv.subflow = (cfg.mode == NFAGG_MODE_KERNEL_DEDUP && cfg.local_fold) ? 1u : 0u;
     h->tv.claim_limit = slots / 4 * 3 + 16;   // max_entries <= slots/2 plus a careful chunk <= slots/4 always fit
     h->tv.epoch_bits = 1ull << 48;            // eviction epoch 1; 0 is "never used"
     // pass 2 of the two-pass fold may collect its claims per workgroup (up to 1024 each, 256 workgroups resident) before
@@ -715,6 +805,13 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->tv.aux) hipFree(h->tv.aux);
     if (h->tv.live_list) hipFree(h->tv.live_list);
     if (h->tv.ctr) hipFree(h->tv.ctr);
+    if (h->jv.hot) hipFree(h->jv.hot);
+    if (h->jv.cold) hipFree(h->jv.cold);
+    if (h->jv.aux) hipFree(h->jv.aux);
+    if (h->jv.live_list) hipFree(h->jv.live_list);
+    if (h->jv.ctr) hipFree(h->jv.ctr);
+    if (h->h_jctr) hipHostFree(h->h_jctr);
+    if (h->d_join) hipFree(h->d_join);
     if (h->h_ctr) hipHostFree(h->h_ctr);
     if (h->h_careful) hipHostFree(h->h_careful);
     if (h->h_exp) hipHostFree(h->h_exp);
@@ -913,11 +1010,52 @@ static int finish_epoch(nfagg_handle* h, int reason, uint64_t flows) {
     return bump_epoch(h);
 }
 
+// Accounter.evict (account.go:102-124) for a sub-flow table: the join (nfagg_dedup_join.hip) of the sub-flows that (n_shards,
+// shard_id) owns into the flow-keyed table, then k_evict_dedup over that. NFAGG_TRUNCATED (nothing evicted; the join is kept for
+// the repeated call) when cap is too small.
+static int subflow_evict(nfagg_handle* h, int reason, uint32_t n_shards, uint32_t shard_id, void* out, bool out_is_device, size_t cap, size_t* n_out) {
+    int rc;
+    *n_out = 0;
+    if (!h->counters_exact && (rc = refresh_counters(h)) != NFAGG_OK) return rc;
+    if (reason == NFAGG_REASON_TIMEOUT && h->live_ub == 0 && !h->exported) return NFAGG_OK;      // account.go:64-66
+    if ((rc = subflow_join(h, n_shards, shard_id)) != NFAGG_OK) return rc;
+    const uint64_t flows = h->join.flows;
+    *n_out = (size_t)flows;
+    if (flows > cap) return NFAGG_TRUNCATED;
+    if (flows && !out) return fail(h, NFAGG_EINVAL, "null output buffer");
+    void* d_out = out;
+    if (!out_is_device) {
+        size_t capb = (size_t)h->d_evict_cap;
+        rc = ensure_bytes(h, &h->d_evict, &capb, (size_t)flows * kRecordBytes + 16);
+        h->d_evict_cap = capb;
+        if (rc != NFAGG_OK) return rc;
+        d_out = h->d_evict;
+    }
+    HIP_TRY(h, hipMemsetAsync(&h->jv.ctr->n_out, 0, sizeof(unsigned long long), h->stream));
+    EventPair ep{};
+    if (h->cfg.profile) prof_begin(h, ep, 1);
+    hipError_t e = launch_evict_dedup(h->jv, flows, ~0ull, d_out, h->stream);      // leaves J's counters reset
+    if (e == hipSuccess) e = launch_reset_counters(h->tv, h->stream);
+    if (h->cfg.profile) prof_end(h, ep);
+    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "evict launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync(h->h_jctr, h->jv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!out_is_device && flows && (rc = d2h_copy(h, out, h->d_evict, (size_t)flows * kRecordBytes)) != NFAGG_OK) return rc;
+    h->mirror_fresh = false;
+    if (h->h_jctr->error) return fail(h, NFAGG_EDEVICE, "sub-flow join table kernel bailed out (code %u)", h->h_jctr->error);
+    if (h->h_jctr->n_out != flows)
+        return fail(h, NFAGG_EDEVICE, "evict wrote %llu records, expected %llu", (unsigned long long)h->h_jctr->n_out, (unsigned long long)flows);
+    h->join.valid = false;
+    if ((rc = subflow_join_table_next_epoch(h)) != NFAGG_OK) return rc;
+    return finish_epoch(h, reason, flows);
+}
+
 static int evict_core(nfagg_handle* h, int reason, void* out, bool out_is_device, size_t cap, size_t* n_out) {
     if (!h || !n_out || reason < 0 || reason > 2) return fail(h, NFAGG_EINVAL, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = NFAGG_OK;
     if (h->exported) return fail(h, NFAGG_ESTATE, "partials were exported from / merged into this table: evict it with nfagg_evict_owned_device");
+    if (h->tv.subflow) return subflow_evict(h, reason, 1, 0, out, out_is_device, cap, n_out);
     if (!h->counters_exact && (rc = refresh_counters(h)) != NFAGG_OK) return rc;
     const uint64_t legit = h->live;
     const uint64_t claimed = h->live_ub;          // = the device's n_live (counters_exact)
@@ -1000,7 +1138,8 @@ static int partials_export_core(nfagg_handle* h, uint32_t n_shards, uint32_t sel
                                 size_t* n_out) {
     if (!h || !counts || !n_out) return fail(h, NFAGG_EINVAL, "null argument");
     if (n_shards == 0 || n_shards > 64) return fail(h, NFAGG_EINVAL, "n_shards must be in [1, 64]");
-    if (h->cfg.mode != NFAGG_MODE_ACCOUNTER) return fail(h, NFAGG_EINVAL, "partials need NFAGG_MODE_ACCOUNTER (the kernel-dedup slots do not merge across tables)");
+    if (h->cfg.mode != NFAGG_MODE_ACCOUNTER && !h->tv.subflow)
+        return fail(h, NFAGG_EINVAL, "partials need NFAGG_MODE_ACCOUNTER, or NFAGG_MODE_KERNEL_DEDUP on a handle created with nfagg_config.local_fold (flow-keyed kernel-dedup slots do not merge across tables)");
     if (h->cfg.n_shards > 1) return fail(h, NFAGG_ESTATE, "a handle that filters its input by shard (n_shards > 1) holds no other shard's flows");
     if (d_out && ((uintptr_t)d_out & 63u)) return fail(h, NFAGG_EINVAL, "partials buffer must be 64-byte aligned");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1034,10 +1173,11 @@ static int partials_export_core(nfagg_handle* h, uint32_t n_shards, uint32_t sel
 static int partials_merge_core(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id, const void* d_partials, size_t n) {
     if (!h || (n && !d_partials)) return fail(h, NFAGG_EINVAL, "null argument");
     if (n_shards == 0 || n_shards > 64 || shard_id >= n_shards) return fail(h, NFAGG_EINVAL, "bad shard (n_shards in [1, 64], shard_id < n_shards)");
-    if (h->cfg.mode != NFAGG_MODE_ACCOUNTER) return fail(h, NFAGG_EINVAL, "partials need NFAGG_MODE_ACCOUNTER");
+    if (h->cfg.mode != NFAGG_MODE_ACCOUNTER && !h->tv.subflow) return fail(h, NFAGG_EINVAL, "partials need NFAGG_MODE_ACCOUNTER or nfagg_config.local_fold");
     if ((uintptr_t)d_partials & 15u) return fail(h, NFAGG_EINVAL, "partials buffer must be 16-byte aligned");
     if (n == 0) return NFAGG_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    { const int rcj = subflow_join_discard(h); if (rcj != NFAGG_OK) return rcj; }
     TableView tv = h->tv;
     tv.n_shards = n_shards; tv.shard_id = shard_id;
     h->counters_exact = false; h->mirror_fresh = false;                  // the merge claims slots
@@ -1051,7 +1191,14 @@ static int partials_merge_core(nfagg_handle* h, uint32_t n_shards, uint32_t shar
 // claims refused by a merge.
 static int owned_count_core(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id, uint64_t* owned, uint64_t* claimed_out) {
     HIP_TRY(h, hipSetDevice(h->device));
-    int rc = partials_scratch(h);
+    int rc;
+    if (h->tv.subflow) {                                         // flows, not sub-flows: known after the join (kept for the eviction)
+        if ((rc = subflow_join(h, n_shards, shard_id)) != NFAGG_OK) return rc;
+        *owned = h->join.flows;
+        if (claimed_out) *claimed_out = h->join.claimed;
+        return NFAGG_OK;
+    }
+    rc = partials_scratch(h);
     if (rc != NFAGG_OK) return rc;
     if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;
     if (h->h_ctr->aborted) return fail(h, NFAGG_EDEVICE, "table too small for the flows this shard owns (claims refused while merging)");
@@ -1071,8 +1218,9 @@ static int owned_count_core(nfagg_handle* h, uint32_t n_shards, uint32_t shard_i
 static int evict_owned_core(nfagg_handle* h, int reason, uint32_t n_shards, uint32_t shard_id, void* d_out, size_t cap, size_t* n_out) {
     if (!h || !n_out || reason < 0 || reason > 2) return fail(h, NFAGG_EINVAL, "bad argument");
     if (n_shards == 0 || n_shards > 64 || shard_id >= n_shards) return fail(h, NFAGG_EINVAL, "bad shard (n_shards in [1, 64], shard_id < n_shards)");
-    if (h->cfg.mode != NFAGG_MODE_ACCOUNTER) return fail(h, NFAGG_EINVAL, "partials need NFAGG_MODE_ACCOUNTER");
+    if (h->cfg.mode != NFAGG_MODE_ACCOUNTER && !h->tv.subflow) return fail(h, NFAGG_EINVAL, "partials need NFAGG_MODE_ACCOUNTER or nfagg_config.local_fold");
     if (d_out && ((uintptr_t)d_out & 15u)) return fail(h, NFAGG_EINVAL, "device output must be 16-byte aligned");
+    if (h->tv.subflow) { HIP_TRY(h, hipSetDevice(h->device)); return subflow_evict(h, reason, n_shards, shard_id, d_out, true, cap, n_out); }
     uint64_t owned = 0, claimed = 0;
     int rc = owned_count_core(h, n_shards, shard_id, &owned, &claimed);
     if (rc != NFAGG_OK) return rc;
@@ -1106,6 +1254,8 @@ int nfagg_partials_merge_device(nfagg_handle* h, uint32_t n_shards, uint32_t sha
 int nfagg_evict_owned_device(nfagg_handle* h, int reason, uint32_t n_shards, uint32_t shard_id, void* d_out, size_t cap, size_t* n_out) {
     return evict_owned_core(h, reason, n_shards, shard_id, d_out, cap, n_out);
 }
+
+size_t nfagg_partial_bytes(const nfagg_handle* h) { return (h && h->tv.subflow) ? kPartialBytesDedup : kPartialBytes; }
 
 int nfagg_set_sequence(nfagg_handle* h, uint64_t next_seq) {
     if (!h) return NFAGG_EINVAL;
@@ -1151,6 +1301,7 @@ static int window_finish_core(nfagg_handle* h, uint64_t next_seq) {
 
 int nfagg_window_restart_device(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id, const void* d_partials, size_t n, uint64_t next_seq) {
     if (!h) return NFAGG_EINVAL;
+    if (h->tv.subflow) return fail(h, NFAGG_ESTATE, "kernel-dedup mode: the sequence window of a local-fold job does not move (the order between a flow's sub-flows would be lost): evict instead");
     int rc = window_clear_core(h);
     if (rc != NFAGG_OK) return rc;
     if ((rc = partials_merge_core(h, n_shards, shard_id, d_partials, n)) != NFAGG_OK) return rc;
@@ -1163,7 +1314,9 @@ constexpr uint64_t kAccountFastMaxEntries = 32768;   // beyond that an epoch is 
 
 // May the persistent epoch kernel (nfagg_epochs.hip) take this batch?
 static bool account_fast_ok(const nfagg_handle* h, size_t n, size_t out_cap) {
-    return h->cfg.mode == NFAGG_MODE_ACCOUNTER && h->cfg.max_entries <= kAccountFastMaxEntries && !h->must_evict && !h->exported &&
+    // (a handle that filters its input by shard takes the host-driven loop: the chain counts the records it skips per window, and a
+    // window that ends on "full" is looked at again from the split on)
+    return h->cfg.mode == NFAGG_MODE_ACCOUNTER && h->cfg.n_shards <= 1 && h->cfg.max_entries <= kAccountFastMaxEntries && !h->must_evict && !h->exported &&
            h->cfg.max_entries + epoch_window() + 16 <= h->tv.claim_limit && out_cap >= h->cfg.max_entries &&
            h->epoch_seq - h->seq_origin + n < kSeqWindow - epoch_window() && (h->tv.epoch_bits >> 48) < 0xFFFFull;
 }
@@ -1343,7 +1496,11 @@ int nfagg_account_device(nfagg_handle* h, const void* d_records, size_t n, void*
     if (!h || (!d_records && n) || !epoch_end || !n_epochs || !consumed || (!d_out && out_cap)) return fail(h, NFAGG_EINVAL, "null argument");
     if ((((uintptr_t)d_records | (uintptr_t)d_out) & 15u) != 0) return fail(h, NFAGG_EINVAL, "device buffers must be 16-byte aligned");
     HIP_TRY(h, hipSetDevice(h->device));
-    return account_device_core(h, d_records, n, d_out, out_cap, epoch_end, max_epochs, n_epochs, consumed);
+    const int rc = account_device_core(h, d_records, n, d_out, out_cap, epoch_end, max_epochs, n_epochs, consumed);
+    // synchronous, as the header says: the last launches of the call (k_finalize copies the new flows' identity dwords out of
+    // d_records; a fall-through to the plain fold is asynchronous altogether) have read the caller's buffer when it returns
+    if (rc >= 0) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return rc;
 }
 
 int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, size_t out_cap, uint64_t* epoch_end, size_t max_epochs,
@@ -1388,7 +1545,9 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->stage_up[b], 0));
         const bool more = lo + m < n;
         size_t room = out_cap - out_pos;
-        if (room > m + (size_t)h->cfg.max_entries) room = m + (size_t)h->cfg.max_entries;
+        // a chunk of m records delivers at most max_entries + m flows, and the device loop wants room for one more whole eviction
+        // (max_entries) whenever an epoch ends: with less it would report "no room" although the caller's buffer has some
+        if (room > m + 2 * (size_t)h->cfg.max_entries) room = m + 2 * (size_t)h->cfg.max_entries;
         void** dbuf = ebuf ? &h->d_ep_out : &h->d_evict;
         size_t capb = ebuf ? h->d_ep_out_cap : (size_t)h->d_evict_cap;
         rc = ensure_bytes(h, dbuf, &capb, room * kRecordBytes + 16);

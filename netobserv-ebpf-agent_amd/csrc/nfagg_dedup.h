@@ -59,13 +59,33 @@ NF_DEV bool record_prologue(const TableView& t, const void* recs, uint64_t i, Re
 }
 
 
+// ---- Local fold across GPUs (TableView.subflow; DESIGN.md §7 a'). What a table counts for a flow depends on the flow's first
+// interface F (flows.c:100-126), and with several GPUs folding parts of ONE stream F is the interface of the earliest record
+// ANYWHERE. A table that may not hold a flow's earliest record therefore keeps nothing that depends on F: it is keyed by the
+// SUB-FLOW (flow key, if_index_first_seen) — the sixth key word lives in SlotHot.end, which this mode does not use — and every
+// slot holds BOTH roles of its interface: the sums, "last value" tags and TLS words of a counted interface, and the two earliest
+// directions of a side interface (dir[0]), plus its own first record stored whole. Such slots merge across tables word by word
+// (nfagg_combine.hip); the epoch ends with a join (nfagg_dedup_join.hip): every sub-flow goes through the two phases below
+// into a flow-keyed table, F being the interface of the sub-flow with the smallest first sequence number.
+NF_DEV uint64_t sub_kx(const TableView& t, uint32_t ifx) { return t.subflow ? (1ull << 32) | (uint64_t)ifx : 0ull; }
+// slot hash of a sub-flow: the partition bits (the top 11 bits of the home slot, SpillView.part_shift) stay the FLOW's — the
+// partition pass owns a flow's sub-flows together and its claims stay inside one window of the table — everything else is mixed
+// with the interface.
+NF_DEV uint64_t sub_hash(const TableView& t, uint64_t h, uint32_t ifx) {
+    if (!t.subflow) return h;
+    uint64_t z = (h ^ ((uint64_t)ifx * 0xD6E8FEB86659FD93ull + 0x9E3779B97F4A7C15ull)) * kMul;
+    z ^= z >> 29;
+    const uint64_t pm = (uint64_t)(kSpillParts - 1) << t.spill.part_shift;
+    return (z & ~pm) | (h & pm);
+}
+
 // ---- pass 1 for one (flow, interface): first record + earliest interfaces. `seq32` is the
 // smallest sequence number of the records represented (a single record, or a cached run).
 NF_DEV void dedup_claim(const TableView& t, uint32_t idx, uint64_t id0_hint, uint32_t ifx, uint32_t seq32) {
     const uint32_t inv = ~seq32;
     const uint64_t my0 = tagged(inv, ifx);                      // record dword 21 IS if_index_first_seen
     if (id0_hint < my0) amax(&t.hot[idx].id0, my0);
-    if (ifx != 0) {
+    if (ifx != 0 && !t.subflow) {                               // (a sub-flow slot has one interface: its own)
         // cheap exit on possibly stale plain loads: a word that once held this interface with an
         // earlier-or-equal record makes this record irrelevant for good (see topk_insert)
         const uint64_t* cw = t.aux[idx].cand;
@@ -114,7 +134,8 @@ template <bool COHERENT = false>
 NF_DEV void dedup_merge(const TableView& t, uint32_t idx, const Hints& x, const DedupPartial& p) {
     SlotHot* H = &t.hot[idx];
     SlotAux* A = &t.aux[idx];
-    const uint32_t F = (uint32_t)x.id0;
+    const bool sub = t.subflow != 0;                             // sub-flow slot: its interface plays both roles until the join
+    const uint32_t F = sub ? p.ifx : (uint32_t)x.id0;
     const bool counted = p.ifx == F;
     if (!counted && p.ifx == 0) return;                          // flows.c:126: `else if (if_index != 0)`
     // end = r.end, by the LAST record that reaches either branch (flows.c:108,128)
@@ -134,11 +155,14 @@ NF_DEV void dedup_merge(const TableView& t, uint32_t idx, const Hints& x, const 
         }
         if (p.cs_tag) amax(&A->cs_tag, p.cs_tag);
         if (p.ks_tag) amax(&A->ks_tag, p.ks_tag);
-    } else {
+    }
+    if (!counted || sub) {
         // side records: remember the two earliest distinct directions of their interface
-        int pos = -1;
+        int pos = sub ? 0 : -1;
+        if (!sub) {
 #pragma unroll
-        for (int k = 0; k < kCand; k++) { const uint64_t c = COHERENT ? ald(&A->cand[k]) : A->cand[k]; if (c != 0 && (uint32_t)c == p.ifx) pos = k; }
+            for (int k = 0; k < kCand; k++) { const uint64_t c = COHERENT ? ald(&A->cand[k]) : A->cand[k]; if (c != 0 && (uint32_t)c == p.ifx) pos = k; }
+        }
         if (pos >= 0) {
             uint64_t* dw = A->dir[pos];
             const uint64_t d0 = dw[0], d1 = dw[1];               // stale copies are lower bounds per direction
@@ -170,9 +194,10 @@ NF_DEV void dedup_publish_first(const TableView& t, uint32_t idx, const Rec& r, 
 // ---- the two passes for ONE record, straight on the table (direct kernels; cache misses)
 NF_DEV void dedup_claim_record(const TableView& t, const Rec& r, const uint64_t w[5], uint64_t h, uint32_t seq32) {
     Hints x;
-    uint32_t idx = probe_home(t, w, h, x);
+    const uint64_t kx = sub_kx(t, r.d[21]), hs = sub_hash(t, h, r.d[21]);
+    uint32_t idx = probe_home(t, w, hs, x, kx);
     if (idx == kNoSlot) {
-        idx = find_or_claim(t, w, h);
+        idx = find_or_claim(t, w, hs, nullptr, nullptr, nullptr, kx);
         if (idx == kNoSlot) return;
         x.id0 = 0;
     }
@@ -181,9 +206,10 @@ NF_DEV void dedup_claim_record(const TableView& t, const Rec& r, const uint64_t 
 
 NF_DEV void dedup_fold_record(const TableView& t, const Rec& r, const uint64_t w[5], uint64_t h, uint32_t seq32) {
     Hints x;
-    uint32_t idx = probe_home(t, w, h, x);
+    const uint64_t kx = sub_kx(t, r.d[21]), hs = sub_hash(t, h, r.d[21]);
+    uint32_t idx = probe_home(t, w, hs, x, kx);
     if (idx == kNoSlot) {
-        idx = find_or_claim(t, w, h);          // pass 1 claimed it: this only walks the probe sequence
+        idx = find_or_claim(t, w, hs, nullptr, nullptr, nullptr, kx);          // pass 1 claimed it: this only walks the probe sequence
         if (idx == kNoSlot) return;
         load_hints(&t.hot[idx], x);
     }

@@ -19,6 +19,7 @@
 //   k_dedup_overflow  the (normally empty) overflow list: claims before k_dedup_parts, folds after it.
 // Merging DedupPartials is associative and commutative (sums, ORs, maxima over sequence-tagged words, top-2 over sequence-tagged
 // words), so the result is that of the direct passes: bit-exact vs the oracle's sequential fold.
+#include <atomic>
 #include "nfagg_dedup.h"
 #include "nfagg_spill.h"
 
@@ -254,9 +255,10 @@ NF_DEV void load_item(const SpillView& q, const void* recs, uint32_t it, uint32_
 // ---- straight on the table, for one item (cache misses, overflow list)
 NF_DEV void claim_item(const TableView& t, const Item& x) {
     Hints hx;
-    uint32_t idx = probe_home(t, x.w, x.h, hx);
+    const uint64_t kx = sub_kx(t, x.ifx), hs = sub_hash(t, x.h, x.ifx);      // sub-flow tables (nfagg_dedup.h): keyed by (flow, interface)
+    uint32_t idx = probe_home(t, x.w, hs, hx, kx);
     if (idx == kNoSlot) {
-        idx = find_or_claim(t, x.w, x.h);
+        idx = find_or_claim(t, x.w, hs, nullptr, nullptr, nullptr, kx);
         if (idx == kNoSlot) return;
         hx.id0 = 0;
     }
@@ -280,9 +282,10 @@ NF_DEV void merge_at(const TableView& t, uint32_t idx, const DedupPartial& p, ui
 
 NF_DEV void fold_item(const TableView& t, const Item& x, const void* recs, uint32_t seq_base32) {
     Hints hx;
-    uint32_t idx = probe_home(t, x.w, x.h, hx);
+    const uint64_t kx = sub_kx(t, x.ifx), hs = sub_hash(t, x.h, x.ifx);
+    uint32_t idx = probe_home(t, x.w, hs, hx, kx);
     if (idx == kNoSlot) {
-        idx = find_or_claim(t, x.w, x.h);          // claimed before: this only walks the probe sequence
+        idx = find_or_claim(t, x.w, hs, nullptr, nullptr, nullptr, kx);          // claimed before: this only walks the probe sequence
         if (idx == kNoSlot) return;
     }
     merge_at(t, idx, x.p, x.ms, recs, seq_base32);
@@ -451,15 +454,15 @@ NF_DEV void parts_flush(const TableView& t, FoldCache<kPartEntries>& L, const vo
         uint64_t w[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
-        const uint64_t h = key_hash(w);
+        const uint64_t kx = sub_kx(t, L.ifx[e]), h = sub_hash(t, key_hash(w), L.ifx[e]);
         Hints hx;
         bool fresh = false;
-        idx = probe_home(t, w, h, hx);
+        idx = probe_home(t, w, h, hx, kx);
         if (idx == kNoSlot) {
             // a lane that claims the slot plants its own first-record tag and candidate interface with the slot's first values
             Partial first{};
             first.first_inv = ~L.min_seq[e]; first.ident0 = L.ifx[e];
-            idx = find_or_claim(t, w, h, &fresh, &hx.home_tag, &first);
+            idx = find_or_claim(t, w, h, &fresh, &hx.home_tag, &first, kx);
             hx.id0 = 0;
         }
         if (idx != kNoSlot && !fresh) dedup_claim(t, idx, hx.id0, L.ifx[e], L.min_seq[e]);
@@ -595,11 +598,11 @@ hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records,
                  lds2 = sizeof(FoldCache<kPartEntries>) + sizeof(PartsLds);
     static_assert(sizeof(StreamCache) + sizeof(spill::Stage) + kDoorBits / 8 <= 160 * 1024, "LDS of one CU");
     static_assert(sizeof(FoldCache<kPartEntries>) + sizeof(PartsLds) <= 160 * 1024, "LDS of one CU");
-    static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
+    static std::atomic<bool> attr_set_dev[64];   // per device: a process may drive several GPUs, from several host threads
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
-    bool& attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set) {
+    std::atomic<bool>& attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_parts<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
 #ifdef NFAGG_DIAG
@@ -608,7 +611,7 @@ hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records,
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dedup_parts<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
 #endif
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     const uint64_t tiles = (n + kBlock - 1) / kBlock;
     const unsigned grid = (unsigned)(tiles < (uint64_t)kStreamGrid ? tiles : (uint64_t)kStreamGrid);

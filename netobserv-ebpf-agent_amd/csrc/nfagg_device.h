@@ -130,7 +130,8 @@ NF_DEV void load_hints(const SlotHot* H, Hints& x) {
 // afterwards. Returns the slot when the home slot is `ready` and holds this key
 // (then `x` holds its hints); kNoSlot means "not decided" — the caller runs the
 // coherent find_or_claim loop. Safety of the plain loads: see find_or_claim.
-NF_DEV uint32_t probe_home(const TableView& t, const uint64_t w[5], uint64_t h, Hints& x) {
+// kx != 0: a sixth key word, kept in SlotHot.end (sub-flow tables of the kernel-dedup mode, nfagg_dedup.h; `end` is unused there).
+NF_DEV uint32_t probe_home(const TableView& t, const uint64_t w[5], uint64_t h, Hints& x, uint64_t kx = 0) {
     const uint64_t idx = h & t.mask;
     const uint4* L = reinterpret_cast<const uint4*>(&t.hot[idx]);
     const uint4 a = L[0], b = L[1], c = L[2], l3 = L[3], l4 = L[4], l6 = L[6], l7 = L[7];
@@ -145,7 +146,7 @@ NF_DEV uint32_t probe_home(const TableView& t, const uint64_t w[5], uint64_t h, 
     x.smac_lo = (uint64_t)l7.x | ((uint64_t)l7.y << 32);
     x.dmac_lo = (uint64_t)l7.z | ((uint64_t)l7.w << 32);
     x.home_tag = (uint64_t)a.x | ((uint64_t)a.y << 32);
-    return eq ? (uint32_t)idx : kNoSlot;
+    return (eq & ((kx == 0) | (x.end == kx))) ? (uint32_t)idx : kNoSlot;
 }
 
 // What one record, or a pre-folded run of records of one key, contributes.
@@ -187,9 +188,10 @@ struct Partial {
 // the partial as the slot's first value instead of zeroes — it owns the slot until the tag says `ready` — and reports it in
 // *fresh: the caller skips the merge (12 atomics and 4 hint loads less per new flow; a flush is bound by the number of small
 // coherent operations the chip retires, ~24 G/s).
+// kx != 0: a sixth key word, written to and compared with SlotHot.end (sub-flow tables of the kernel-dedup mode, nfagg_dedup.h).
 template <bool DEFER = false>
 NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t h, bool* fresh = nullptr, const uint64_t* home_tag = nullptr,
-                              const Partial* init = nullptr) {
+                              const Partial* init = nullptr, uint64_t kx = 0) {
     const uint64_t ready = tag_ready(t, h), locked = tag_locked(t, h);
     uint64_t idx = h & t.mask;
     uint64_t probes = 0;
@@ -240,6 +242,7 @@ NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t 
                         if (init->dmac_inv) { v[9] = tagged(init->dmac_inv, (uint32_t)init->dmac); ch[1] = tagged(init->dmac_inv, (uint32_t)(init->dmac >> 32)); }
                         *fresh = true;
                     }
+                    if (kx) v[1] = kx;
                     ast(&hw[1], w[0]);
                     ast16(&hw[2], w[1], w[2]);
                     ast16(&hw[4], w[3], w[4]);
@@ -265,6 +268,7 @@ NF_DEV uint32_t find_or_claim(const TableView& t, const uint64_t w[5], uint64_t 
             bool eq = true;
 #pragma unroll
             for (int k = 0; k < 5; k++) eq &= (ald(&s->key[k]) == w[k]);
+            if (kx) eq &= (ald(&s->end) == kx);
             if (eq) { result = (uint32_t)idx; done = 1; }
             else { idx = (idx + 1) & t.mask; probes++; }
         } else if (tag == locked && !DEFER) {

@@ -18,6 +18,7 @@
 // workgroup sees for that flow (LDS atomic min over sequence numbers; tiles are
 // consumed in increasing sequence order) publishes its identity dwords to HBM
 // itself, and so does the earliest record with a non-zero src/dst MAC.
+#include <atomic>
 #include "nfagg_device.h"
 
 namespace nfagg {
@@ -211,15 +212,15 @@ template <int BLOCK, int K, bool SKETCH, bool TIMING = false>
 static hipError_t run_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,
                              int blocks_per_cu, hipStream_t s) {
     const size_t lds = sizeof(FlowCache<K>);
-    static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
+    static std::atomic<bool> attr_set_dev[64];   // per device: a process may drive several GPUs, from several host threads
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
-    bool& attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set) {
+    std::atomic<bool>& attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ingest_cached<BLOCK, K, SKETCH, TIMING>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     const uint64_t tiles = (n + BLOCK - 1) / BLOCK;
     uint64_t grid = 256ull * blocks_per_cu;

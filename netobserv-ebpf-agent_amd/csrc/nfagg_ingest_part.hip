@@ -23,6 +23,7 @@
 // numbers; the flush gathers the MACs from the batch (still in HBM — the caller owns it
 // until the call returns) and publishes the first record's sequence number, whose
 // identity dwords k_finalize (nfagg_kernels.hip) copies from the batch afterwards.
+#include <atomic>
 #include "nfagg_device.h"
 
 namespace nfagg {
@@ -604,18 +605,18 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
                       uint64_t seq_base, hipStream_t s) {
     const size_t lds1 = sizeof(Cache) + sizeof(Stage) + (DOOR ? sizeof(Door) : 0), lds2 = sizeof(Cache) + sizeof(Pass2Lds);
     static_assert(sizeof(Cache) + sizeof(Stage) + sizeof(Door) <= 160 * 1024, "pass 1 needs the whole LDS of a CU");
-    static bool attr_set_dev[64] = {};   // per device: a process may drive several GPUs
+    static std::atomic<bool> attr_set_dev[64];   // per device: a process may drive several GPUs, from several host threads
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
-    bool& attr_set = attr_set_dev[dev_ & 63];
-    if (!attr_set) {
+    std::atomic<bool>& attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<SKETCH, T1, DOOR, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<SKETCH, T2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     const uint64_t tiles = (n + kBlock - 1) / kBlock;
     // a workgroup's cache pays for itself (set-up, one flush of up to 1024 entries — ~10 small coherent operations each, and the

@@ -131,6 +131,8 @@ struct TableView {
     uint64_t epoch_bits;           // current eviction epoch (1..65535) << 48: the tags of this epoch's slots carry it
     uint32_t n_shards, shard_id;
     uint32_t defer_claims;         // 1: tables of 2^21 slots or more (see nfagg_create)
+    uint32_t subflow;              // kernel-dedup mode of a local-fold rank: the table is keyed by the SUB-FLOW (flow key,
+                                   // if_index_first_seen); SlotHot.end holds the sixth key word (nfagg_dedup.h)
     SpillView spill;               // set by the API for the two-pass fold
 };
 
@@ -194,6 +196,15 @@ hipError_t launch_partition_prefix_counts(const uint32_t* d_orig, const uint64_t
 // launch_export_scatter: d_cursor[o] = first position of segment o in d_out; launch_merge_raw: everything that combines, then
 // the winner's plain identity dwords (t.n_shards / t.shard_id = the merging shard); launch_count_owned: owned flows of t itself.
 constexpr size_t kPartialBytes = 192;
+// Kernel-dedup mode (sub-flow tables, nfagg_dedup.h "local fold"): a partial is one SUB-FLOW's slot — hot line, cold half line and
+// the eight words of the aux lines a sub-flow uses (last end, TLS words, its two earliest directions): 256 bytes.
+constexpr size_t kPartialBytesDedup = 256;
+// d_partials of launch_export_scatter / launch_merge_raw hold kPartialBytesDedup-byte partials when t.subflow is set.
+// The join that ends a sub-flow table's epoch (nfagg_dedup_join.hip): every live sub-flow of S that (n_shards, shard_id) owns is
+// folded into the flow-keyed table J by the two phases of the kernel-dedup merge (claim + first record + earliest interfaces,
+// then update_existing_flow with F final); J is then evicted with launch_evict_dedup. d_slot_of: n_live words of scratch.
+hipError_t launch_subflow_join(const TableView& S, const TableView& J, uint64_t n_live, uint64_t seq_limit, uint32_t n_shards,
+                               uint32_t shard_id, uint32_t* d_slot_of, hipStream_t s);
 hipError_t launch_export_count(const TableView& t, uint64_t n_live, uint64_t seq_limit, uint32_t n_shards, uint32_t self_shard,
                                unsigned long long* d_counts, hipStream_t s);
 hipError_t launch_export_scatter(const TableView& t, uint64_t n_live, uint64_t seq_limit, uint32_t n_shards, uint32_t self_shard,

@@ -3,7 +3,7 @@
 // Replaces the body of Accounter.Account's record arm and Accounter.evict
 // (pkg/flow/account.go:81-96, 102-124). HBM-bound hash/scatter work: no MFMA.
 #include <hipcub/hipcub.hpp>
-#include "nfagg_device.h"
+#include "nfagg_dedup.h"
 
 namespace nfagg {
 
@@ -46,7 +46,9 @@ __global__ __launch_bounds__(256) void k_claim(TableView t, const void* __restri
         r.key_words(w);
         const uint64_t h = key_hash(w);
         if (t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id) { slot_idx[i] = kNoSlot; continue; }
-        const uint32_t idx = find_or_claim(t, w, h);
+        // sub-flow tables (kernel-dedup mode of a local-fold rank, nfagg_dedup.h): the key is (flow, if_index_first_seen)
+        const uint32_t idx = t.subflow ? find_or_claim(t, w, sub_hash(t, h, r.d[21]), nullptr, nullptr, nullptr, sub_kx(t, r.d[21]))
+                                       : find_or_claim(t, w, h);
         slot_idx[i] = idx;
         // plant the first-record tracker (tagged dword 21) so that phase B can find first occurrences
         if (idx != kNoSlot) amax(&t.hot[idx].id0, tagged(~(uint32_t)(seq_base + i), r.d[21]));

@@ -53,7 +53,7 @@ class FlowTable:
 
     def __init__(self, max_entries=5000, device=0, mode=L.MODE_ACCOUNTER, sketches=0, cm_depth=0, cm_log2_width=0,
                  hll_p=0, table_log2_slots=0, staging_records=0, n_shards=1, shard_id=0, profile=False,
-                 ingest_variant=0, ext_sketch=None, copy_threads=0):
+                 ingest_variant=0, ext_sketch=None, copy_threads=0, local_fold=False):
         cfg = L.Config()
         cfg.struct_size = C.sizeof(L.Config)
         cfg.device = device
@@ -67,6 +67,7 @@ class FlowTable:
         cfg.profile = 1 if profile else 0
         cfg.ingest_variant = ingest_variant
         cfg.copy_threads = copy_threads
+        cfg.local_fold = 1 if local_fold else 0       # a rank of a local-fold job (nfagg_partials_*); kernel-dedup mode: sub-flow table
         if ext_sketch:
             for k, p in enumerate(ext_sketch):
                 cfg.ext_sketch[k] = p
@@ -396,8 +397,13 @@ class FlowTable:
     def set_sequence(self, next_seq: int):
         self._check(L.lib.nfagg_set_sequence(self._h, next_seq))
 
+    @property
+    def partial_bytes(self) -> int:
+        """nfagg_partial_bytes: 192, or 256 for the sub-flow partials of a kernel-dedup handle."""
+        return int(L.lib.nfagg_partial_bytes(self._h))
+
     def partials_export_device(self, n_shards: int, self_shard: int, d_out: int, cap: int):
-        """The live flows as 192-byte partials grouped by owner shard, into device memory at d_out (room for cap partials).
+        """The live flows as partials of partial_bytes grouped by owner shard, into device memory at d_out (room for cap partials).
         Returns (rc, counts[n_shards], n): rc TRUNCATED = nothing written, n partials needed."""
         counts = (C.c_uint64 * n_shards)()
         n = C.c_size_t(0)

@@ -28,9 +28,12 @@ def test_c_driver_builds_and_needs_only_libnfagg_and_hip(nf, driver):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("max_entries,batch,how", [(1 << 16, 70_000, ""), (700, 5_000, ""), (700, 40_000, "account"), (1 << 16, 70_000, "account")])
+@pytest.mark.parametrize("max_entries,batch,how", [(1 << 16, 70_000, ""), (700, 5_000, ""), (700, 40_000, "account"), (1 << 16, 70_000, "account"),
+                                                   (1 << 16, 30_000, "ring"), (700, 5_000, "ring")])
 def test_c_driver_matches_oracle(nf, O, driver, tmp_path, max_entries, batch, how):
-    """how = "account": nfagg_account from / into nfagg_host_alloc buffers (the cgo shim's flush), else nfagg_ingest + nfagg_evict."""
+    """how = "account": nfagg_account from / into nfagg_host_alloc buffers (the cgo shim's flush); "ring": the records come out of a
+    BPF-style ring buffer (discarded and wrong-length samples in between) through nfagg_staging_acquire -> nfagg_ringbuf_drain ->
+    nfagg_staging_commit; else nfagg_ingest + nfagg_evict."""
     th = O.zipf_thresholds(4000, 1.1)
     recs = O.gen_stream(150_000, seed=17, n_keys=4000, thresholds=th, variant=1)
     recs["metrics"]["if_index_first_seen"] = 2 + (np.arange(len(recs)) % 3)           # eth0 / eth1+udn / unknown

@@ -118,7 +118,9 @@ def test_local_fold_truncated_eviction_is_repeatable(nf, O):
         assert grp.ingest(recs.view(nf.FLOW_RECORD)[:10]) == (nf.OK, 10)
 
 
-def test_local_fold_rejects_kernel_dedup_mode(nf):
-    with pytest.raises(nf.NfaggError) as ei:
-        nf.FlowGroup([0, 0], mode=nf.MODE_KERNEL_DEDUP, local_fold=True)
-    assert "NFAGG_MODE_ACCOUNTER" in str(ei.value)
+def test_local_fold_accepts_kernel_dedup_mode(nf):
+    """Round 4: the members of a kernel-dedup local-fold group are sub-flow tables (tests/test_dedup_local_fold_gpu.py)."""
+    with nf.FlowGroup([0, 0], mode=nf.MODE_KERNEL_DEDUP, local_fold=True) as grp:
+        assert [m.partial_bytes for m in grp.members] == [256, 256]
+    with nf.FlowGroup([0, 0], mode=nf.MODE_KERNEL_DEDUP) as grp:       # routed: flow-keyed members
+        assert [m.partial_bytes for m in grp.members] == [192, 192]

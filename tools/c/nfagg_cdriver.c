@@ -7,7 +7,11 @@
  *   stdout        : one line per eviction "reason n_flows", then "hll_src <estimate>" when sketches are on.
  * With a sixth argument "account" the batches go through nfagg_account instead — the evict-on-full loop runs inside the library —
  * from / into page-locked buffers (nfagg_host_alloc): the control flow of INTEGRATION.md section 3's GPUAccounter.flush.
- * usage: nfagg_cdriver <records.bin> <out-prefix> <max_entries> <batch_records> <sketches 0|1> [account]
+ * With "ring" instead, the records reach the library the way the agent's RingBufTracer would hand them over in batches
+ * (pkg/flow/tracer_ringbuf.go:112-134): a producer puts them into a BPF-style ring buffer — with discarded and wrong-length
+ * samples in between, wrapping around the data area — and the consumer loop is nfagg_staging_acquire -> nfagg_ringbuf_drain
+ * (straight into the pinned staging buffer) -> nfagg_staging_commit, with the same evict-on-full handling.
+ * usage: nfagg_cdriver <records.bin> <out-prefix> <max_entries> <batch_records> <sketches 0|1> [account|ring]
  *   cc -std=c11 -O2 -I include tools/c/nfagg_cdriver.c -o nfagg_cdriver -L <libdir> -lnfagg -Wl,-rpath,<libdir> */
 #include <inttypes.h>
 #include <stdio.h>
@@ -20,9 +24,29 @@ static void die(nfagg_handle* h, const char* what, int rc) {
     exit(2);
 }
 
+/* ---- a BPF_MAP_TYPE_RINGBUF as the kernel leaves it in memory (kernel/bpf/ringbuf.c): 8-byte header {len | flags, pad}, data
+ * padded to 8 bytes; the producer side of the "ring" mode */
+#define RB_SIZE (1u << 16)
+#define RB_DISCARD 0x40000000u
+static uint8_t rb_data[RB_SIZE];
+static volatile uint64_t rb_prod, rb_cons;
+static int rb_push(const void* payload, uint32_t len, uint32_t flags) {
+    const uint32_t total = 8 + ((len + 7u) & ~7u);
+    if (rb_prod - rb_cons + total > RB_SIZE) return 0;           /* no room: the consumer must drain first */
+    uint8_t blob[8 + 160];
+    memset(blob, 0, sizeof blob);
+    const uint32_t hdr = len | flags;
+    memcpy(blob, &hdr, 4);
+    memcpy(blob + 8, payload, len);
+    for (uint32_t k = 0; k < total; k++) rb_data[(rb_prod + k) & (RB_SIZE - 1)] = blob[k];
+    rb_prod += total;
+    return 1;
+}
+
 int main(int argc, char** argv) {
-    if (argc != 6 && argc != 7) { fprintf(stderr, "usage: %s records.bin out-prefix max_entries batch sketches [account]\n", argv[0]); return 1; }
+    if (argc != 6 && argc != 7) { fprintf(stderr, "usage: %s records.bin out-prefix max_entries batch sketches [account|ring]\n", argv[0]); return 1; }
     const int account = argc == 7 && strcmp(argv[6], "account") == 0;
+    const int ring = argc == 7 && strcmp(argv[6], "ring") == 0;
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 1; }
     fseek(f, 0, SEEK_END);
@@ -42,6 +66,7 @@ int main(int argc, char** argv) {
     cfg.struct_size = sizeof cfg;
     cfg.max_entries = max_entries;
     cfg.sketch_flags = sketches ? (NFAGG_SKETCH_CM | NFAGG_SKETCH_HLL) : 0;
+    if (ring) cfg.staging_records = batch;                       /* the pinned staging buffer takes one drain */
     nfagg_handle* h = 0;
     int rc = nfagg_create(&cfg, &h);
     if (rc != NFAGG_OK) die(0, "nfagg_create", rc);
@@ -68,6 +93,43 @@ int main(int argc, char** argv) {
             printf("full %zu\n", (size_t)(epoch_end[e] - lo));
             lo = epoch_end[e];
         }
+    }
+    if (ring) {
+        rb_prod = rb_cons = (uint64_t)RB_SIZE * 5 - 200;         /* the first samples wrap around the data area */
+        const nfagg_ringbuf rb = {rb_data, RB_SIZE - 1, &rb_prod, &rb_cons};
+        size_t produced = 0, skipped_total = 0, injected = 0;
+        nfagg_flow_record* rest = malloc((batch ? batch : 1) * sizeof *rest);
+        while (produced < n || rb_prod != rb_cons) {
+            while (produced < n) {                               /* the kernel side: fill the ring */
+                const uint8_t junk[24] = {1, 2, 3};
+                if (produced % 11 == 5 && (injected & 1) == 0) { if (!rb_push(junk, 24, 0)) break; injected |= 1; }               /* wrong length */
+                if (produced % 13 == 7 && (injected & 2) == 0) { if (!rb_push(recs + produced, 144, RB_DISCARD)) break; injected |= 2; }  /* discarded */
+                if (!rb_push(recs + produced, 144, 0)) break;
+                produced++; injected = 0;
+            }
+            for (;;) {                                           /* the agent side: drain straight into the staging buffer */
+                void* buf = 0; size_t cap = 0, got = 0, skipped = 0, consumed = 0;
+                if ((rc = nfagg_staging_acquire(h, &buf, &cap)) != NFAGG_OK) die(h, "nfagg_staging_acquire", rc);
+                if ((rc = nfagg_ringbuf_drain(&rb, buf, cap, &got, &skipped, 0)) != NFAGG_OK) die(h, "nfagg_ringbuf_drain", rc);
+                skipped_total += skipped;
+                memcpy(rest, buf, got * sizeof *rest);            /* only needed when the commit stops on full */
+                rc = nfagg_staging_commit(h, got, &consumed);
+                if (rc < 0) die(h, "nfagg_staging_commit", rc);
+                size_t at = consumed;
+                while (rc == NFAGG_FULL) {                       /* account.go:85-94: evict, then resubmit the rest */
+                    if ((rc = nfagg_evict(h, NFAGG_REASON_FULL, out, (size_t)max_entries, &n_out)) != NFAGG_OK) die(h, "nfagg_evict(full)", rc);
+                    fwrite(out, sizeof *out, n_out, fo);
+                    printf("full %zu\n", n_out);
+                    rc = nfagg_ingest(h, rest + at, got - at, &consumed);
+                    if (rc < 0) die(h, "nfagg_ingest", rc);
+                    at += consumed;
+                }
+                if (got < cap) break;                            /* ring empty */
+            }
+        }
+        fprintf(stderr, "ring: %zu samples skipped (discarded / wrong length)\n", skipped_total);
+        free(rest);
+        off = n;
     }
     while (off < n) {                                            /* the record arm of Accounter.Account, batched */
         const size_t m = n - off < batch ? n - off : batch;
