@@ -496,29 +496,17 @@ def cpu_baseline(args, d_recs, n, max_entries):
         "sample": "first %d records of rank 0's stream (%d flows), oracle Accounter ingest+evict, %.1f s" % (m, len(ev), cpu_dt),
         "host_cores_available": os.cpu_count(),
     }
-    # best-effort multi-core variant of the same restatement: the sample split by a key hash
-    # over T workers, one oracle Accounter each (ctypes releases the GIL). The reference itself is one goroutine.
-    if not args.dedup:
-        import threading
-        T = max(2, min(32, (os.cpu_count() or 2) // 2))
-        accs = [O.Accounter(max_entries, 0) for _ in range(T)]
-        got = [0] * T
-
-        def work(k):
-            got[k] = accs[k].ingest_shard(sample, T, k)
-            got[k] = (got[k], len(accs[k].evict()))
-        t1 = time.perf_counter()
-        ths = [threading.Thread(target=work, args=(k,)) for k in range(T)]
-        for t_ in ths:
-            t_.start()
-        for t_ in ths:
-            t_.join()
-        mc_dt = time.perf_counter() - t1
-        for a_ in accs:
-            a_.close()
-        assert sum(g[0] for g in got) == m and sum(g[1] for g in got) == len(ev)
-        res["multicore"] = {"value": round(m / mc_dt / 1e6, 3), "unit": "Mrecords/s", "cores": T, "kind": "port",
-                            "sample": "same sample, key-hash split over %d threads, %.1f s" % (T, mc_dt)}
+    # best-effort multi-core variant of the same restatement: PARTITION, THEN FOLD (oracle/nfagg_oracle_mt.c) —
+    # T threads hash and bucket their contiguous slices of the sample by key shard (indices, arrival order kept), then thread k
+    # folds shard k through the same Accounter code. Both phases are timed; every record is looked at by one partitioner and one
+    # folder. (Round 3 let every thread scan the whole sample and skip (T-1)/T of it.) The reference itself is one goroutine.
+    T = max(2, min(64, (os.cpu_count() or 2) // 2))
+    folded, mc_flows, part_s, fold_s = O.partition_fold_mt(sample, T, max_entries, 1 if args.dedup else 0)
+    assert folded == m and mc_flows == len(ev), (folded, m, mc_flows, len(ev))
+    res["multicore"] = {"value": round(m / (part_s + fold_s) / 1e6, 3), "unit": "Mrecords/s", "cores": T, "kind": "port",
+                        "what": "partition-then-fold: %d threads bucket their slices by key shard, then fold one shard each (oracle/nfagg_oracle_mt.c)" % T,
+                        "partition_s": round(part_s, 4), "fold_s": round(fold_s, 4),
+                        "sample": "same sample, %.2f s" % (part_s + fold_s)}
     return res
 
 
@@ -658,6 +646,27 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
             dt = time.perf_counter() - t0
             res["ingest_evict_loop_device_resident" if dev else "ingest_evict_loop_host_path"] = {
                 "ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m3 / dt / 1e6, 1), "evictions": evs, "evicted_flows": int(flows), "us_per_epoch": round(dt / evs * 1e6, 1)}
+    # the CPU side of the same leg: the oracle Accounter (1 core) over the same m2 records with evict-on-full at 5000 entries — a
+    # 5000-entry map lives in the CPU's L1/L2: the CPU's best case, the GPU's worst (pkg/config/config.go:146 is the default)
+    try:
+        from oracle import oracle as O
+        O.build()
+        acc = O.Accounter(5000, 0)
+        raw = host[:m2].view(np.uint8).reshape(-1)
+        t0 = time.perf_counter()
+        off, evs, cflows = 0, 0, 0
+        while off < m2:
+            off += acc.ingest(raw[off * 144:])
+            if off < m2:
+                cflows += len(acc.evict()); evs += 1
+        cflows += len(acc.evict()); evs += 1
+        dt = time.perf_counter() - t0
+        acc.close()
+        res["cpu_oracle_1_core"] = {"ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m2 / dt / 1e6, 1), "evictions": evs, "evicted_flows": int(cflows),
+                                    "us_per_epoch": round(dt / evs * 1e6, 1), "kind": "port", "cores": 1,
+                                    "what": "oracle/nfagg_oracle.c Accounter (C restatement of pkg/flow/account.go:58-124), same records, evict-on-full at 5000"}
+    except Exception as exc:
+        res["cpu_oracle_1_core"] = {"error": repr(exc)[:200]}
     ex["cache_max_flows_5000"] = {"what": "CACHE_MAX_FLOWS = 5000 (the reference's default), configs[1] stream, evict-on-full (account.go:85-94) every ~%d records: "
                                           "nfagg_account[_device] (%d M records; the loop runs on the device) and the caller-driven nfagg_ingest / nfagg_evict loop (%d M records)"
                                           % (m2 // max(res["account_host_path"]["evictions"], 1), m2 // 1_000_000, m3 // 1_000_000), **res}

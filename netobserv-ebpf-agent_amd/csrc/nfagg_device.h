@@ -53,7 +53,12 @@ typedef unsigned int nf_u32x4 __attribute__((ext_vector_type(4)));
 NF_DEV void ast16(void* p, uint64_t lo, uint64_t hi) {
     nf_u32x4 v;
     v.x = (unsigned int)lo; v.y = (unsigned int)(lo >> 32); v.z = (unsigned int)hi; v.w = (unsigned int)(hi >> 32);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    // The hazard pad is INSIDE the string: hipcc treats an asm statement as one opaque instruction and does not know that it is a
+    // 128-bit store, so it neither delays the next write to v[] (gfx940+: a VALU write to the data registers of a store of more
+    // than 64 bits needs 2 wait states) nor keeps the registers out of reuse. Round 4 found out the hard way: a change elsewhere
+    // moved the register allocation, the claimer's key word 3 went out as the address computed for its NEXT store into the same
+    // registers, and ~3 % of the fresh slots carried a key that no record has (tools/exp/dedup_anatomy.py, profiles/r04_ast16_hazard.txt).
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
 
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;

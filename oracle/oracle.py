@@ -15,7 +15,7 @@ _SO = os.path.join(_HERE, "libnfagg_oracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("nfagg_oracle.c", "nfagg_oracle_pb.c", "nfagg_oracle_maps.c", "nfagg_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("nfagg_oracle.c", "nfagg_oracle_pb.c", "nfagg_oracle_maps.c", "nfagg_oracle_mt.c", "nfagg_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=sys.stderr)   # never on stdout: bench.py prints one JSON line there
     return _SO
@@ -42,6 +42,7 @@ def lib():
             "orc_acc_ingest": (_sz, [_vp, _vp, _sz]), "orc_acc_len": (_sz, [_vp]),
             "orc_acc_evict": (_sz, [_vp, _vp, _sz]),
             "orc_acc_ingest_shard": (_sz, [_vp, _vp, _sz, C.c_uint32, C.c_uint32]),
+            "orc_partition_fold_mt": (_sz, [_vp, _sz, C.c_uint32, _u64, C.c_int, C.POINTER(_sz), C.POINTER(C.c_double)]),
             "orc_record_times": (None, [C.c_int64, _u64, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
             "orc_key_hash": (_u64, [_vp]), "orc_ip_hash": (_u64, [_vp, C.c_uint32]),
             "orc_shard_of": (C.c_uint32, [_vp, C.c_uint32]),
@@ -160,6 +161,15 @@ def run_accounter(records, max_entries, mode=0):
     out.append(("closing", acc.evict()))
     acc.close()
     return out
+
+
+def partition_fold_mt(records, threads, max_entries, mode=0):
+    """nfagg_oracle_mt.c: (records folded, distinct flows, partition seconds, fold seconds) on `threads` cores."""
+    r = np.ascontiguousarray(records)
+    flows = C.c_size_t(0)
+    secs = (C.c_double * 2)()
+    folded = lib().orc_partition_fold_mt(_p(r), r.nbytes // 144, threads, max_entries, mode, C.byref(flows), secs)
+    return folded, flows.value, secs[0], secs[1]
 
 
 def gen_stream(n, j0=0, seed=1, n_keys=1000, thresholds=None, hot_permille=0, variant=0, pop_index=None):
