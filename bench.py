@@ -216,7 +216,7 @@ def rank_main(args):
     cm_t = hll_t = None
     if sketches:
         cm_t = [torch.zeros(4 << 20, dtype=torch.int64, device="cuda") for _ in range(2)]
-        hll_t = [torch.zeros(1 << 14, dtype=torch.int32, device="cuda") for _ in range(2)]
+        hll_t = [torch.zeros(1 << 14, dtype=torch.uint8, device="cuda") for _ in range(2)]     # one byte per register: a 16 KiB all-reduce
         ext = [cm_t[0].data_ptr(), cm_t[1].data_ptr(), hll_t[0].data_ptr(), hll_t[1].data_ptr()]
         torch.cuda.synchronize()
     tab = nf.FlowTable(max_entries=max_entries, device=local_rank, sketches=sk_flags, profile=True,
@@ -417,7 +417,7 @@ def rank_main(args):
                     "partial_bytes": PARTIAL_BYTES,
                     "routed_bytes_per_step_rank0": int(phase.get("partials_sent", 0)) * PARTIAL_BYTES,
                     "routed_bytes_if_records_were_routed": int(n * (world - 1) / world) * 144,
-                    "sketch_allreduce_bytes": (2 * (4 << 20) * 8 + 2 * (1 << 14) * 4) if sketches else 0,
+                    "sketch_allreduce_bytes": (2 * (4 << 20) * 8 + 2 * (1 << 14)) if sketches else 0,
                 }
         ev_ms = st.evict_kernel_ms / max(st.evict_launches, 1)
         if ev_ms > 0 and not args.dedup and not local_fold:
@@ -479,9 +479,36 @@ def rank_main(args):
     return 0
 
 
-def cpu_baseline(args, d_recs, n, max_entries):
+def _oracle():
+    """The CPU oracle, for the cpu_baseline legs only (never the thing measured as the product, never shipped)."""
     from oracle import oracle as O
     O.build()
+    return O
+
+
+def cpu_baseline_small_table(host_records, max_entries):
+    """cpu_baseline at the reference's default CACHE_MAX_FLOWS: the oracle Accounter (1 core) over the same records as
+    extra.cache_max_flows_5000, evicting on full exactly as account.go:85-94 does."""
+    O = _oracle()
+    m2 = len(host_records)
+    acc = O.Accounter(max_entries, 0)
+    raw = host_records.view(np.uint8).reshape(-1)
+    t0 = time.perf_counter()
+    off, evs, cflows = 0, 0, 0
+    while off < m2:
+        off += acc.ingest(raw[off * 144:])
+        if off < m2:
+            cflows += len(acc.evict()); evs += 1
+    cflows += len(acc.evict()); evs += 1
+    dt = time.perf_counter() - t0
+    acc.close()
+    return {"ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m2 / dt / 1e6, 1), "evictions": evs, "evicted_flows": int(cflows),
+            "us_per_epoch": round(dt / evs * 1e6, 1), "kind": "port", "cores": 1,
+            "what": "oracle/nfagg_oracle.c Accounter (C restatement of pkg/flow/account.go:58-124), same records, evict-on-full at %d" % max_entries}
+
+
+def cpu_baseline(args, d_recs, n, max_entries):
+    O = _oracle()
     m = min(args.cpu_sample, n)
     sample = d_recs[: m * 144].cpu().numpy()
     acc = O.Accounter(max_entries, 1 if args.dedup else 0)
@@ -510,19 +537,40 @@ def cpu_baseline(args, d_recs, n, max_entries):
     return res
 
 
+def leg_traffic(leg, records_per_call):
+    """HBM bytes per ingest call of an extra leg, from the PMC passes of the same workload committed under profiles/ (newest file
+    whose "leg" and records_per_call match; tools/profile_bench.sh + tools/summarize_prof.py). None when there is none."""
+    import glob
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(tf))
+        except Exception:
+            continue
+        if tj.get("leg") == leg and tj.get("records_per_call") == int(records_per_call) and tj.get("traffic_bytes_per_call"):
+            return int(tj["traffic_bytes_per_call"]), os.path.relpath(tf, ROOT)
+    return None, None
+
+
 def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
     """The legs next to the headline, measured in the same run (bounded: a few seconds in all). Every block: what ran, ms per
     step, records/s, and — where one kernel family dominates — its HIP-event time per call against SURVEY §8(d)'s bytes and
     against the stream floor (the 144-byte records alone)."""
     ex = {}
 
-    def device_leg(name, mode, sk, variant, hot, what, steps=3):
-        gen_stream(variant, hot)
+    def device_leg(name, mode, sk, variant, hot, what, steps=3, n_keys=0, max_entries=DEFAULT_MAX_ENTRIES):
+        if n_keys:                                   # another population than the headline's (thresholds are per population size)
+            th_k = synth.zipf_thresholds(n_keys, args.zipf)
+            d_th_k = torch.from_numpy(th_k.view(np.int64)).cuda()
+            synth.stream_device(d_recs.data_ptr(), n, j0=0, seed=2, n_keys=n_keys, d_thresholds=d_th_k.data_ptr(), hot_permille=hot, variant=variant)
+            torch.cuda.synchronize()
+            del d_th_k
+        else:
+            gen_stream(variant, hot)
         cm_t = [torch.zeros(4 << 20, dtype=torch.int64, device="cuda") for _ in range(2)] if sk else None
-        hll_t = [torch.zeros(1 << 14, dtype=torch.int32, device="cuda") for _ in range(2)] if sk else None
+        hll_t = [torch.zeros(1 << 14, dtype=torch.uint8, device="cuda") for _ in range(2)] if sk else None
         ext = [cm_t[0].data_ptr(), cm_t[1].data_ptr(), hll_t[0].data_ptr(), hll_t[1].data_ptr()] if sk else None
         torch.cuda.synchronize()
-        with nf.FlowTable(max_entries=DEFAULT_MAX_ENTRIES, device=torch.cuda.current_device(), sketches=(nf.SKETCH_CM | nf.SKETCH_HLL) if sk else 0,
+        with nf.FlowTable(max_entries=max_entries, device=torch.cuda.current_device(), sketches=(nf.SKETCH_CM | nf.SKETCH_HLL) if sk else 0,
                           profile=True, mode=mode, ext_sketch=ext) as tab:
             def one():
                 rc, c = tab.ingest_device(d_recs.data_ptr(), n)
@@ -541,11 +589,19 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
             st = tab.stats()
         k_ms = (st.ingest_kernel_ms + st.sketch_kernel_ms) / max(st.ingest_launches, 1)
         alg = ALG_BYTES_INGEST + (ALG_BYTES_SKETCH if sk else 0)
+        # Yardsticks. SURVEY §8(d)'s model (392 / 522 B per record: a slot read + write per record) is what the headline's
+        # roofline.achieved uses; a design that folds in LDS never moves those bytes, so on these legs the model can exceed the
+        # peak — it is reported as a RATE (alg_model_GBs), not as a fraction of a bound. The fractions are of things that are
+        # bounds: the 144-byte records read once (frac_stream_floor) and the HBM bytes the counters saw (frac_traffic, from the
+        # PMC passes of this leg under profiles/).
+        tb, tsrc = leg_traffic(name, n)
         ex[name] = {"what": what, "steps": steps, "ms_per_step": round(dt * 1e3, 3), "Mrecords_per_s": round(n / dt / 1e6, 1),
                     "evicted_flows_per_step": int(flows), "ingest_call_ms": round(k_ms, 4),
-                    "frac": round(alg * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
+                    "alg_bytes_per_record": alg,
+                    "alg_model_GBs": round(alg * n / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
                     "frac_stream_floor": round(144 * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
-                    "alg_bytes_per_record": alg}
+                    "traffic_bytes_per_launch": tb, "traffic_source": tsrc,
+                    "frac_traffic": round(tb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (tb and k_ms > 0) else None}
 
     device_leg("configs2", nf.MODE_ACCOUNTER, True, 0, 0,
                "configs[2]: the configs[1] stream + Count-Min(d=4,w=2^20) + HLL(p=14) per src/dst IP, one ingest call + eviction per step, device-resident")
@@ -555,6 +611,19 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
     device_leg("dedup_zipf", nf.MODE_KERNEL_DEDUP, False, 2, 0,
                "the configs[1] stream with every flow seen on two interfaces (stream variant 2), NFAGG_MODE_KERNEL_DEDUP, one ingest call + "
                "eviction per step, device-resident")
+
+    if n >= 50_000_000:
+        # the many-flow regime: what configs[3]'s local fold puts every rank in (5.4 M of 10 M flows seen per rank at N = 8)
+        d_big = torch.empty((10_000_000 + 4096) * 144 + 16, dtype=torch.uint8, device="cuda")
+        keep_out = d_out
+        d_out = d_big
+        try:
+            device_leg("flows_10m", nf.MODE_ACCOUNTER, False, 0, 0,
+                       "the same number of records over 10 M unique flows (Zipf 1.1), hash-aggregate only, one ingest call + eviction per step, "
+                       "device-resident: the regime of one rank of configs[3]", n_keys=10_000_000, max_entries=1 << 24)
+        finally:
+            d_out = keep_out
+            del d_big
 
     # ---- host path (PCIe-inclusive): the route the cgo shim takes. 20 M records from pageable host memory through
     # nfagg_ingest (pinned double-buffered ring, H2D on its own stream) + nfagg_evict (records back to host memory)
@@ -591,6 +660,59 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
     ex["e2e_page_locked"] = {"what": "the same from / into page-locked caller buffers (nfagg_host_alloc): no host copy into the staging ring",
                              "ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m / dt / 1e6, 1), "GBs_host_to_device": round(m * 144 / dt / 1e9, 1),
                              "evicted_flows": int(flows_p), "bound": "PCIe Gen5 x16"}
+
+    # ---- ring buffer -> pinned staging -> fold -> evict: the agent's own entry (pkg/flow/tracer_ringbuf.go:112-134 reads ONE sample,
+    # decodes it with reflection and sends it down a channel; here nfagg_ringbuf_drain copies every committed sample of the BPF ring
+    # straight into the buffer nfagg_staging_acquire lent out, nfagg_staging_commit sends it up and folds it while the next drain
+    # runs). A synthetic producer refills a 64 MiB ring between the consumer's turns; only the consumer's time is counted.
+    try:
+        import ctypes as C
+        Lb = nf._lib
+        m_r = min(8_000_000, m)
+        flat = np.zeros((m_r, 152), dtype=np.uint8)
+        flat[:, 0] = 144                                                  # sample header: len = 144, flags 0, 4 bytes of padding
+        flat[:, 8:] = host[:m_r].view(np.uint8).reshape(m_r, 144)
+        flat = flat.reshape(-1)
+        ring_bytes = 1 << 26
+        ring = np.zeros(ring_bytes, dtype=np.uint8)
+        prod, cons = np.zeros(1, dtype=np.uint64), np.zeros(1, dtype=np.uint64)
+        rb = Lb.RingBuf(ring.ctypes.data, ring_bytes - 1, prod.ctypes.data, cons.ctypes.data)
+        with nf.FlowTable(max_entries=DEFAULT_MAX_ENTRIES, device=torch.cuda.current_device()) as tab:
+            def ring_pass():
+                prod[0] = cons[0] = 152 * 1000 + 72                       # samples wrap around the data area somewhere
+                k, t_cons, drains = 0, 0.0, 0
+                n_c, sk_c, cap_c, buf_c, took = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_void_p(), C.c_size_t(0)
+                while k < m_r or int(prod[0]) != int(cons[0]):
+                    take = min(m_r - k, (ring_bytes - int(prod[0] - cons[0])) // 152)
+                    if take:                                              # the kernel side (not timed)
+                        pos, nb = int(prod[0]) & (ring_bytes - 1), take * 152
+                        first = min(nb, ring_bytes - pos)
+                        ring[pos:pos + first] = flat[k * 152:k * 152 + first]
+                        ring[:nb - first] = flat[k * 152 + first:k * 152 + nb]
+                        prod[0] += nb
+                        k += take
+                    t0 = time.perf_counter()
+                    while True:                                           # the agent side
+                        assert Lb.lib.nfagg_staging_acquire(tab._h, C.byref(buf_c), C.byref(cap_c)) == nf.OK
+                        assert Lb.lib.nfagg_ringbuf_drain(C.byref(rb), buf_c, cap_c.value, C.byref(n_c), C.byref(sk_c), None) == nf.OK
+                        assert Lb.lib.nfagg_staging_commit(tab._h, n_c.value, C.byref(took)) == nf.OK and took.value == n_c.value
+                        drains += 1
+                        if n_c.value < cap_c.value:
+                            break
+                    t_cons += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                fl = len(tab.evict(nf.REASON_TIMEOUT, out=h_flows))
+                return t_cons + time.perf_counter() - t0, fl, drains
+            ring_pass()
+            dt, fl, drains = ring_pass()
+        ex["e2e_ring"] = {"what": "BPF-style ring buffer (64 MiB, refilled by a synthetic producer that is not timed) -> nfagg_staging_acquire -> "
+                                  "nfagg_ringbuf_drain straight into the pinned staging buffer -> nfagg_staging_commit (H2D + fold, asynchronous) -> "
+                                  "nfagg_evict to host memory: %d M records, consumer time only" % (m_r // 1_000_000),
+                          "ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m_r / dt / 1e6, 1), "drains": drains, "evicted_flows": int(fl),
+                          "bound": "host cores copying 144-byte samples out of the ring into the pinned buffer (nfagg_ringbuf_drain: runs of plain samples over 4 threads), then PCIe"}
+        del flat, ring
+    except Exception as exc:
+        ex["e2e_ring"] = {"error": repr(exc)[:300]}
 
     # ---- the reference's default CACHE_MAX_FLOWS = 5000 (pkg/config/config.go:146): the stream stops on "full" every few
     # thousand records. nfagg_account runs that loop on the device (one persistent kernel per staged chunk); next to it the
@@ -646,25 +768,10 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
             dt = time.perf_counter() - t0
             res["ingest_evict_loop_device_resident" if dev else "ingest_evict_loop_host_path"] = {
                 "ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m3 / dt / 1e6, 1), "evictions": evs, "evicted_flows": int(flows), "us_per_epoch": round(dt / evs * 1e6, 1)}
-    # the CPU side of the same leg: the oracle Accounter (1 core) over the same m2 records with evict-on-full at 5000 entries — a
-    # 5000-entry map lives in the CPU's L1/L2: the CPU's best case, the GPU's worst (pkg/config/config.go:146 is the default)
+    # the CPU side of the same leg (cpu_baseline_small_table, next to cpu_baseline): a 5000-entry map lives in the CPU's L1/L2 —
+    # the CPU's best case, the GPU's worst (pkg/config/config.go:146 is the default)
     try:
-        from oracle import oracle as O
-        O.build()
-        acc = O.Accounter(5000, 0)
-        raw = host[:m2].view(np.uint8).reshape(-1)
-        t0 = time.perf_counter()
-        off, evs, cflows = 0, 0, 0
-        while off < m2:
-            off += acc.ingest(raw[off * 144:])
-            if off < m2:
-                cflows += len(acc.evict()); evs += 1
-        cflows += len(acc.evict()); evs += 1
-        dt = time.perf_counter() - t0
-        acc.close()
-        res["cpu_oracle_1_core"] = {"ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m2 / dt / 1e6, 1), "evictions": evs, "evicted_flows": int(cflows),
-                                    "us_per_epoch": round(dt / evs * 1e6, 1), "kind": "port", "cores": 1,
-                                    "what": "oracle/nfagg_oracle.c Accounter (C restatement of pkg/flow/account.go:58-124), same records, evict-on-full at 5000"}
+        res["cpu_oracle_1_core"] = cpu_baseline_small_table(host[:m2], 5000)
     except Exception as exc:
         res["cpu_oracle_1_core"] = {"error": repr(exc)[:200]}
     ex["cache_max_flows_5000"] = {"what": "CACHE_MAX_FLOWS = 5000 (the reference's default), configs[1] stream, evict-on-full (account.go:85-94) every ~%d records: "

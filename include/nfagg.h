@@ -208,7 +208,7 @@ enum {
 enum {
     NFAGG_CM_SRC  = 0,   /* uint64_t[cm_depth << cm_log2_width] */
     NFAGG_CM_DST  = 1,
-    NFAGG_HLL_SRC = 2,   /* uint8_t [1 << hll_p] in snapshots; uint32_t on device */
+    NFAGG_HLL_SRC = 2,   /* uint8_t [1 << hll_p], on the device and in snapshots */
     NFAGG_HLL_DST = 3,
 };
 
@@ -242,8 +242,8 @@ typedef struct nfagg_config {
                                     there); others are A/B and diagnostic builds, see DESIGN.md §4.1b */
     /* Optional caller-owned DEVICE buffers for the sketches (so that another
      * library, e.g. RCCL via torch.distributed, can all-reduce them in place).
-     * NULL -> the library allocates. Sizes as listed under NFAGG_CM_* above,
-     * HLL buffers hold uint32_t registers. */
+     * NULL -> the library allocates. Sizes as listed under NFAGG_CM_* above
+     * (HLL: one byte per register, buffer 4-byte aligned). */
     void*    ext_sketch[4];
     uint32_t copy_threads;       /* host threads that copy a caller buffer into the pinned staging ring in
                                     nfagg_ingest (one core moves ~28 GB/s, PCIe Gen5 x16 takes ~50); 0 -> 4, 1 -> inline */
@@ -402,6 +402,24 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
 int nfagg_account_device(nfagg_handle* h, const void* d_records, size_t n, void* d_out, size_t out_cap, uint64_t* epoch_end,
                          size_t max_epochs, size_t* n_epochs, size_t* consumed);
 
+/* ------------------------------------------------------------------ */
+/* Capacity limiter — replaces, for the evictions of ONE nfagg_account   */
+/* call, the decision of CapacityLimiter.Limit                            */
+/* (pkg/flow/limiter.go:28-38): `if len(out) < cap(out) || cap(out) == 0  */
+/* { out <- i } else { dropped += len(i) }`.                              */
+/* ------------------------------------------------------------------ */
+
+/* nfagg_account delivers n_epochs evictions at once (out[epoch_end[e-1] .. epoch_end[e])); the reference's limiter sees them
+ * one by one on a channel and drops a whole batch when the exporter's channel is full. The shim takes this decision BEFORE it
+ * builds a single model.Record (model.NewRecord per flow is the hottest allocation site, pkg/model/record_bench_test.go:10-13):
+ * queue_len / queue_cap = len(out) / cap(out) of the exporter's channel now. keep[e] = 1: batch e is forwarded (it then occupies
+ * one more slot of the channel; nothing is assumed to drain meanwhile: the exporter can only make the outcome better), 0: dropped.
+ * *dropped_flows = the flows of the dropped batches — what the shim adds to DroppedFlowsCounter("limiter", "full") and to the
+ * droppedFlows the limiter's periodic warning reports (limiter.go:33-34,41-57). queue_cap == 0 (unbuffered channel) never
+ * drops (limiter.go:30). Pure host arithmetic, no device. Returns the number of batches kept. */
+size_t nfagg_limit_batches(const uint64_t* epoch_end, size_t n_epochs, size_t queue_len, size_t queue_cap, uint8_t* keep,
+                           uint64_t* dropped_flows);
+
 /* pkg/model/record.go:90-97: TimeFlowStart = now - (mono_now - start_mono),
  * TimeFlowEnd likewise; uint64 wrap then signed nanoseconds, as Go does.
  * now_unix_ns is the wall clock in ns since the Unix epoch. */
@@ -514,7 +532,7 @@ int nfagg_map_merge_device(nfagg_handle* h, const nfagg_map_view* d_main_map, co
 /* Copy a sketch to HOST memory. CM: uint64_t[depth<<log2w]; HLL: uint8_t[1<<p]. */
 int nfagg_sketch_snapshot(nfagg_handle* h, int which, void* out, size_t out_bytes);
 /* Device pointer and byte size of a sketch array (for in-place RCCL all-reduce:
- * CM sum uint64, HLL max uint32). */
+ * CM sum uint64, HLL max uint8 — 16 KiB per array at p = 14). */
 int nfagg_sketch_device_ptr(nfagg_handle* h, int which, void** d_ptr, size_t* bytes);
 /* Zero all sketches (start of a sketch window). */
 int nfagg_sketch_reset(nfagg_handle* h);
@@ -729,7 +747,7 @@ int nfagg_group_ingest(nfagg_group* g, const void* records, size_t n, size_t* co
 int nfagg_group_ingest_device(nfagg_group* g, uint32_t src_member, const void* d_records, size_t n, size_t* consumed);
 /* len(c.entries) over all shards. */
 int nfagg_group_len(nfagg_group* g, uint64_t* entries);
-/* The per-tick collective: ncclAllReduce(sum, uint64) over each Count-Min array and ncclAllReduce(max, uint32) over each
+/* The per-tick collective: ncclAllReduce(sum, uint64) over each Count-Min array and ncclAllReduce(max, uint8) over each
  * HLL register array, in place on every member, on the members' streams. Afterwards every member answers
  * nfagg_hll_estimate / nfagg_cm_query / nfagg_cm_topk for the whole node. IN PLACE means: call it ONCE per window, then
  * nfagg_sketch_reset every member (nfagg_group_member) before the next window's records arrive — a second call, or the next

@@ -128,6 +128,7 @@ SIGNATURES = {
     "nfagg_cm_query": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(C.c_uint64)]),
     "nfagg_hll_estimate_from_histogram": (C.c_double, [_vp, C.c_uint32]),
     "nfagg_ringbuf_drain": (C.c_int, [C.POINTER(RingBuf), _vp, _sz, _psz, _psz, _vp]),
+    "nfagg_limit_batches": (C.c_size_t, [C.POINTER(C.c_uint64), _sz, _sz, _sz, _vp, C.POINTER(C.c_uint64)]),
     "nfagg_encode_pb": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
     "nfagg_encode_pb_device": (C.c_int, [_vp, _vp, _sz, C.POINTER(PbOptions), _vp, _sz, _vp, _vp, _vp, _psz]),
     "nfagg_cm_topk": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _vp, _psz]),

@@ -286,7 +286,7 @@ int ensure_seq_window(nfagg_handle* h, uint64_t n, bool* blocked) {
 int snapshot_sketches(nfagg_handle* h, bool restore) {
     if (!h->sk.flags) return NFAGG_OK;
     const size_t cmb = (h->sk.flags & NFAGG_SKETCH_CM) ? ((size_t)h->sk.cm_depth << h->sk.cm_log2w) * sizeof(uint64_t) : 0;
-    const size_t hlb = (h->sk.flags & NFAGG_SKETCH_HLL) ? ((size_t)1 << h->sk.hll_p) * sizeof(uint32_t) : 0;
+    const size_t hlb = (h->sk.flags & NFAGG_SKETCH_HLL) ? ((size_t)1 << h->sk.hll_p) : 0;      // one byte per register
     int rc = ensure_bytes(h, &h->d_opt[1], &h->d_opt_cap[1], 2 * (cmb + hlb));
     if (rc != NFAGG_OK) return rc;
     char* snap = (char*)h->d_opt[1];
@@ -741,9 +741,9 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
         }
     }
     if (h->sk.flags & NFAGG_SKETCH_HLL) {
-        const size_t bytes = ((size_t)1 << cfg.hll_p) * sizeof(uint32_t);
+        const size_t bytes = ((size_t)1 << cfg.hll_p);              // uint8_t registers (hll_p >= 4: a multiple of 4 bytes)
         for (int k = 0; k < 2; k++) {
-            if (cfg.ext_sketch[2 + k]) h->sk.hll[k] = (uint32_t*)cfg.ext_sketch[2 + k];
+            if (cfg.ext_sketch[2 + k]) h->sk.hll[k] = (uint8_t*)cfg.ext_sketch[2 + k];
             else { CREATE_TRY(hipMalloc((void**)&h->sk.hll[k], bytes)); h->own_sketch[2 + k] = true; CREATE_TRY(hipMemsetAsync(h->sk.hll[k], 0, bytes, h->stream)); }
         }
     }
@@ -1756,7 +1756,7 @@ static int sketch_info(nfagg_handle* h, int which, void** p, size_t* bytes) {
     if (which == NFAGG_HLL_SRC || which == NFAGG_HLL_DST) {
         if (!(h->sk.flags & NFAGG_SKETCH_HLL)) return fail(h, NFAGG_ESTATE, "HyperLogLog sketch not enabled");
         *p = h->sk.hll[which - NFAGG_HLL_SRC];
-        *bytes = ((size_t)1 << h->sk.hll_p) * sizeof(uint32_t);
+        *bytes = ((size_t)1 << h->sk.hll_p);                     // uint8_t registers
         return NFAGG_OK;
     }
     return fail(h, NFAGG_EINVAL, "unknown sketch id %d", which);
@@ -1779,15 +1779,8 @@ int nfagg_sketch_snapshot(nfagg_handle* h, int which, void* out, size_t out_byte
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return NFAGG_OK;
     }
-    const size_t m = (size_t)1 << h->sk.hll_p;
-    if (out_bytes < m) return NFAGG_TRUNCATED;
-    size_t cap0 = h->d_roll_cap[0];
-    rc = ensure_bytes(h, &h->d_roll[0], &cap0, m);
-    h->d_roll_cap[0] = cap0;
-    if (rc != NFAGG_OK) return rc;
-    hipError_t e = launch_hll_pack((const uint32_t*)p, h->sk.hll_p, (uint8_t*)h->d_roll[0], h->stream);
-    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "hll pack launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(h, hipMemcpyAsync(out, h->d_roll[0], m, hipMemcpyDeviceToHost, h->stream));
+    if (out_bytes < bytes) return NFAGG_TRUNCATED;                   // the device registers ARE the snapshot layout: one byte each
+    HIP_TRY(h, hipMemcpyAsync(out, p, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NFAGG_OK;
 }
@@ -1826,7 +1819,7 @@ int nfagg_hll_estimate(nfagg_handle* h, int which, double* estimate) {
     void* p; size_t bytes;
     int rc = sketch_info(h, which, &p, &bytes);
     if (rc != NFAGG_OK) return rc;
-    hipError_t e = launch_hll_histogram((const uint32_t*)p, h->sk.hll_p, h->d_hist, h->stream);
+    hipError_t e = launch_hll_histogram((const uint8_t*)p, h->sk.hll_p, h->d_hist, h->stream);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "hll histogram launch failed: %s", hipGetErrorString(e));
     uint32_t hist[65];
     HIP_TRY(h, hipMemcpyAsync(hist, h->d_hist, sizeof hist, hipMemcpyDeviceToHost, h->stream));

@@ -57,7 +57,7 @@ NF_DEV void ast16(void* p, uint64_t lo, uint64_t hi) {
     // 128-bit store, so it neither delays the next write to v[] (gfx940+: a VALU write to the data registers of a store of more
     // than 64 bits needs 2 wait states) nor keeps the registers out of reuse. Round 4 found out the hard way: a change elsewhere
     // moved the register allocation, the claimer's key word 3 went out as the address computed for its NEXT store into the same
-    // registers, and ~3 % of the fresh slots carried a key that no record has (tools/exp/dedup_anatomy.py, profiles/r04_ast16_hazard.txt).
+    // registers, and ~3 % of the fresh slots carried a key that no record has (tests/tools/dedup_anatomy.py, profiles/r04_ast16_hazard.txt).
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
 
@@ -406,8 +406,19 @@ NF_DEV void sketch_add_side(const SketchView& sk, int side, uint64_t lo, uint64_
         const uint64_t h = ip_hash(lo, hi, 2);
         const uint64_t idx = h >> (64 - sk.hll_p);
         const uint32_t rho = (uint32_t)__clzll((long long)((h << sk.hll_p) | (1ull << (sk.hll_p - 1)))) + 1u;
-        // registers only grow: a stale smaller value merely costs one atomic
-        if (sk.hll[side][idx] < rho) amax(&sk.hll[side][idx], rho);
+        // One byte per register (what the all-reduce moves): raised by a CAS on the 32-bit word that holds it.
+        // Registers only grow and saturate quickly: the plain read skips nearly every update (a stale smaller value merely costs
+        // one look at the word), and a CAS only fails when a neighbour in the same word was raised meanwhile.
+        if (sk.hll[side][idx] < rho) {
+            uint32_t* wp = reinterpret_cast<uint32_t*>(sk.hll[side] + (idx & ~3ull));
+            const uint32_t sh = (uint32_t)(idx & 3ull) * 8u;
+            uint32_t cur = ald(wp);
+            while (((cur >> sh) & 0xffu) < rho) {
+                const uint32_t old = acas(wp, cur, (cur & ~(0xffu << sh)) | (rho << sh));
+                if (old == cur) break;
+                cur = old;
+            }
+        }
     }
 }
 

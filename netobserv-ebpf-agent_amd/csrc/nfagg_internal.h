@@ -138,7 +138,8 @@ struct TableView {
 
 struct SketchView {
     uint64_t* cm[2];               // src, dst : depth << log2w counters
-    uint32_t* hll[2];              // src, dst : 1 << p registers (uint32 on device)
+    uint8_t* hll[2];               // src, dst : 1 << p registers of ONE BYTE each (the spec's and the collective's layout; the buffers
+                                   // are 4-byte aligned: a register is raised by a CAS on the word that holds it)
     uint32_t cm_depth, cm_log2w, hll_p, flags;
 };
 
@@ -245,8 +246,7 @@ hipError_t launch_cm_sort_desc(const uint64_t* d_est, uint64_t* d_est_sorted, co
                                void* d_temp, size_t* temp_bytes, hipStream_t s);
 hipError_t launch_cm_gather(const void* d_records, int side, const uint64_t* d_est_sorted, const uint32_t* d_idx_sorted, uint64_t m,
                             uint64_t* d_rows, hipStream_t s);
-hipError_t launch_hll_histogram(const uint32_t* d_regs, uint32_t p, uint32_t* d_hist65, hipStream_t s);
-hipError_t launch_hll_pack(const uint32_t* d_regs, uint32_t p, uint8_t* d_out, hipStream_t s);
+hipError_t launch_hll_histogram(const uint8_t* d_regs, uint32_t p, uint32_t* d_hist65, hipStream_t s);
 
 // Per-CPU rollups (nfagg_rollup.hip). kind: 0 additional,1 dns,2 drops,3 netev,4 xlat,5 quic.
 hipError_t launch_rollup(int kind, const void* d_partials, uint64_t n_flows, uint64_t n_cpu,

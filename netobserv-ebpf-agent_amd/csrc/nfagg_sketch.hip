@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_sketch_update(SketchView sk, TableView 
     carried_flush(sk, 1, cd);
 }
 
-__global__ __launch_bounds__(256) void k_hll_histogram(const uint32_t* __restrict__ regs, uint32_t p, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(256) void k_hll_histogram(const uint8_t* __restrict__ regs, uint32_t p, uint32_t* __restrict__ hist) {
     __shared__ unsigned int sh[65];
     for (int k = threadIdx.x; k < 65; k += blockDim.x) sh[k] = 0;
     __syncthreads();
@@ -110,10 +110,6 @@ __global__ __launch_bounds__(256) void k_hll_histogram(const uint32_t* __restric
     }
     __syncthreads();
     for (int k = threadIdx.x; k < 65; k += blockDim.x) hist[k] = sh[k];
-}
-
-__global__ __launch_bounds__(256) void k_hll_pack(const uint32_t* __restrict__ regs, uint32_t m, uint8_t* __restrict__ out) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) out[i] = (uint8_t)regs[i];
 }
 
 // Heavy hitters: Count-Min stores no keys, so the candidates are the addresses that occur in a record batch (typically the
@@ -170,14 +166,8 @@ hipError_t launch_sketch_update(const SketchView& sk, const TableView& t, const 
     return hipGetLastError();
 }
 
-hipError_t launch_hll_histogram(const uint32_t* d_regs, uint32_t p, uint32_t* d_hist65, hipStream_t s) {
+hipError_t launch_hll_histogram(const uint8_t* d_regs, uint32_t p, uint32_t* d_hist65, hipStream_t s) {
     (void)hipGetLastError(); hipLaunchKernelGGL(k_hll_histogram, dim3(1), dim3(256), 0, s, d_regs, p, d_hist65);
-    return hipGetLastError();
-}
-
-hipError_t launch_hll_pack(const uint32_t* d_regs, uint32_t p, uint8_t* d_out, hipStream_t s) {
-    const uint32_t m = 1u << p;
-    (void)hipGetLastError(); hipLaunchKernelGGL(k_hll_pack, dim3((m + 255) / 256), dim3(256), 0, s, d_regs, m, d_out);
     return hipGetLastError();
 }
 

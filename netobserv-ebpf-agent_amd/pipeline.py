@@ -41,6 +41,19 @@ class CapacityLimiter:                                    # limiter.go:19-26
                 self.droppedFlows += len(batch)
 
 
+def limit_batches(epoch_end, queue_len: int, queue_cap: int):
+    """nfagg_limit_batches: CapacityLimiter.Limit's decision (limiter.go:28-38) for the evictions one nfagg_account call
+    delivered, taken before any Record is built. Returns (keep flags, dropped flows)."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib as L
+    ends = (C.c_uint64 * max(len(epoch_end), 1))(*[int(x) for x in epoch_end])
+    keep = np.zeros(max(len(epoch_end), 1), dtype=np.uint8)
+    dropped = C.c_uint64(0)
+    L.lib.nfagg_limit_batches(ends, len(epoch_end), queue_len, queue_cap, keep.ctypes.data_as(C.c_void_p), C.byref(dropped))
+    return [bool(k) for k in keep[: len(epoch_end)]], dropped.value
+
+
 def _mac(b) -> str:                                       # net.HardwareAddr.String()
     return ":".join("%02x" % x for x in bytes(b))
 

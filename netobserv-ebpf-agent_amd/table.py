@@ -260,7 +260,7 @@ class FlowTable:
         if which in (L.CM_SRC, L.CM_DST):
             out = np.zeros(b.value // 8, dtype=np.uint64)
         else:
-            out = np.zeros(b.value // 4, dtype=np.uint8)
+            out = np.zeros(b.value, dtype=np.uint8)
         self._check(L.lib.nfagg_sketch_snapshot(self._h, which, out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
 

@@ -209,3 +209,38 @@ def test_map_tracer_evict_flows_decoration(nf, O):
     k1 = [f for f in exported if int(f.ID["src_port"]) == 123][0]
     assert (k1.DNSLatency, k1.TimeFlowRtt, k1.DNSMetrics) == (0, 0, None)
     assert tracer.metrics.evicted_flows_total == {("hashmap", ""): 2}
+
+
+def test_limit_batches_abi_equals_the_limiter_on_a_burst(nf):
+    """nfagg_limit_batches (include/nfagg.h) = CapacityLimiter.Limit (pkg/flow/limiter.go:28-38) applied to the burst of evictions
+    one nfagg_account call delivers, nothing draining meanwhile — the setting of limiter_test.go:17-71 (limiterLen = 50: 49 batches
+    all pass, of 52 the first 50 pass) — checked against the host mirror of the limiter itself."""
+    import queue
+    P = nf.pipeline
+    rng = np.random.default_rng(3)
+    for n_batches, qlen, qcap in ((49, 0, 50), (52, 0, 50), (10, 45, 50), (7, 50, 50), (5, 0, 0), (0, 3, 50), (30, 0, 1)):
+        sizes = rng.integers(0, 5000, n_batches)
+        ends = np.cumsum(sizes).tolist()
+        keep, dropped = P.limit_batches(ends, qlen, qcap)
+        # the mirror of the reference limiter on a queue that already holds qlen batches
+        inp, out = queue.Queue(), queue.Queue(maxsize=qcap)
+        for _ in range(qlen):
+            out.put([None])
+        m = nf.Metrics() if hasattr(nf, "Metrics") else None
+        lim = P.CapacityLimiter(m)
+        for s in sizes:
+            inp.put([None] * int(s))
+        inp.put(P.CLOSE)
+        if qcap == 0:                      # an unbuffered channel never drops (the mirror would block on put: take the rule itself)
+            assert keep == [True] * n_batches and dropped == 0
+            continue
+        want_keep = []
+        for s in sizes:                    # limiter.go:30 step by step (Limit() itself needs a consumer for CLOSE)
+            if out.qsize() < out.maxsize:
+                out.put([None] * int(s)); want_keep.append(True)
+            else:
+                lim.droppedFlows += int(s); want_keep.append(False)
+        assert keep == want_keep, (n_batches, qlen, qcap)
+        assert dropped == lim.droppedFlows == int(sizes[[not k for k in want_keep]].sum()) if n_batches else dropped == 0
+    keep, dropped = P.limit_batches(list(range(1, 53)), 0, 50)       # limiter_test.go:44-71: 52 one-record batches, 50 pass
+    assert keep == [True] * 50 + [False] * 2 and dropped == 2

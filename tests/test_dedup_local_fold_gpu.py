@@ -311,3 +311,30 @@ def test_group_local_fold_truncated_eviction_is_repeatable(nf, O):
         assert np.array_equal(nf.distributed.shard_ids(got, n_members), np.repeat(np.arange(n_members), counts))
         assert_records_equal(nf.sort_by_key(got), want)
         assert grp.ingest(recs.view(nf.FLOW_RECORD)[:10]) == (nf.OK, 10)
+
+
+# ---------------------------------------------------------------- bench.py --gpus N --dedup: configs[4] as it is written
+def test_bench_gpus_2_dedup_runs_the_common_stream_rehearsed_on_one_gpu(nf, O):
+    """`python bench.py --gpus 2 --dedup --hot-permille 900` as a PLAIN process (it spawns its ranks), both ranks on cuda:0 over
+    gloo: ONE common stream — no pre-sharded escape any more — whose hot flow alternates over two interfaces and is folded by
+    both ranks; sub-flow partials travel to the owners of their flows, the owners join and evict. The number of evicted flows
+    must be the number of distinct keys of the common stream (one kernel-dedup table over it: the oracle)."""
+    from test_partials_gpu import _bench
+    from netobserv_ebpf_agent_amd import synth
+    n, keys = 500_000, 30_000
+    j = _bench("--gpus", "2", "--dedup", "--hot-permille", "900", "--no-sketches", "--same-device", "--backend", "gloo", "--records", str(n),
+               "--flows", str(keys), "--steps", "2", "--warmup", "1")
+    assert j["n_gpus"] == 2 and j["value"] > 0
+    c = j["config"]
+    assert "configs[4]" in c["workload"] and "local fold" in c["parallelism"] and "REHEARSAL" in c["parallelism"]
+    assert c["mode"] == "kernel_dedup" and c["stream_variant"] == 2 and c["hot_permille"] == 900
+    assert c["member_records_folded"] == [3 * n, 3 * n]                      # warm-up + 2 timed steps, both ranks, nothing skipped or routed
+    ex = c["exchange"]
+    assert ex["partial_bytes"] == 256 and ex["partials_sent"] > 0 and ex["partials_received"] > 0 and ex["all_to_all_ms"] > 0
+    th = synth.zipf_thresholds(2 * keys, 1.1)
+    whole = synth.stream_host(2 * n, seed=2, n_keys=2 * keys, thresholds=th, hot_permille=900, variant=2)
+    want = O.run_accounter(whole, 1 << 22, mode=1)[0][1]
+    assert c["evicted_flows_per_step"] == len(want)
+    # the hot flow is seen on two interfaces by both ranks: it really is one flow with an observed interface in the oracle's eviction
+    hot = want[np.argmax(want["metrics"]["packets"])]
+    assert hot["metrics"]["nb_observed_intf"] >= 1

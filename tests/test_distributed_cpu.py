@@ -36,7 +36,7 @@ def _worker(rank, world, port, q):
     ev = O.run_accounter(mine, 1 << 20)[0][1]
     cm_s, cm_d, hs, hd = O.sketches(mine, 4, 14, 12)
     cm = [torch.from_numpy(cm_s.view(np.int64)), torch.from_numpy(cm_d.view(np.int64))]
-    hll = [torch.from_numpy(hs.astype(np.int32)), torch.from_numpy(hd.astype(np.int32))]
+    hll = [torch.from_numpy(hs.astype(np.uint8)), torch.from_numpy(hd.astype(np.uint8))]     # one byte per register, as on the device
     nf.distributed.merge_sketches(cm, hll)
     # gather the shards' evictions on rank 0
     gathered = [None] * world

@@ -75,3 +75,67 @@ def test_uniform_singleton_heavy_stream_bit_exact_80m(nf, O, torch):
     host = d.cpu().numpy()
     want = _fold_and_compare(nf, O, torch, d, host, nf.MODE_ACCOUNTER, False, 1 << 24, N=n)
     assert 7_900_000 < len(want) <= keys
+
+
+def test_configs3_at_size_eight_ranks_rehearsed_on_one_gpu(nf, O, torch):
+    """configs[3] at its own size in multi-handle form, rehearsed on ONE GPU: 8 unsharded handles stand for the ranks of
+    `bench.py --gpus 8`; rank r folds the contiguous slice [12.5 M r, 12.5 M (r + 1)) of ONE 100 M-record Zipf(1.1) stream over
+    10 M flows with job-global sequence numbers (one call per rank, CM + HLL on), then the tick: every rank's flows as 192-byte
+    partials grouped by owner, device-to-device "exchange" (pointer arithmetic: the ranks share the device), merge, evict owned.
+    The union must be bit-identical to ONE Accounter (pkg/flow/account.go:58-124; the oracle) over the whole stream, the merged
+    Count-Min / HLL arrays equal to the oracle's over all records, the HLL estimates within 1 ULP."""
+    n_ranks, n, keys = 8, 100_000_000, 10_000_000
+    per = n // n_ranks
+    th = nf.synth.zipf_thresholds(keys, 1.1)
+    d = dev_stream(torch, nf.synth, n, seed=4, n_keys=keys, thresholds=th, variant=1)          # SURVEY §8(d) config 4: seed 4
+    host = d.cpu().numpy()
+    want = O.run_accounter(host, 1 << 25)[0][1]
+    assert 5_000_000 < len(want) <= keys
+    sk = nf.SKETCH_CM | nf.SKETCH_HLL
+    max_entries = 1 << 22                                               # a rank sees ~1.9 M of the flows; after the merge it holds what it owns too
+    tabs = [nf.FlowTable(max_entries=max_entries, table_log2_slots=24, sketches=sk) for _ in range(n_ranks)]
+    try:
+        for r, tab in enumerate(tabs):
+            tab.set_sequence(r * per)
+            assert tab.ingest_device(d.data_ptr() + r * per * 144, per) == (nf.OK, per)
+        seen = [len(t) for t in tabs]
+        assert all(1_000_000 < s < max_entries for s in seen), seen
+        # the per-tick collective, rehearsed: CM sum / HLL max over the ranks' arrays = the oracle's over all records
+        cm_s, cm_d, hs, hd = O.sketches(host)
+        for which, ref in ((nf.CM_SRC, cm_s), (nf.CM_DST, cm_d)):
+            acc = np.zeros_like(ref)
+            for t in tabs:
+                acc += t.sketch_snapshot(which)
+            assert np.array_equal(acc, ref)
+        for which, ref in ((nf.HLL_SRC, hs), (nf.HLL_DST, hd)):
+            acc = np.zeros_like(ref)
+            for t in tabs:
+                acc = np.maximum(acc, t.sketch_snapshot(which))
+            assert np.array_equal(acc, ref)
+            hist = np.bincount(acc, minlength=65).astype(np.uint32)
+            est, want_est = nf.hll_estimate_from_histogram(hist, 14), O.hll_estimate(ref, 14)
+            assert abs(est - want_est) <= np.spacing(want_est)
+        # export by owner, exchange, merge, evict owned
+        exp = [torch.empty(s * 24, dtype=torch.int64, device="cuda") for s in seen]
+        torch.cuda.synchronize()
+        counts = []
+        for r, tab in enumerate(tabs):
+            rc, c, total = tab.partials_export_device(n_ranks, r, exp[r].data_ptr(), seen[r])
+            assert rc == nf.OK and total == sum(c) and c[r] == 0
+            counts.append(c)
+        for owner in range(n_ranks):
+            for src in range(n_ranks):
+                if src != owner and counts[src][owner]:
+                    tabs[owner].partials_merge_device(n_ranks, owner, exp[src].data_ptr() + sum(counts[src][:owner]) * 192, counts[src][owner])
+        got = []
+        for r, tab in enumerate(tabs):
+            rc, need = tab.evict_owned_device(n_ranks, r, 0, 0)
+            assert rc == nf.TRUNCATED and need > 0
+            out = torch.empty(need * 144 + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+            assert tab.evict_owned_device(n_ranks, r, out.data_ptr(), need) == (nf.OK, need)
+            got.append(out[: need * 144].cpu().numpy().view(nf.FLOW_RECORD))
+        assert sum(len(g) for g in got) == len(want)
+        assert_records_equal(nf.sort_by_key(np.concatenate(got)), want, "configs[3] at size: union of 8 ranks vs ONE Accounter")
+    finally:
+        for t in tabs:
+            t.close()

@@ -139,3 +139,47 @@ def test_drain_empty_full_and_truncated(nf, O):
     before = int(ring.cons[0])
     rc, got, _, _ = drain(nf, ring, 10)
     assert rc == nf._lib.EINVAL and len(got) == 2 and int(ring.cons[0]) == before + 2 * 152
+
+
+def test_bulk_drain_runs_of_plain_samples_split_over_threads(nf, O):
+    """Runs of >= 32768 plain 144-byte samples take the multi-threaded path of nfagg_ringbuf_drain (each thread verifies the headers
+    of its range; the run ends at the first header that is not "144 bytes, committed"): same result as the per-sample reader, with a
+    discarded sample, a wrong-length sample and a busy sample placed inside / between the runs, and the ring wrapping."""
+    rng = np.random.default_rng(5)
+    n = 150_000
+    recs = O.gen_stream(n, seed=21, n_keys=5000, variant=1)
+    raw = recs.view(np.uint8).reshape(n, 144)
+    size = 1 << 25
+    ring = Ring(size, start_pos=size * 3 - 152 * 40_000)              # the first run wraps around the data area
+
+    def push_many(lo, hi):                                            # vectorised bpf_ringbuf_reserve + submit
+        blob = np.zeros((hi - lo, 152), dtype=np.uint8)
+        blob[:, 0] = 144
+        blob[:, 8:] = raw[lo:hi]
+        flat = blob.reshape(-1)
+        p = int(ring.prod[0])
+        pos = p & (size - 1)
+        first = min(len(flat), size - pos)
+        ring.data[pos:pos + first] = flat[:first]
+        ring.data[:len(flat) - first] = flat[first:]
+        ring.prod[0] = p + len(flat)
+
+    push_many(0, 70_000)
+    ring.push(raw[70_000].tobytes(), discard=True)                    # ends the first run
+    push_many(70_001, 110_000)
+    ring.push(bytes(24))                                              # wrong length
+    push_many(110_000, 149_000)
+    busy = ring.push(raw[149_000].tobytes(), busy=True)               # reserved, not committed: the drain stops here
+    push_many(149_001, 150_000)
+    shadow = Ring(size); shadow.data, shadow.prod, shadow.cons = ring.data, ring.prod.copy(), ring.cons.copy()
+    want, want_cons, why = ref_drain(shadow, n)
+    rc, got, skipped, errs = drain(nf, ring, n)
+    assert rc == nf.OK and why == "busy" and len(want) == 148_999
+    assert int(ring.cons[0]) == want_cons and skipped == 2
+    assert got == want
+    assert int(errs.sum()) == len(got)
+    ring.commit(busy)
+    shadow.cons = ring.cons.copy()
+    want2, want_cons2, _ = ref_drain(shadow, 500)                     # a small destination: stops when it is full
+    rc, got2, _, _ = drain(nf, ring, 500)
+    assert rc == nf.OK and got2 == want2 and len(got2) == 500 and int(ring.cons[0]) == want_cons2

@@ -5,6 +5,6 @@ L=$PWD/netobserv-ebpf-agent_amd/lib
 for v in "libnfagg.so 10 0" "libnfagg.so 10 1"; do
   set -- $v
   echo "== $v"
-  NFAGG_LIB=$L/$1 timeout 120 python tools/exp/dedup_anatomy.py $2 $3 $4 2>&1 | grep -v amdgpu.ids | tail -12
+  NFAGG_LIB=$L/$1 timeout 120 python tests/tools/dedup_anatomy.py $2 $3 $4 2>&1 | grep -v amdgpu.ids | tail -12
 done > gpurun_out/r04b/anatomy2.txt 2>&1
 cat gpurun_out/r04b/anatomy2.txt
