@@ -90,7 +90,7 @@ def test_configs3_at_size_eight_ranks_rehearsed_on_one_gpu(nf, O, torch):
     d = dev_stream(torch, nf.synth, n, seed=4, n_keys=keys, thresholds=th, variant=1)          # seed 4
     host = d.cpu().numpy()
     want = O.run_accounter(host, 1 << 25)[0][1]
-    assert 5_000_000 < len(want) <= keys
+    assert 4_500_000 < len(want) <= keys                                # 4.86 M of the 10 M flows appear in 100 M records
     sk = nf.SKETCH_CM | nf.SKETCH_HLL
     max_entries = 1 << 22                                               # a rank sees ~1.9 M of the flows; after the merge it holds what it owns too
     tabs = [nf.FlowTable(max_entries=max_entries, table_log2_slots=24, sketches=sk) for _ in range(n_ranks)]

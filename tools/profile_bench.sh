@@ -11,10 +11,14 @@ export TMPDIR=/tmp
 ARGS="${BENCH_ARGS:---steps 3 --warmup 1 --cpu-sample 0 --no-extras}"
 PMC_ARGS="${PMC_BENCH_ARGS:---steps 1 --warmup 0 --cpu-sample 0 --no-extras}"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py $ARGS > $OUT/trace_bench.json 2> $OUT/trace_err.txt
-for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+PROG="${PROF_PROG:-python $R/bench.py}"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $PROG $ARGS > $OUT/trace_bench.json 2> $OUT/trace_err.txt
+# PMC_LIGHT=1: only the two traffic counters (the extra legs of round 4: one FETCH_SIZE and one WRITE_SIZE pass each)
+if [ "${PMC_LIGHT:-0}" = "1" ]; then GROUPS_=("FETCH_SIZE" "WRITE_SIZE"); else GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"); fi
+PROG="${PROF_PROG:-python $R/bench.py}"
+for c in "${GROUPS_[@]}"; do
   tag=$(echo $c | tr ' ' '_' | cut -c1-24)
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$tag -- python $R/bench.py $PMC_ARGS > $OUT/pmc_${tag}_bench.json 2> $OUT/pmc_${tag}_err.txt
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$tag -- $PROG $PMC_ARGS > $OUT/pmc_${tag}_bench.json 2> $OUT/pmc_${tag}_err.txt
 done
 if [ -x $R/tools/pmc_calib ]; then
   for c in FETCH_SIZE WRITE_SIZE; do

@@ -15,6 +15,7 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof"
+leg = sys.argv[3] if len(sys.argv) > 3 else None          # round 4: the bench leg this profile belongs to (extra.<leg> looks it up)
 os.makedirs("profiles", exist_ok=True)
 ks = sorted(glob.glob(f"{src}/trace/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
 if ks:
@@ -73,7 +74,10 @@ if f_read and f_write:
         bench = json.load(open(f"{src}/pmc_FETCH_SIZE_bench.json"))
     except Exception:
         bench = None
-    ingest = [k for k in per_kernel if any(s in k for s in ("k_fold", "k_pass1", "k_pass2", "k_merge_overflow", "k_ingest", "k_dedup_claim", "k_dedup_fold", "k_dedup_stream", "k_dedup_parts", "k_dedup_overflow", "k_finalize"))]
+    ingest = [k for k in per_kernel if any(s in k for s in ("k_fold", "k_pass1", "k_pass2", "k_merge_overflow", "k_ingest", "k_dedup_claim", "k_dedup_fold", "k_dedup_stream", "k_dedup_parts", "k_dedup_overflow", "k_finalize",
+                                                                "k_sketch_update", "k_ep_", "k_ring_to_front", "k_account_epochs"))]
+    if leg == "cache_max_flows_5000":                          # nfagg_account: the evictions are part of the call
+        ingest += [k for k in per_kernel if "k_evict" in k and k not in ingest]
     evict = [k for k in per_kernel if "k_evict" in k]
     ev_calls = max((per_kernel[k].get("FETCH_SIZE", (1, 0))[0] for k in evict), default=1)
     ev_traffic = (sum(per_kernel[k].get("FETCH_SIZE", (0, 0))[1] for k in evict) * f_read +
@@ -83,7 +87,7 @@ if f_read and f_write:
     write_kib = sum(per_kernel[k].get("WRITE_SIZE", (0, 0))[1] for k in ingest)
     traffic = (fetch_kib * f_read + write_kib * f_write) * 1024.0 / calls
     out = {
-        "tag": tag, "ingest_calls": calls, "kernels": ingest,
+        "tag": tag, "leg": leg, "ingest_calls": calls, "kernels": ingest,
         "fetch_kib_per_call": fetch_kib / calls, "write_kib_per_call": write_kib / calls,
         "factor_read": f_read, "factor_write": f_write,
         "traffic_bytes_per_call": traffic,
