@@ -384,6 +384,8 @@ struct PartsLds {
     uint32_t sub_cnt[kSubs];        // ... of the first round, per sub-partition
     uint32_t sub_off[kSubs + 1];    // counting sort: start of every sub-partition's segment
     uint32_t sub_fill[kSubs];
+    uint32_t new_cnt[4];            // grouped flush: [0] fresh slots claimed by it, [1..2] base of their live-list range, [3] deferred claims allowed
+    uint32_t grp[kPartEntries];     // grouped flush: flow hash -> leader entry + 1 (0 = empty)
 };
 constexpr uint32_t kPackItems = 768;   // consecutive sub-partitions share a round while their items (>= sub-flows) surely fit a cache
 
@@ -477,6 +479,189 @@ NF_DEV void parts_flush(const TableView& t, FoldCache<kPartEntries>& L, const vo
     __syncthreads();
 }
 
+// ---- the FIRST flush of a partition, grouped by flow (round 4) -----------------------------------------------------------------
+// The partition's workgroup owns its flows while it runs, and after the first round nearly every flow of a one-call epoch is NEW
+// to the table. The flush above pays for such a flow, per sub-flow: a probe, (one of them) a claim that zeroes 512 bytes with 26
+// write-through stores, then ~10 atomics on the words just zeroed. Here the sub-flow entries of a flow are first brought together
+// in LDS (a hash of the flow key elects one entry the LEADER, the others hang on its list); the leader takes the slot
+// (find_or_claim<DEFER>: tag = claimed, nothing written) and, when the slot is fresh, works out the flow's whole state from its
+// entries — F = the interface of the entry with the smallest sequence number, the seven earliest interfaces, the counted entry's
+// sums and "last value" tags, the side entries' directions, end and flags (exactly what dedup_claim + dedup_merge would leave) —
+// and writes hot line, cold half line and aux lines ONCE with plain 16-byte stores (key and tag coherent, as
+// merge_partial_exclusive does). The slots claimed this way enter the live list as one range per workgroup. A flow whose slot
+// exists already (an earlier call, the overflow kernel, an item of the round that found no cache entry and was claimed at once),
+// a flow with more than kGroupMax entries, and every flow on tables too small for deferred claims (TableView.defer_claims) take
+// the two-phase path above, lane by lane. Exactness: the state is a pure function of the flow's sub-flow partials (the slot was
+// empty), and it is the function the atomic path computes — the join of nfagg_dedup_join.hip is the same computation on slots.
+constexpr int kGroupMax = 8;
+struct FlushLink { uint32_t lead_nxt; uint32_t slot; };   // overlays FoldCache.h64[e] during the flush: leader entry | next entry << 16; the leader's slot | fresh << 31
+static_assert(sizeof(FlushLink) == sizeof(uint64_t), "FlushLink overlays h64");
+
+// The leader of a fresh flow: everything the slot will hold, from the entries on its list.
+NF_DEV void flush_fresh_flow(const TableView& t, const FoldCache<kPartEntries>& L, const FlushLink* K, int lead, uint32_t idx, const uint64_t w[5],
+                             const void* recs, uint32_t seq_base32) {
+    // the entry with the flow's earliest record: its interface is F (flows.c: the first record is stored whole, its if_index is if_index_first_seen)
+    uint32_t first_seq = 0xffffffffu; int fe = lead;
+    for (uint32_t x = (uint32_t)lead; x != 0xffffu; x = K[x].lead_nxt >> 16) {
+        const uint32_t sq = L.min_seq[x];
+        if (sq < first_seq) { first_seq = sq; fe = (int)x; }
+    }
+    const uint32_t F = L.ifx[fe];
+    // end: the LAST record that reaches either branch; flags: every record that does (side records: the 16 flag bits only)
+    uint64_t endl_lo = 0, endl_hi = 0;
+    uint32_t flags = 0;
+    for (uint32_t x = (uint32_t)lead; x != 0xffffu; x = K[x].lead_nxt >> 16) {
+        const uint32_t ifx = L.ifx[x];
+        if (ifx != F && ifx == 0) continue;                                  // flows.c:126: ignored
+        const uint64_t lo = L.endl_lo[x], hi = L.endl_hi[x];
+        endl_lo = lo > endl_lo ? lo : endl_lo; endl_hi = hi > endl_hi ? hi : endl_hi;
+        flags |= ifx == F ? L.flags[x] : (L.flags[x] & 0xffffu);
+    }
+    // the seven interfaces that appear earliest (non-zero ones; F among them when it is non-zero); side ones with their directions
+    uint64_t cand[kCand], d0[kCand], d1[kCand];
+    long long prev = -1;
+#pragma unroll
+    for (int k = 0; k < kCand; k++) {
+        uint32_t best = 0xffffffffu; int bx = -1;
+        for (uint32_t x = (uint32_t)lead; x != 0xffffu; x = K[x].lead_nxt >> 16) {
+            const uint32_t sq = L.min_seq[x];
+            if (L.ifx[x] != 0 && (long long)sq > prev && sq < best) { best = sq; bx = (int)x; }
+        }
+        cand[k] = 0; d0[k] = 0; d1[k] = 0;
+        if (bx >= 0) {
+            cand[k] = tagged(~best, L.ifx[bx]);
+            if (L.ifx[bx] != F) { d0[k] = L.dir[0][bx]; d1[k] = L.dir[1][bx]; }
+            prev = (long long)best;
+        } else prev = 0x100000000ll;                                         // none left
+    }
+    // the first record, whole (account.go:95): start, eth_protocol, MACs here; its identity dwords too (k_finalize writes them again)
+    Rec r;
+    load_record(recs, (uint64_t)(first_seq - seq_base32), r);
+    r.canonicalize();
+    const uint32_t inv = ~first_seq;
+    uint4* HL = reinterpret_cast<uint4*>(&t.hot[idx]);
+    uint4* CL = reinterpret_cast<uint4*>(&t.cold[idx]);
+    uint4* AL = reinterpret_cast<uint4*>(&t.aux[idx]);
+    const uint64_t bytes = L.bytes[fe], pf = (uint64_t)L.packets[fe] | ((uint64_t)flags << 32), id0 = tagged(inv, F);
+    const uint64_t smac_lo = tagged(inv, (uint32_t)r.smac()), dmac_lo = tagged(inv, (uint32_t)r.dmac());
+    HL[3] = u4(bytes, 0);
+    HL[4] = u4(r.start(), pf);
+    HL[5] = u4((uint64_t)r.eth(), L.dscp_tag[fe]);
+    HL[6] = u4(L.samp_tag[fe], id0);
+    HL[7] = u4(smac_lo, dmac_lo);
+    CL[0] = u4(tagged(inv, (uint32_t)(r.smac() >> 32)), tagged(inv, (uint32_t)(r.dmac() >> 32)));
+    CL[1] = make_uint4(r.d[22], r.d[24], r.d[25], r.d[26]);                 // (pad2 cleared by canonicalize)
+    CL[2] = make_uint4(r.d[27], r.d[28], r.d[29], r.d[30]);
+    CL[3] = make_uint4(r.d[31], r.d[32], r.d[33], r.d[34]);
+    // aux words: cand[0..6], endl_lo, endl_hi, ssl_first, ssl_max | ssl_minv << 32, cs_tag, ks_tag, dir[k][0..1] (13 + 2k), pad
+    AL[0] = u4(cand[0], cand[1]); AL[1] = u4(cand[2], cand[3]); AL[2] = u4(cand[4], cand[5]);
+    AL[3] = u4(cand[6], endl_lo);
+    AL[4] = u4(endl_hi, L.ssl_first[fe]);
+    AL[5] = u4((uint64_t)L.ssl_max[fe] | ((uint64_t)L.ssl_minv[fe] << 32), L.cs_tag[fe]);
+    AL[6] = u4(L.ks_tag[fe], d0[0]);
+    AL[7] = u4(d1[0], d0[1]); AL[8] = u4(d1[1], d0[2]); AL[9] = u4(d1[2], d0[3]); AL[10] = u4(d1[3], d0[4]);
+    AL[11] = u4(d1[4], d0[5]); AL[12] = u4(d1[5], d0[6]); AL[13] = u4(d1[6], 0);
+    AL[14] = u4(0, 0); AL[15] = u4(0, 0);
+    // the key, coherently (other workgroups compare it while they probe past this slot); the tag follows after the drain
+    SlotHot* H = &t.hot[idx];
+#pragma unroll
+    for (int k = 0; k < 5; k++) ast(&H->key[k], w[k]);
+}
+
+NF_DEV void parts_flush_grouped(const TableView& t, FoldCache<kPartEntries>& L, PartsLds& P, const void* recs, uint32_t seq_base32) {
+    static_assert(offsetof(SlotAux, endl_lo) == 56 && offsetof(SlotAux, ssl_first) == 72 && offsetof(SlotAux, cs_tag) == 88 &&
+                  offsetof(SlotAux, dir) == 104, "flush_fresh_flow writes the aux lines as 16-byte units");
+    const int e = threadIdx.x;
+    const bool used = L.h64[e] != 0 && L.min_seq[e] != 0xffffffffu;
+    const bool defer = P.new_cnt[3] != 0;                                  // written before the round (a barrier since)
+    uint64_t w[5] = {0, 0, 0, 0, 0}, h = 0;
+    if (used) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
+        h = key_hash(w);
+    }
+    __syncthreads();                                                         // every lane has looked at its h64: the links may overlay it
+    FlushLink* K = reinterpret_cast<FlushLink*>(L.h64);
+    K[e].lead_nxt = (uint32_t)e | 0xffff0000u;                               // its own leader, empty list
+    K[e].slot = kNoSlot;
+    P.grp[e] = 0;
+    if (e == 0) P.new_cnt[0] = 0;
+    __syncthreads();
+    // ---- bring the sub-flows of a flow together: the entry that plants itself in the flow's grp slot leads
+    int lead = e;
+    if (used) {
+        uint32_t g = (uint32_t)(h >> 20) & (uint32_t)(kPartEntries - 1);
+        for (;;) {
+            uint32_t cur = P.grp[g];
+            if (cur == 0) { cur = atomicCAS(&P.grp[g], 0u, (uint32_t)e + 1u); if (cur == 0) break; }
+            const int o = (int)cur - 1;
+            bool same = true;
+#pragma unroll
+            for (int k = 0; k < 5; k++) same &= (L.key[k][o] == w[k]);
+            if (same) { lead = o; break; }
+            g = (g + 1) & (uint32_t)(kPartEntries - 1);
+        }
+        if (lead != e) {                                                     // hang on the leader's list (its word: leader | head << 16)
+            uint32_t* lw = &K[lead].lead_nxt;
+            uint32_t cur = *lw;
+            for (;;) {
+                K[e].lead_nxt = (uint32_t)lead | (cur & 0xffff0000u);        // my next = the old head
+                const uint32_t old = atomicCAS(lw, cur, (cur & 0xffffu) | ((uint32_t)e << 16));
+                if (old == cur) break;
+                cur = old;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- leaders take the slot
+    bool fresh = false;
+    uint32_t my_k = 0;
+    if (used && lead == e) {
+        int len = 0;
+        for (uint32_t x = (uint32_t)e; x != 0xffffu && len <= kGroupMax; x = K[x].lead_nxt >> 16) len++;
+        Hints hx;
+        uint32_t idx = probe_home(t, w, h, hx);
+        if (idx == kNoSlot) {
+            if (defer && len <= kGroupMax) idx = find_or_claim<true>(t, w, h, &fresh, &hx.home_tag);
+            else idx = find_or_claim(t, w, h);
+        }
+        if (fresh) my_k = atomicAdd(&P.new_cnt[0], 1u);
+        K[e].slot = idx == kNoSlot ? kNoSlot : (idx | (fresh ? 0x80000000u : 0u));
+    }
+    __syncthreads();
+    // ---- fresh flows: the leader writes the whole slot. Every other entry: pass 1 of the two-phase path on the flow's slot
+    const uint32_t sl = used ? K[lead].slot : kNoSlot;
+    const uint32_t idx = sl == kNoSlot ? kNoSlot : (sl & 0x7fffffffu);
+    const bool flow_fresh = sl != kNoSlot && (sl & 0x80000000u) != 0;
+    if (fresh) flush_fresh_flow(t, L, K, e, idx, w, recs, seq_base32);
+    else if (idx != kNoSlot && !flow_fresh) dedup_claim(t, idx, 0, L.ifx[e], L.min_seq[e]);
+    drain_stores();                                                          // this lane's claims / slot stores have reached the memory side
+    __syncthreads();
+    const uint32_t cnt = P.new_cnt[0];
+    if (e == 0 && cnt) {                                                     // the fresh slots: one range of the live list (pass2_flush's rule)
+        const unsigned long long base = aadd(&t.ctr->n_live, (unsigned long long)cnt);
+        P.new_cnt[1] = (uint32_t)base; P.new_cnt[2] = (uint32_t)(base >> 32);
+        if (base + cnt > t.claim_limit) {
+            const unsigned long long keep = base < t.claim_limit ? t.claim_limit - base : 0ull;
+            aadd(&t.ctr->n_live, ~(unsigned long long)(cnt - keep) + 1ull);
+            atomicExch(&t.ctr->aborted, 1u);
+        }
+    }
+    if (fresh) ast(&t.hot[idx].tag, tag_ready(t, h));
+    else if (idx != kNoSlot && !flow_fresh) {
+        DedupPartial p;
+        partial_of_entry(L, e, p);
+        merge_at(t, idx, p, L.min_seq[e], recs, seq_base32);
+    }
+    __syncthreads();
+    if (fresh) {
+        const unsigned long long base = (unsigned long long)P.new_cnt[1] | ((unsigned long long)P.new_cnt[2] << 32);
+        if (base + my_k < t.claim_limit) t.live_list[base + my_k] = idx;
+        else ast(&t.hot[idx].tag, (uint64_t)0);
+    }
+    __syncthreads();
+}
+
 constexpr int kMaxRounds = 16;
 
 // Rounds over the items at list[0..m) (written by this workgroup) until none is left: every round takes what fits a fresh cache
@@ -524,7 +709,11 @@ __global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q
     const bool tag_on = n <= (uint64_t)kIdxMask;                  // the streaming pass put the sub-partition bits above the index
     const uint32_t idx_mask = tag_on ? kIdxMask : kIdxMaskUntagged;
     cache_init(L, tid);
-    if (tid == 0) P.retry_cnt = 0;
+    if (tid == 0) {
+        P.retry_cnt = 0;
+        // deferred claims of the grouped flush (as pass 2 of the accounter fold: a look at n_live a round early)
+        P.new_cnt[3] = (t.defer_claims && ald(&t.ctr->n_live) + 512ull * kPartEntries <= t.claim_limit) ? 1u : 0u;
+    }
     if (tid < kSubs) { P.sub_cnt[tid] = 0; P.sub_fill[tid] = 0; }
     __syncthreads();
     if (tid == 0) q.qtail[blockIdx.x] = 0;                        // every lane has read it: ready for the next batch
@@ -533,7 +722,8 @@ __global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q
         if (!(ABL & 1)) parts_flush(t, L, recs, seq_base32);
         return;
     }
-    parts_flush(t, L, recs, seq_base32);
+    if (t.defer_claims && !t.subflow) parts_flush_grouped(t, L, P, recs, seq_base32);     // sub-flow tables: every entry its own slot
+    else parts_flush(t, L, recs, seq_base32);
     const uint32_t m = P.retry_cnt;
     if (m == 0) return;
     drain_stores();

@@ -123,3 +123,27 @@ def test_dedup_with_sketches(nf, O):
     cs, _, _, hd = O.sketches(recs)
     assert np.array_equal(cm, cs) and np.array_equal(hll, hd)
     assert_records_equal(got, O.run_accounter(recs, 4096, mode=1)[0][1])
+
+
+@pytest.mark.parametrize("style", [0, 1, 2, 3])
+@pytest.mark.parametrize("batch", [1 << 30, 9000])
+def test_dedup_grouped_first_flush_on_tables_with_deferred_claims(nf, O, style, batch):
+    """Tables of 2^21 slots or more let the partition pass claim slots per workgroup (TableView.defer_claims): its first flush then
+    brings the sub-flow entries of a flow together in LDS and the leader writes a NEW flow's whole slot once, with plain stores
+    (csrc/nfagg_dedup_cached.hip parts_flush_grouped) — the state dedup_claim + dedup_merge would have left. Every style, one call
+    and several (later calls meet existing slots: the two-phase path), flows with more interfaces than a leader takes (style 0 / 2:
+    up to 14 per flow) included."""
+    th = O.zipf_thresholds(3000, 1.1)
+    recs = dedup_stream(O, 120_000, seed=300 + style, n_keys=3000, thresholds=th, style=style)
+    check_dedup(nf, O, recs, 1 << 18, batch, ingest_variant=10, table_log2_slots=21)
+
+
+def test_dedup_grouped_first_flush_hot_flow_and_epochs(nf, O):
+    th = O.zipf_thresholds(50_000, 1.1)
+    with nf.FlowTable(max_entries=1 << 19, mode=nf.MODE_KERNEL_DEDUP, table_log2_slots=21) as tab:
+        for epoch, (style, hot) in enumerate(((1, 900), (2, 0), (1, 0))):
+            recs = dedup_stream(O, 400_000, seed=40 + epoch, n_keys=50_000, thresholds=th, hot_permille=hot, style=style)
+            view = recs.view(nf.FLOW_RECORD)
+            for lo in range(0, len(recs), 150_000):
+                assert tab.ingest(view[lo:lo + 150_000]) == (nf.OK, min(150_000, len(recs) - lo))
+            assert_records_equal(nf.sort_by_key(tab.evict(nf.REASON_TIMEOUT)), O.run_accounter(recs, 1 << 22, mode=1)[0][1], "epoch %d" % epoch)
