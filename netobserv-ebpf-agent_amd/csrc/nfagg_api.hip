@@ -87,6 +87,7 @@ struct nfagg_handle {
     void* d_opt[4] = {};
     size_t d_opt_cap[4] = {};
     uint64_t epoch_len_hint = 0;   // records the last epoch that ended on "full" took (0 = this stream has not stopped on full)
+    uint64_t last_epoch_flows = 0; // slots the last epoch had claimed when it ended (flows; sub-flows on a sub-flow table): what the next one is sized by
     uint64_t abort_cap = 0;        // largest chunk worth trying after the kernels refused claims (0 = no limit known)
     // spill queues of the two-pass ingest
     void* d_spill = nullptr;
@@ -209,6 +210,12 @@ int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t 
             h->tv.spill.ovf = (uint32_t*)((char*)h->d_spill + qbytes);
             h->tv.spill.ovf_cap = (uint32_t)((h->d_spill_cap - qbytes) / sizeof(uint32_t) > 0xfffffff0ull ? 0xfffffff0ull
                                              : ((h->d_spill_cap - qbytes) / sizeof(uint32_t)) & ~3ull);
+        }
+        if (h->cfg.mode == NFAGG_MODE_KERNEL_DEDUP) {
+            // the partition pass sorts its items by sub-partition first when a partition's flows will not fit one cache (1024
+            // sub-flow entries x 2048 partitions): the last epoch's flow count is the guess, the table's size before there is one
+            const uint64_t guess = h->last_epoch_flows ? h->last_epoch_flows * (h->tv.subflow ? 1 : 2) : (h->cfg.max_entries > (1ull << 22) ? ~0ull : 0ull);
+            h->tv.spill.sort_first = h->cfg.ingest_variant == 16 ? 2u : (guess > 2500000ull ? 1u : 0u);    // 2: whatever the partition's size (tests)      // ~1200 sub-flows per partition: one cache (and its retry round) still holds them
         }
         if (h->cfg.mode == NFAGG_MODE_KERNEL_DEDUP && !h->tv.spill.xp) {     // exported cache entries of the streaming pass (38 MB)
             size_t cap = 0;
@@ -1001,6 +1008,7 @@ static int bump_epoch(nfagg_handle* h) {
 
 // The bookkeeping that ends an eviction epoch (the kernels have been launched; the device counters are reset by them).
 static int finish_epoch(nfagg_handle* h, int reason, uint64_t flows) {
+    h->last_epoch_flows = h->tv.subflow ? h->join.claimed : flows;
     h->stats.evictions[reason]++;
     h->stats.evicted_flows[reason] += flows;
     h->epoch_seq = 0; h->seq_origin = 0; h->live = 0; h->live_ub = 0; h->must_evict = false; h->split_seq = 0; h->exported = false;

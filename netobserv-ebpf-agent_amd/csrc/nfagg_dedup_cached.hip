@@ -77,7 +77,7 @@ NF_DEV void cache_init(FoldCache<K>& L, int tid) {
 // filter `door`, as in nfagg_ingest_part.hip) — one-off sub-flows of the cold tail do not take the entries of the hot ones.
 // Exactly one of the lanes that meet a new sub-flow in the same tile is turned away (the atomic's return value decides).
 template <int K, int DOORBITS, typename Cache>
-NF_DEV int claim(Cache& L, uint32_t* door, uint64_t hs, const uint64_t w[5], uint32_t ifx) {
+NF_DEV int claim(Cache& L, uint32_t* door, uint64_t hs, const uint64_t w[5], uint32_t ifx, uint32_t* fill = nullptr) {
     uint32_t e = (uint32_t)(hs >> 40) & (K - 1);
 #pragma unroll 1
     for (int p = 0; p < kProbe; p++) {
@@ -92,6 +92,7 @@ NF_DEV int claim(Cache& L, uint32_t* door, uint64_t hs, const uint64_t w[5], uin
 #pragma unroll
                 for (int k = 0; k < 5; k++) L.key[k][e] = w[k];
                 L.ifx[e] = ifx;
+                if (fill) atomicAdd(fill, 1u);                   // entries in use (the partition pass sizes its rounds by it)
                 return (int)e;
             }
         }
@@ -384,6 +385,7 @@ struct PartsLds {
     uint32_t sub_cnt[kSubs];        // ... of the first round, per sub-partition
     uint32_t sub_off[kSubs + 1];    // counting sort: start of every sub-partition's segment
     uint32_t sub_fill[kSubs];
+    uint32_t fill;                  // cache entries in use since the last cache_init (sorted rounds)
     uint32_t new_cnt[4];            // grouped flush: [0] fresh slots claimed by it, [1..2] base of their live-list range, [3] deferred claims allowed
     uint32_t grp[kPartEntries];     // grouped flush: flow hash -> leader entry + 1 (0 = empty)
 };
@@ -395,9 +397,12 @@ constexpr uint32_t kPackItems = 768;   // consecutive sub-partitions share a rou
 // been claimed. COHERENT: the items were written by this workgroup (read past L1).
 // ABL (libnfagg_diag.so only, ingest_variant 13..15: timing experiments, results are WRONG): bit 0 = no flush, bit 1 = no fold
 // into the entry, bit 2 = no cache claim either (every item only gathered and decoded).
-template <bool FIRST, bool COHERENT, int ABL = 0>
+// retry_to: where misses go (the list itself for the in-place rounds; the front of the queue region when the items were sorted into
+// its tail first: k_dedup_parts). COUNT_SUBS: keep the per-sub-partition counts of the misses (the unsorted first round).
+template <bool FIRST, bool COHERENT, int ABL = 0, bool COUNT_SUBS = true>
 NF_DEV void parts_round(const TableView& t, const SpillView& q, FoldCache<kPartEntries>& L, PartsLds& P, uint32_t* queue, uint32_t count,
-                        const void* recs, uint32_t seq_base32, uint32_t idx_mask) {
+                        const void* recs, uint32_t seq_base32, uint32_t idx_mask, uint32_t* retry_to = nullptr) {
+    if (!retry_to) retry_to = queue;
     constexpr int K = kPartEntries;
     const int tid = threadIdx.x;
     auto qload = [&](uint32_t pos) -> uint32_t { return COHERENT ? ald(&queue[pos]) : queue[pos]; };
@@ -424,7 +429,7 @@ NF_DEV void parts_round(const TableView& t, const SpillView& q, FoldCache<kPartE
         int ent = -1;
         if (valid) {
             decode_item(it_cur, idx_mask, raw, seq_base32, x);
-            if (!(ABL & 4)) ent = claim<K, 0>(L, nullptr, subflow_hash(x.h, x.ifx), x.w, x.ifx);
+            if (!(ABL & 4)) ent = claim<K, 0>(L, nullptr, subflow_hash(x.h, x.ifx), x.w, x.ifx, &P.fill);
             if (ABL & 4) asm volatile("" :: "v"(x.h), "v"(x.p.bytes), "v"(x.p.dir0));
         }
         __syncthreads();
@@ -434,9 +439,9 @@ NF_DEV void parts_round(const TableView& t, const SpillView& q, FoldCache<kPartE
             } else {
                 if (FIRST) {
                     claim_item(t, x);
-                    atomicAdd(&P.sub_cnt[(it_cur & ~kXpFlag) >> kIdxBits], 1u);      // (untagged items: all in sub-partition 0..7 of the index bits; unused then)
+                    if (COUNT_SUBS) atomicAdd(&P.sub_cnt[(it_cur & ~kXpFlag) >> kIdxBits], 1u);      // (untagged items: all in sub-partition 0..7 of the index bits; unused then)
                 }
-                queue[atomicAdd(&P.retry_cnt, 1u)] = it_cur;     // lands below (tile + 1) * kBlock
+                retry_to[atomicAdd(&P.retry_cnt, 1u)] = it_cur;  // in place: lands below (tile + 1) * kBlock
             }
         }
         it_cur = it_next; it_next = it_nn;
@@ -715,8 +720,79 @@ __global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q
         P.new_cnt[3] = (t.defer_claims && ald(&t.ctr->n_live) + 512ull * kPartEntries <= t.claim_limit) ? 1u : 0u;
     }
     if (tid < kSubs) { P.sub_cnt[tid] = 0; P.sub_fill[tid] = 0; }
+    if (tid == 0) P.fill = 0;
     __syncthreads();
     if (tid == 0) q.qtail[blockIdx.x] = 0;                        // every lane has read it: ready for the next batch
+    // ---- Round 4: SORT FIRST. The items carry three more bits of their flow's hash (the sub-partition): a counting sort of the
+    // queue by those bits — 4-byte items, no record is touched — puts every flow's items into one of eight runs, and the runs are
+    // folded one after the other, several sharing a cache while it has room (P.fill: entries in use; the density seen so far
+    // decides how many runs the next segment takes) and a flush + a fresh cache when it has not. Every flush sees COMPLETE flows
+    // (all sub-flows of a flow are in one run), so it can be the grouped one, and what used to overflow the one cache of the first
+    // round — claimed item by item on the table, gathered again in retry rounds: ~80 % of the items at 10 M flows per GPU — mostly
+    // fits now. It costs the sparse case ~9 % (more, shorter segments; two flushes where one cache nearly held the partition: dedup
+    // Zipf over 1 M flows 7.1 -> 7.8 ms per 100 M records), so the API asks for it (SpillView.sort_first) when the last epoch
+    // delivered more flows than the partitions' caches hold together — both ways are exact. Partitions too small to bother,
+    // untagged items (batches of 2^28 records or more) and regions without room for the sorted copy take the unsorted first
+    // round below.
+    const uint32_t sorted_at0 = (count + 3u) & ~3u;
+    if (ABL == 0 && q.sort_first && tag_on && (count >= 4u * kBlock || q.sort_first == 2u) && (uint64_t)sorted_at0 + count <= q.qcap) {
+        for (uint32_t k = tid; k < count; k += kBlock) {
+            const uint32_t it = my_queue[k];
+            if (it != kPad) atomicAdd(&P.sub_cnt[(it & ~kXpFlag) >> kIdxBits], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) { uint32_t o = 0; for (int s2 = 0; s2 < kSubs; s2++) { P.sub_off[s2] = o; o += P.sub_cnt[s2]; } P.sub_off[kSubs] = o; }
+        __syncthreads();
+        uint32_t* sorted = my_queue + sorted_at0;
+        for (uint32_t k = tid; k < count; k += kBlock) {
+            const uint32_t it = my_queue[k];
+            if (it == kPad) continue;
+            const uint32_t s2 = (it & ~kXpFlag) >> kIdxBits;
+            sorted[P.sub_off[s2] + atomicAdd(&P.sub_fill[s2], 1u)] = it;
+        }
+        drain_stores();
+        __syncthreads();
+        const bool grouped = t.defer_claims && !t.subflow;                 // sub-flow tables: every entry its own slot
+        constexpr uint32_t kFillLimit = 832;                               // entries a cache takes before its probe windows start to overflow
+        int s0 = 0, runs_in_cache = 0;
+        while (s0 < kSubs) {
+            // how many runs the next segment takes: one when nothing is known yet, else what the density seen in this cache allows
+            const uint32_t fill = P.fill;
+            __syncthreads();                                               // every lane has read it before the next round's claims raise it
+            int take = 1;
+            if (runs_in_cache > 0) {
+                const uint32_t per_run = fill / (uint32_t)runs_in_cache + 1u;
+                const uint32_t room = fill < kFillLimit ? kFillLimit - fill : 0u;
+                take = (int)(room / (per_run + per_run / 4u));
+                if (take == 0) {                                           // no room for another run: flush, fresh cache
+                    __syncthreads();
+                    if (grouped) parts_flush_grouped(t, L, P, recs, seq_base32); else parts_flush(t, L, recs, seq_base32);
+                    cache_init(L, tid);
+                    if (tid == 0) {
+                        P.fill = 0;
+                        P.new_cnt[3] = (t.defer_claims && ald(&t.ctr->n_live) + 512ull * kPartEntries <= t.claim_limit) ? 1u : 0u;
+                    }
+                    __syncthreads();
+                    runs_in_cache = 0;
+                    take = (int)(kFillLimit / (per_run + per_run / 4u));   // the density of the last cache is the best guess
+                    if (take < 1) take = 1;
+                }
+            }
+            int s1 = s0 + take < kSubs ? s0 + take : kSubs;
+            const uint32_t lo = P.sub_off[s0], hi = P.sub_off[s1];
+            if (hi > lo) parts_round<true, true, 0, false>(t, q, L, P, sorted + lo, hi - lo, recs, seq_base32, idx_mask, my_queue);
+            else __syncthreads();
+            runs_in_cache += s1 - s0;
+            s0 = s1;
+        }
+        if (grouped) parts_flush_grouped(t, L, P, recs, seq_base32); else parts_flush(t, L, recs, seq_base32);
+        const uint32_t m2 = P.retry_cnt;                                   // sub-flows of a run that overflowed a whole cache: claimed already
+        if (m2 == 0) return;
+        drain_stores();
+        __syncthreads();
+        parts_drain(t, q, L, P, my_queue, m2, recs, seq_base32, idx_mask, max_rounds);
+        return;
+    }
     parts_round<true, false, ABL>(t, q, L, P, my_queue, count, recs, seq_base32, idx_mask);
     if (ABL) {
         if (!(ABL & 1)) parts_flush(t, L, recs, seq_base32);

@@ -116,6 +116,8 @@ struct SpillView {
     uint32_t n_parts;              // partitions in use (power of two, <= kSpillParts): the two-pass accounter fold scales them to the
                                    // batch (launch_ingest_part), the kernel-dedup passes always use kSpillParts
     uint4* xp;                     // kernel-dedup mode: kDedupXpEntries exported cache entries of 144 bytes (nfagg_dedup_cached.hip)
+    uint32_t sort_first;           // kernel-dedup partition pass: many flows per partition expected (the API's guess from the last epoch):
+                                   // sort the items by sub-partition before the first round (both ways are exact)
 };
 constexpr uint64_t kDedupXpEntries = 256ull * 1024ull;   // streaming workgroups x their cache entries
 constexpr uint64_t kDedupXpBytes = kDedupXpEntries * 144ull;

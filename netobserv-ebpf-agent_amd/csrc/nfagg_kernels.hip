@@ -308,12 +308,13 @@ bool ingest_variant_supported(int variant) {
     if (variant == 6 || variant == 8 || variant == 9 || (variant >= 13 && variant <= 15) || (variant >= 20 && variant <= 27)) return true;
 #endif
     return variant == 0 || variant == 1 || variant == 3 || variant == 4 || variant == 5 || variant == 7 || variant == 10 || variant == 11 || variant == 12 ||
+           variant == 16 ||   // 16 (kernel-dedup mode, tests): the cached passes always, the partition pass always sorts its items first
            variant == 30;   // 30: nfagg_account's persistent epoch kernel instead of the kernel chain (everything else as 0)
 }
 static bool takes_direct(int variant, uint64_t n, uint32_t sketch_flags) {
     return variant == 1 || ((variant == 0 || variant == 30) && n < kDirectMaxBatch && sketch_flags == 0);   // with sketches on, the cached kernel fuses them: one launch
 }
-static bool dedup_takes_cached(int variant, uint64_t n) { return !(variant == 1 || (variant != 10 && (variant < 12 || variant > 15) && n < kDedupCachedMinBatch)); }
+static bool dedup_takes_cached(int variant, uint64_t n) { return !(variant == 1 || (variant != 10 && (variant < 12 || variant > 16) && n < kDedupCachedMinBatch)); }
 bool ingest_needs_spill(int mode, int variant, uint64_t n) { return mode == 0 ? takes_two_pass(variant, n) : dedup_takes_cached(variant, n); }
 bool ingest_fuses_sketches(int mode, int variant, uint64_t n, uint32_t sketch_flags) {
     return mode == 0 && !takes_direct(variant, n, sketch_flags) && variant != 6 && variant != 8 && variant != 9 && (variant < 20 || variant == 30);

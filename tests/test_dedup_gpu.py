@@ -23,7 +23,7 @@ def check_dedup(nf, O, records, max_entries, batch, **kw):
     return want
 
 
-@pytest.mark.parametrize("ingest_variant", [1, 10])   # 1 = direct per-record passes, 10 = LDS-cached passes (0 picks by batch size)
+@pytest.mark.parametrize("ingest_variant", [1, 10, 16])   # 1 = direct per-record passes, 10 = LDS-cached passes (0 picks by batch size), 16 = the same with the partition pass sorting its items first
 @pytest.mark.parametrize("style", [0, 1, 2, 3])
 @pytest.mark.parametrize("batch", [1 << 30, 1000, 257])
 def test_dedup_stream_parity(nf, O, style, batch, ingest_variant):
@@ -68,7 +68,7 @@ def test_dedup_cached_passes_with_many_flows(nf, O):
     check_dedup(nf, O, recs, 1 << 17, 1 << 30, ingest_variant=10)
 
 
-@pytest.mark.parametrize("ingest_variant", [10, 12])   # 12: the partition pass makes no retry rounds (misses merged item by item)
+@pytest.mark.parametrize("ingest_variant", [10, 12, 16])   # 12: the partition pass makes no retry rounds (misses merged item by item); 16: sorted first
 def test_dedup_partitions_with_more_subflows_than_cache_entries(nf, O, ingest_variant):
     """~2.4 M sub-flows over 2048 partitions (1024 cache entries each): exported entries and spilled records of one flow meet in
     the partition pass, sub-flows that find no entry are claimed at once and folded in retry rounds — the first interface of a
@@ -77,7 +77,7 @@ def test_dedup_partitions_with_more_subflows_than_cache_entries(nf, O, ingest_va
     check_dedup(nf, O, recs, 1 << 20, 2_000_000, ingest_variant=ingest_variant)
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 10])
+@pytest.mark.parametrize("ingest_variant", [0, 10, 16])
 @pytest.mark.parametrize("max_entries,batch", [(2, 1 << 30), (50, 333), (1, 50), (250, 4096)])
 def test_dedup_evict_on_full_inside_batches(nf, O, max_entries, batch, ingest_variant):
     th = O.zipf_thresholds(400, 1.1)
@@ -136,6 +136,7 @@ def test_dedup_grouped_first_flush_on_tables_with_deferred_claims(nf, O, style, 
     th = O.zipf_thresholds(3000, 1.1)
     recs = dedup_stream(O, 120_000, seed=300 + style, n_keys=3000, thresholds=th, style=style)
     check_dedup(nf, O, recs, 1 << 18, batch, ingest_variant=10, table_log2_slots=21)
+    check_dedup(nf, O, recs, 1 << 18, batch, ingest_variant=16, table_log2_slots=21)     # sorted first: several grouped flushes per partition
 
 
 def test_dedup_grouped_first_flush_hot_flow_and_epochs(nf, O):
@@ -147,3 +148,17 @@ def test_dedup_grouped_first_flush_hot_flow_and_epochs(nf, O):
             for lo in range(0, len(recs), 150_000):
                 assert tab.ingest(view[lo:lo + 150_000]) == (nf.OK, min(150_000, len(recs) - lo))
             assert_records_equal(nf.sort_by_key(tab.evict(nf.REASON_TIMEOUT)), O.run_accounter(recs, 1 << 22, mode=1)[0][1], "epoch %d" % epoch)
+
+
+def test_dedup_sorted_first_with_dense_partitions(nf, O):
+    """~2.4 M sub-flows over 2048 partitions — more than a cache holds per partition, ~150 per sub-partition: the sorted rounds flush
+    several times per partition (fill-aware segments, grouped flushes on a table with deferred claims), a second batch meets the
+    slots of the first, and a sub-flow table (local_fold) takes the same route with one slot per sub-flow."""
+    recs = dedup_stream(O, 3_000_000, seed=29, n_keys=300_000, style=2)
+    check_dedup(nf, O, recs, 1 << 20, 2_000_000, ingest_variant=16, table_log2_slots=21)
+    want = O.run_accounter(recs, 1 << 22, mode=1)[0][1]
+    with nf.FlowTable(max_entries=1 << 22, mode=nf.MODE_KERNEL_DEDUP, local_fold=True, ingest_variant=16) as tab:
+        view = recs.view(nf.FLOW_RECORD)
+        assert tab.ingest(view[:2_000_000]) == (nf.OK, 2_000_000)
+        assert tab.ingest(view[2_000_000:]) == (nf.OK, 1_000_000)
+        assert_records_equal(nf.sort_by_key(tab.evict(nf.REASON_TIMEOUT)), want)
