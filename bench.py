@@ -528,11 +528,12 @@ def cpu_baseline(args, d_recs, n, max_entries):
     # folds shard k through the same Accounter code. Both phases are timed; every record is looked at by one partitioner and one
     # folder. (Round 3 let every thread scan the whole sample and skip (T-1)/T of it.) The reference itself is one goroutine.
     T = max(2, min(64, (os.cpu_count() or 2) // 2))
-    folded, mc_flows, part_s, fold_s = O.partition_fold_mt(sample, T, max_entries, 1 if args.dedup else 0)
+    folded, mc_flows, part_s, fold_s, biggest = O.partition_fold_mt(sample, T, max_entries, 1 if args.dedup else 0)
     assert folded == m and mc_flows == len(ev), (folded, m, mc_flows, len(ev))
     res["multicore"] = {"value": round(m / (part_s + fold_s) / 1e6, 3), "unit": "Mrecords/s", "cores": T, "kind": "port",
                         "what": "partition-then-fold: %d threads bucket their slices by key shard, then fold one shard each (oracle/nfagg_oracle_mt.c)" % T,
                         "partition_s": round(part_s, 4), "fold_s": round(fold_s, 4),
+                        "largest_shard_share": round(biggest, 4),      # a key lives in ONE shard: the hottest flow's shard bounds the fold
                         "sample": "same sample, %.2f s" % (part_s + fold_s)}
     return res
 

@@ -85,8 +85,9 @@ static void run(mt_job* jobs, uint32_t T, void* (*fn)(void*)) {
 }
 
 /* Returns the number of records folded (n unless a shard filled up); *flows = distinct flows over all shards;
- * seconds[0] = partition (count + prefix + fill), seconds[1] = fold. T <= 256 threads = shards; n < 2^32. */
-size_t orc_partition_fold_mt(const void* records, size_t n, uint32_t T, uint64_t max_entries, int mode, size_t* flows, double seconds[2]) {
+ * seconds[0] = partition (count + prefix + fill), seconds[1] = fold, seconds[2] = the largest shard's share of the records (what
+ * bounds the fold on a skewed stream: a key lives in ONE shard). T <= 256 threads = shards; n < 2^32. */
+size_t orc_partition_fold_mt(const void* records, size_t n, uint32_t T, uint64_t max_entries, int mode, size_t* flows, double seconds[3]) {
     if (T == 0 || T > 256 || n >= 0xFFFFFFFFull) return 0;
     mt_job* jobs = (mt_job*)calloc(T, sizeof *jobs);
     uint8_t* shard_of = (uint8_t*)malloc(n ? n : 1);
@@ -114,7 +115,9 @@ size_t orc_partition_fold_mt(const void* records, size_t n, uint32_t T, uint64_t
     size_t folded = 0, fl = 0;
     for (uint32_t t = 0; t < T; t++) { folded += jobs[t].folded; fl += jobs[t].flows; }
     if (flows) *flows = fl;
-    if (seconds) { seconds[0] = t1 - t0; seconds[1] = t2 - t1; }
+    size_t biggest = 0;
+    for (uint32_t s = 0; s < T; s++) if (shard_begin[s + 1] - shard_begin[s] > biggest) biggest = shard_begin[s + 1] - shard_begin[s];
+    if (seconds) { seconds[0] = t1 - t0; seconds[1] = t2 - t1; seconds[2] = n ? (double)biggest / (double)n : 0.0; }
     free(jobs); free(shard_of); free(counts); free(start); free(idx); free(shard_begin);
     return folded;
 }

@@ -164,12 +164,12 @@ def run_accounter(records, max_entries, mode=0):
 
 
 def partition_fold_mt(records, threads, max_entries, mode=0):
-    """nfagg_oracle_mt.c: (records folded, distinct flows, partition seconds, fold seconds) on `threads` cores."""
+    """nfagg_oracle_mt.c: (records folded, distinct flows, partition seconds, fold seconds, largest shard's share) on `threads` cores."""
     r = np.ascontiguousarray(records)
     flows = C.c_size_t(0)
-    secs = (C.c_double * 2)()
+    secs = (C.c_double * 3)()
     folded = lib().orc_partition_fold_mt(_p(r), r.nbytes // 144, threads, max_entries, mode, C.byref(flows), secs)
-    return folded, flows.value, secs[0], secs[1]
+    return folded, flows.value, secs[0], secs[1], secs[2]
 
 
 def gen_stream(n, j0=0, seed=1, n_keys=1000, thresholds=None, hot_permille=0, variant=0, pop_index=None):
