@@ -80,8 +80,9 @@ NF_DEV void cache_init(Cache& L, int tid) {
 }
 
 // phase A: find or claim the entry of hash h (the creator writes the key); -1 = window full (or not admitted yet)
+// fill (pass 2's retry rounds): counts the entries created, so that the rounds can be sized by what the cache holds
 template <bool DOOR>
-NF_DEV int cache_claim(Cache& L, uint32_t* door, uint64_t h, const uint64_t w[5]) {
+NF_DEV int cache_claim(Cache& L, uint32_t* door, uint64_t h, const uint64_t w[5], uint32_t* fill = nullptr) {
     const uint64_t hk = h | 1ull;
     uint32_t e = (uint32_t)(h >> 40) & (kEntries - 1);
 #pragma unroll 1
@@ -99,6 +100,7 @@ NF_DEV int cache_claim(Cache& L, uint32_t* door, uint64_t h, const uint64_t w[5]
                 *hi64(&L.k0[e]) = w[0];
                 L.k1[e] = mk4(w[1], w[2]);
                 L.k2[e] = mk4(w[3], w[4]);
+                if (fill) atomicAdd(fill, 1u);
                 return (int)e;
             }
         }
@@ -384,6 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
 struct Pass2Lds {                 // after the Cache
     uint32_t new_list[kEntries];  // slots claimed by the current flush
     uint32_t new_cnt[4];          // [0] count, [1..2] base of the reserved live-list range, [3] deferred claims allowed
+    uint32_t fill;                // retry rounds: cache entries in use since the last cache_init
     uint32_t retry_cnt;           // indices written back for a second round
     uint32_t sub_cnt[kSubs];      // ... per sub-partition
     uint32_t sub_off[kSubs + 1];  // counting sort: start of every sub-partition's segment
@@ -425,7 +428,7 @@ NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass
         if (valid) { r.canonicalize(); r.key_words(w); h = key_hash(w); }
         const uint32_t seq32 = seq_base32 + i;
         if (TIMING) { asm volatile("" :: "v"(h)); NF_TICK2(0); }
-        int ent = valid ? cache_claim<false>(L, nullptr, h, w) : -1;
+        int ent = valid ? cache_claim<false>(L, nullptr, h, w, COHERENT ? &P.fill : nullptr) : -1;   // (COHERENT = the retry rounds)
         NF_TICK2(1);
         __syncthreads();
         NF_TICK2(2);
@@ -550,22 +553,54 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
         }
         drain_stores();
         __syncthreads();
-        // one round per run of consecutive sub-partitions that surely fits a cache (records >= flows): a partition with few
-        // misses gets one more round, not eight
-        for (int s = 0; s < kSubs;) {
-            uint32_t c = P.sub_cnt[s];
-            int e = s + 1;
-            while (e < kSubs && c + P.sub_cnt[e] <= kPackRecords) { c += P.sub_cnt[e]; e++; }
-            if (c) {
+        // The sub-partitions are folded one run after the other, several sharing a cache while it has room — a partition with
+        // few misses gets one more round, not eight. Round 4: how many runs share a cache is decided by what the cache HOLDS
+        // (P.fill, entries in use; the density seen so far sizes the next segment), not by the runs' record counts alone:
+        // with several thousand flows per partition (10 M flows per GPU) a run has ~600 records over ~180 flows, and the
+        // record-count rule (768 records surely fit) gave every run a round, a flush and a cache set-up of its own.
+        constexpr uint32_t kFillLimit = 832;                      // entries a cache takes before its probe windows start to overflow
+        int s = 0, runs = 0;
+        bool open = false;                                        // a cache holds entries that have not been flushed
+        uint32_t per_run = 0;
+        while (s < kSubs) {
+            const uint32_t fill = P.fill;
+            __syncthreads();                                      // every lane has read it before the next round's claims raise it
+            int take = 0;
+            if (open) {
+                per_run = fill / (uint32_t)runs + 1u;
+                const uint32_t room = fill < kFillLimit ? kFillLimit - fill : 0u;
+                take = (int)(room / (per_run + per_run / 4u));
+                if (take == 0) {
+                    pass2_flush<SKETCH>(t, sk, L, P, recs, seq_base32);
+                    NF_TICK3(4);
+                    open = false;
+                }
+            }
+            if (!open) {
                 cache_init(L, tid);
-                if (tid == 0) pass2_defer_ok(t, P);
+                if (tid == 0) { pass2_defer_ok(t, P); P.fill = 0; }
                 __syncthreads();
                 NF_TICK3(6);
-                pass2_round<SKETCH, TIMING, false, true>(t, sk, L, P, sorted + P.sub_off[s], c, nullptr, recs, seq_base, idx_mask, direct, ph, tp);
-                pass2_flush<SKETCH>(t, sk, L, P, recs, seq_base32);
-                NF_TICK3(4);
+                runs = 0;
+                take = per_run ? (int)(kFillLimit / (per_run + per_run / 4u)) : 1;
+                if (take < 1) take = 1;
             }
+            int e = s + take < kSubs ? s + take : kSubs;
+            if (!open) {                                           // into an empty cache: runs whose records surely fit come along
+                uint32_t c0 = P.sub_off[e] - P.sub_off[s];
+                while (e < kSubs && c0 + P.sub_cnt[e] <= kPackRecords) { c0 += P.sub_cnt[e]; e++; }
+            }
+            const uint32_t c = P.sub_off[e] - P.sub_off[s];
+            if (c) {
+                pass2_round<SKETCH, TIMING, false, true>(t, sk, L, P, sorted + P.sub_off[s], c, nullptr, recs, seq_base, idx_mask, direct, ph, tp);
+                open = true;
+            }
+            runs += e - s;
             s = e;
+        }
+        if (open) {
+            pass2_flush<SKETCH>(t, sk, L, P, recs, seq_base32);
+            NF_TICK3(4);
         }
     }
 #undef NF_TICK3
