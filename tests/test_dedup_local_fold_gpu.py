@@ -338,3 +338,54 @@ def test_bench_gpus_2_dedup_runs_the_common_stream_rehearsed_on_one_gpu(nf, O):
     # the hot flow is seen on two interfaces by both ranks: it really is one flow with an observed interface in the oracle's eviction
     hot = want[np.argmax(want["metrics"]["packets"])]
     assert hot["metrics"]["nb_observed_intf"] >= 1
+
+
+# ---------------------------------------------------------------- the limits of a sub-flow table
+@pytest.mark.parametrize("style", [1, 2])
+def test_subflow_table_large_batches_split_exactly_on_full(nf, O, style):
+    """Batches large enough for the optimistic fold (folded whole, rolled back and split when the table filled): NFAGG_FULL comes
+    at the record whose NEW (flow, interface) pair finds max_entries of them; every eviction equals one kernel-dedup table over
+    exactly the records consumed since the last one, nothing is folded twice or lost across the rollbacks."""
+    th = O.zipf_thresholds(60_000, 1.1)
+    recs = dedup_stream(O, 1_000_000, seed=26 + style, n_keys=60_000, thresholds=th, style=style)
+    view = recs.view(nf.FLOW_RECORD)
+    with nf.FlowTable(max_entries=40_000, mode=nf.MODE_KERNEL_DEDUP, local_fold=True) as tab:
+        off, start, fulls = 0, 0, 0
+        while off < len(recs):
+            rc, c = tab.ingest(view[off:])
+            off += c
+            if rc == nf.FULL:
+                assert len(tab) == 40_000
+                got = nf.sort_by_key(tab.evict(nf.REASON_FULL))
+                assert_records_equal(got, _want(O, recs[start:off]), "eviction %d" % fulls)
+                start, fulls = off, fulls + 1
+        assert_records_equal(nf.sort_by_key(tab.evict(nf.REASON_CLOSING)), _want(O, recs[start:]))
+        st = tab.stats()
+        assert fulls >= 2 and st.optimistic_rollbacks >= 1 and st.records_ingested == len(recs)
+
+
+def test_subflow_tables_end_the_epoch_when_the_sequence_window_is_used_up(nf, O):
+    """The 32-bit window of a sub-flow table does not move (the order BETWEEN the slots of one flow matters until the join): the
+    batch that would cross it gets NFAGG_FULL with nothing consumed, the caller evicts — exactly the records folded so far — and
+    resubmits. One handle and a local-fold group."""
+    th = O.zipf_thresholds(2000, 1.1)
+    recs = dedup_stream(O, 60_000, seed=71, n_keys=2000, thresholds=th, style=1)
+    view = recs.view(nf.FLOW_RECORD)
+    with nf.FlowTable(max_entries=1 << 16, mode=nf.MODE_KERNEL_DEDUP, local_fold=True) as tab:
+        assert tab.ingest(view[:20_000]) == (nf.OK, 20_000)
+        tab.debug_skip_sequence(0xFFFFFFF0 - 20_000 - 5_000)                 # 5000 sequence numbers left in the window
+        assert tab.ingest(view[20_000:]) == (nf.FULL, 0)
+        assert tab.stats().sequence_rebases == 0
+        assert_records_equal(nf.sort_by_key(tab.evict(nf.REASON_FULL)), _want(O, recs[:20_000]))
+        assert tab.ingest(view[20_000:]) == (nf.OK, 40_000)                  # a new epoch: a fresh window
+        assert_records_equal(nf.sort_by_key(tab.evict(nf.REASON_CLOSING)), _want(O, recs[20_000:]))
+        with pytest.raises(nf.NfaggError):
+            tab.window_restart_device(2, 0, 0, 0, 1 << 20)
+    with nf.FlowGroup([0, 0, 0], max_entries=1 << 16, mode=nf.MODE_KERNEL_DEDUP, local_fold=True, staging_records=7_000) as grp:
+        assert grp.ingest(view[:20_000]) == (nf.OK, 20_000)
+        grp.debug_skip_sequence(0xFFFFFFF0 - 20_000 - 5_000)
+        rc, c = grp.ingest(view[20_000:])
+        assert rc == nf.FULL and c < 7_000                                  # the chunk that would cross the window is refused
+        assert_records_equal(nf.sort_by_key(grp.evict(nf.REASON_FULL)), _want(O, recs[:20_000 + c]))
+        assert grp.ingest(view[20_000 + c:]) == (nf.OK, 40_000 - c)
+        assert_records_equal(nf.sort_by_key(grp.evict(nf.REASON_CLOSING)), _want(O, recs[20_000 + c:]))
