@@ -559,6 +559,12 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
     ex = {}
 
     def device_leg(name, mode, sk, variant, hot, what, steps=3, n_keys=0, max_entries=DEFAULT_MAX_ENTRIES):
+        try:                                          # a leg that fails says so under its own key; the others still run
+            _device_leg(name, mode, sk, variant, hot, what, steps, n_keys, max_entries)
+        except Exception as exc:
+            ex[name] = {"what": what, "error": repr(exc)[:300]}
+
+    def _device_leg(name, mode, sk, variant, hot, what, steps, n_keys, max_entries):
         if n_keys:                                   # another population than the headline's (thresholds are per population size)
             th_k = synth.zipf_thresholds(n_keys, args.zipf)
             d_th_k = torch.from_numpy(th_k.view(np.int64)).cuda()
