@@ -752,6 +752,12 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
                 "ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m2 / dt / 1e6, 1), "evictions": evs, "evicted_flows": int(flows), "us_per_epoch": round(dt / evs * 1e6, 1)}
         del d_ev
         pin_ev.close()
+    tb5, tsrc5 = leg_traffic("cache_max_flows_5000", m2)           # the PMC passes of tools/account_5000_prof.py (same records, same call)
+    if tb5 and "account_device_resident" in res:
+        r5 = res["account_device_resident"]
+        r5["traffic_bytes_per_launch"], r5["traffic_source"] = tb5, tsrc5
+        r5["frac_traffic"] = round(tb5 / (r5["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)       # latency-bound: ~0.04
+        r5["frac_stream_floor"] = round(144 * m2 / (r5["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     pin_in.close(); pin_out.close()
     m3 = min(2_000_000, m2)
     with nf.FlowTable(max_entries=5000, device=torch.cuda.current_device()) as tab:
