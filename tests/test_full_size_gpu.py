@@ -139,3 +139,53 @@ def test_configs3_at_size_eight_ranks_rehearsed_on_one_gpu(nf, O, torch):
     finally:
         for t in tabs:
             t.close()
+
+
+def test_configs4_at_size_eight_ranks_dedup_local_fold_rehearsed_on_one_gpu(nf, O, torch):
+    """configs[4] as BASELINE.json writes it — "adversarial 90 % single-hot-flow stream, dedup on, 8 GPU" — at 100 M records,
+    rehearsed on ONE GPU: 8 kernel-dedup handles created with local_fold (sub-flow tables) stand for the ranks of
+    `bench.py --gpus 8 --dedup --hot-permille 900`; rank r folds the contiguous slice [12.5 M r, 12.5 M (r + 1)) of ONE stream whose
+    hot flow alternates over two interfaces (stream variant 2) with job-global sequence numbers, then the tick: sub-flow partials
+    (256 bytes) grouped by the owner of their FLOW, device-to-device exchange, merge, join, evict owned. Every rank folds ~11 M
+    records of the hot flow; which interface is counted is decided by the rank that holds the stream's first record. The union
+    must be bit-identical to ONE kernel-dedup table (bpf/flows.c:76-143; the oracle in mode 1, pinned to oracle/_ref)."""
+    n_ranks, n, keys = 8, 100_000_000, 1_000_000
+    per = n // n_ranks
+    th = nf.synth.zipf_thresholds(keys, 1.1)
+    d = dev_stream(torch, nf.synth, n, seed=5, n_keys=keys, thresholds=th, variant=2, hot_permille=900)    # SURVEY §8(d) config 5: seed 5
+    host = d.cpu().numpy()
+    want = O.run_accounter(host, 1 << 22, mode=1)[0][1]
+    assert 400_000 < len(want) <= keys and (want["metrics"]["nb_observed_intf"] >= 1).any()
+    tabs = [nf.FlowTable(max_entries=1 << 21, mode=nf.MODE_KERNEL_DEDUP, local_fold=True) for _ in range(n_ranks)]
+    try:
+        for r, tab in enumerate(tabs):
+            tab.set_sequence(r * per)
+            assert tab.ingest_device(d.data_ptr() + r * per * 144, per) == (nf.OK, per)
+        seen = [len(t) for t in tabs]                                     # (flow, interface) pairs per rank
+        pb = tabs[0].partial_bytes
+        assert pb == 256
+        exp = [torch.empty(s * pb // 8, dtype=torch.int64, device="cuda") for s in seen]
+        torch.cuda.synchronize()
+        counts = []
+        for r, tab in enumerate(tabs):
+            rc, c, total = tab.partials_export_device(n_ranks, r, exp[r].data_ptr(), seen[r])
+            assert rc == nf.OK and total == sum(c) and c[r] == 0
+            counts.append(c)
+        for owner in range(n_ranks):
+            for src in range(n_ranks):
+                if src != owner and counts[src][owner]:
+                    tabs[owner].partials_merge_device(n_ranks, owner, exp[src].data_ptr() + sum(counts[src][:owner]) * pb, counts[src][owner])
+        got = []
+        for r, tab in enumerate(tabs):
+            rc, need = tab.evict_owned_device(n_ranks, r, 0, 0)
+            assert rc == nf.TRUNCATED and need > 0
+            out = torch.empty(need * 144 + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+            assert tab.evict_owned_device(n_ranks, r, out.data_ptr(), need) == (nf.OK, need)
+            got.append(out[: need * 144].cpu().numpy().view(nf.FLOW_RECORD))
+        assert sum(len(g) for g in got) == len(want)
+        assert_records_equal(nf.sort_by_key(np.concatenate(got)), want, "configs[4] at size: union of 8 dedup ranks vs ONE kernel-dedup table")
+        hot = want[np.argmax(want["metrics"]["packets"])]
+        assert hot["metrics"]["packets"] > 0.8 * n * 0.45                  # the hot flow: ~90 % of the records, counted on ONE of its two interfaces
+    finally:
+        for t in tabs:
+            t.close()
