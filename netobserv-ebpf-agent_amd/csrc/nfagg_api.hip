@@ -134,7 +134,7 @@ struct nfagg_handle {
     DevCounters* h_jctr = nullptr;  // pinned mirror of jv.ctr
     void* d_join = nullptr;         // slot_of[]: the J slot of every live sub-flow
     size_t d_join_cap = 0;
-    struct { bool valid = false; uint32_t n_shards = 0, shard_id = 0; uint64_t flows = 0, claimed = 0; } join;
+    struct { bool valid = false, dirty = false; uint32_t n_shards = 0, shard_id = 0; uint64_t flows = 0, claimed = 0; } join;   // dirty: J may hold claims
     nfagg_stats stats{};
     std::vector<EventPair> ev_pending;
     std::vector<EventPair> ev_free;
@@ -616,8 +616,8 @@ int subflow_join_table_next_epoch(nfagg_handle* h) {
 
 // A join that was made and not delivered (the caller's buffer was too small) is void once the table changes again.
 int subflow_join_discard(nfagg_handle* h) {
-    if (!h->join.valid) return NFAGG_OK;
-    h->join.valid = false;
+    if (!h->join.dirty) { h->join.valid = false; return NFAGG_OK; }      // (dirty without valid: a join that failed part-way)
+    h->join.valid = false; h->join.dirty = false;
     const hipError_t e = launch_reset_counters(h->jv, h->stream);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "join table reset failed: %s", hipGetErrorString(e));
     return subflow_join_table_next_epoch(h);
@@ -634,6 +634,7 @@ int subflow_join(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id) {
     if ((rc = subflow_join_table(h)) != NFAGG_OK) return rc;
     if ((rc = ensure_bytes(h, &h->d_join, &h->d_join_cap, (size_t)claimed * sizeof(uint32_t) + 16)) != NFAGG_OK) return rc;
     const uint64_t seq_limit = h->must_evict ? h->split_seq - h->seq_origin : ~0ull;
+    h->join.dirty = true;
     const hipError_t e = launch_subflow_join(h->tv, h->jv, claimed, seq_limit, n_shards, shard_id, (uint32_t*)h->d_join, h->stream);
     if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "sub-flow join launch failed: %s", hipGetErrorString(e));
     HIP_TRY(h, hipMemcpyAsync(h->h_jctr, h->jv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
@@ -1053,7 +1054,7 @@ static int subflow_evict(nfagg_handle* h, int reason, uint32_t n_shards, uint32_
     if (h->h_jctr->error) return fail(h, NFAGG_EDEVICE, "sub-flow join table kernel bailed out (code %u)", h->h_jctr->error);
     if (h->h_jctr->n_out != flows)
         return fail(h, NFAGG_EDEVICE, "evict wrote %llu records, expected %llu", (unsigned long long)h->h_jctr->n_out, (unsigned long long)flows);
-    h->join.valid = false;
+    h->join.valid = false; h->join.dirty = false;                 // launch_evict_dedup left J's counters reset; its slots expire with the tag
     if ((rc = subflow_join_table_next_epoch(h)) != NFAGG_OK) return rc;
     return finish_epoch(h, reason, flows);
 }
