@@ -198,8 +198,9 @@ int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t 
     if (ingest_needs_spill((int)h->cfg.mode, (int)h->cfg.ingest_variant, n)) {
         // room for twice the even share of a batch in which every record spills; beyond that the kernel merges directly
         uint64_t qcap = (2 * n / kSpillParts + 1024 + 3) & ~3ull;
-        // overflow list: every record may overflow, plus one padded group per partition per workgroup
-        const uint64_t ovf_cap = ((n + 3) & ~3ull) + 256ull * kSpillParts * 4;
+        // overflow list: every item (record; kernel-dedup mode: or exported cache entry) may overflow, ONE slot each
+        // (overflow_push_one), plus one padded group per partition per workgroup
+        const uint64_t ovf_cap = ((n + 3) & ~3ull) + kDedupXpEntries + 256ull * kSpillParts * 4;
         if (qcap > h->tv.spill.qcap || ovf_cap > h->tv.spill.ovf_cap) {
             if (qcap < h->tv.spill.qcap) qcap = h->tv.spill.qcap;
             const size_t qbytes = (size_t)kSpillParts * qcap * sizeof(uint32_t);

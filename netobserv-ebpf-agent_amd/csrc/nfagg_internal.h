@@ -108,7 +108,7 @@ struct SpillView {
     uint32_t* queue;               // kSpillParts x qcap record indices (0xffffffff = padding)
     uint32_t* qtail;               // kSpillParts reserved-entry counters; zero between launches
     uint32_t qcap;                 // entries per partition, multiple of 4
-    uint32_t* ovf;                 // overflow list (partition queue or staging group full), groups of 4
+    uint32_t* ovf;                 // overflow list (partition queue or staging group full): groups of 4 and single items, read item by item
     uint32_t* ovf_tail;
     uint32_t ovf_cap;
     unsigned int* error;           // = &DevCounters.error

@@ -24,7 +24,15 @@ NF_DEV uint32_t part_of(uint64_t h, uint32_t shift) { return (uint32_t)(h >> shi
 
 NF_DEV void overflow_push(const SpillView& q, uint4 v) {
     const uint32_t at = aadd(q.ovf_tail, 4u);
-    if (at + 4 <= q.ovf_cap) *reinterpret_cast<uint4*>(q.ovf + at) = v;
+    if (at + 4 > q.ovf_cap) { atomicExch(q.error, 5u); return; }
+    if ((at & 3u) == 0) *reinterpret_cast<uint4*>(q.ovf + at) = v;
+    else { q.ovf[at] = v.x; q.ovf[at + 1] = v.y; q.ovf[at + 2] = v.z; q.ovf[at + 3] = v.w; }   // behind single items: not 16-byte aligned
+}
+// One item (a spill that found its staging group full twice in a row): ONE slot, so that the list's worst case stays one slot
+// per record — a batch whose uncached records all belong to one partition (a handful of flows) sends nearly all of them here.
+NF_DEV void overflow_push_one(const SpillView& q, uint32_t item) {
+    const uint32_t at = aadd(q.ovf_tail, 1u);
+    if (at < q.ovf_cap) q.ovf[at] = item;
     else atomicExch(q.error, 5u);
 }
 
@@ -71,7 +79,7 @@ struct Lane {
         if (carry != 0xffffffffu) {
             const uint32_t at = atomicAdd(&S.cnt[carry_p], 1u);
             if (at < (uint32_t)kStage) { S.buf[carry_p][at] = carry; if (at == (uint32_t)kStage - 1) fill_p[0] = carry_p; }
-            else overflow_push(q, make_uint4(carry, 0xffffffffu, 0xffffffffu, 0xffffffffu));   // full twice in a row: very rare
+            else overflow_push_one(q, carry);   // full twice in a row: very rare
             carry = 0xffffffffu;
         }
         if (spill_now) {
@@ -86,7 +94,7 @@ struct Lane {
         if (carry != 0xffffffffu) {
             const uint32_t at = atomicAdd(&S.cnt[carry_p], 1u);
             if (at < (uint32_t)kStage) S.buf[carry_p][at] = carry;
-            else overflow_push(q, make_uint4(carry, 0xffffffffu, 0xffffffffu, 0xffffffffu));
+            else overflow_push_one(q, carry);
         }
         __syncthreads();
         // pending groups, then whatever is staged (padded with invalid indices): groups filled in the last tile are still in LDS

@@ -162,3 +162,17 @@ def test_dedup_sorted_first_with_dense_partitions(nf, O):
         assert tab.ingest(view[:2_000_000]) == (nf.OK, 2_000_000)
         assert tab.ingest(view[2_000_000:]) == (nf.OK, 1_000_000)
         assert_records_equal(nf.sort_by_key(tab.evict(nf.REASON_TIMEOUT)), want)
+
+
+@pytest.mark.parametrize("ingest_variant", [0, 16])
+@pytest.mark.parametrize("n_keys", [1, 2])
+def test_dedup_one_launch_whose_records_all_belong_to_one_partition(nf, O, n_keys, ingest_variant):
+    """1.5 M records of one or two flows in ONE launch (found by tests/tools/soak.py): the records the streaming pass does not
+    cache (the TLS ones) all spill to one partition, its staging group of four is full for nearly every one of them, and they
+    go to the overflow list one slot each (nfagg_spill.h overflow_push_one; four slots each overran the list: error 5)."""
+    recs = O.gen_stream(1_500_000, seed=918135167, n_keys=n_keys, variant=1)
+    want = O.run_accounter(recs, 1 << 12, mode=1)[0][1]
+    with nf.FlowTable(max_entries=1 << 12, mode=nf.MODE_KERNEL_DEDUP, ingest_variant=ingest_variant, staging_records=1 << 21) as tab:
+        assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
+        got = nf.sort_by_key(tab.evict(nf.REASON_CLOSING))
+    assert_records_equal(got, want, "one-partition batch")
