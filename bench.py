@@ -716,7 +716,7 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
                                   "nfagg_ringbuf_drain straight into the pinned staging buffer -> nfagg_staging_commit (H2D + fold, asynchronous) -> "
                                   "nfagg_evict to host memory: %d M records, consumer time only" % (m_r // 1_000_000),
                           "ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m_r / dt / 1e6, 1), "drains": drains, "evicted_flows": int(fl),
-                          "bound": "host cores copying 144-byte samples out of the ring into the pinned buffer (nfagg_ringbuf_drain: runs of plain samples over up to 8 threads), then PCIe"}
+                          "bound": "host cores copying 144-byte samples out of the ring into the pinned buffer (nfagg_ringbuf_drain: runs of plain samples over 4 threads), then PCIe"}
         del flat, ring
     except Exception as exc:
         ex["e2e_ring"] = {"error": repr(exc)[:300]}

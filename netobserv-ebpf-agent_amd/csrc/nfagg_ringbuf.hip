@@ -14,7 +14,7 @@ constexpr uint64_t kHdr = 8;                 // BPF_RINGBUF_HDR_SZ
 constexpr uint32_t kRecord = 144;            // sizeof(flow_record_t), bpf/types.h:212-215
 constexpr uint64_t kStride = kHdr + kRecord; // a committed flow sample: header + 144 bytes (already a multiple of 8)
 constexpr size_t kBulkMin = 32768;           // samples from which a drain is worth splitting over threads
-constexpr unsigned kBulkThreads = 8;         // one core copies ~5 GB/s of 144-byte samples; the pinned buffer feeds a ~50 GB/s link
+constexpr unsigned kBulkThreads = 4;         // one core copies ~5 GB/s of 144-byte samples; the pinned buffer feeds a ~50 GB/s link. (Eight: faster on some boxes, 2-4 x slower on others — profiles/r04_ring_drain_threads.txt)
 
 inline void copy_sample(const nfagg_ringbuf* rb, uint64_t dstart, uint8_t* o) {
     const uint64_t size = rb->mask + 1;
