@@ -727,31 +727,44 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
     m2 = min(8_000_000, m)
     ends_cap = m2 // 5000 + 16
     res = {}
-    with nf.FlowTable(max_entries=5000, device=torch.cuda.current_device()) as tab:
-        d_ev = torch.empty((m2 + 8192) * 144, dtype=torch.uint8, device="cuda")
-        h_ev = np.empty(m2 // 2 + 8192, dtype=nf.FLOW_RECORD)       # the caller's buffer for the evicted flows, reused call after call
-        h_ev.view(np.uint8)[::4096] = 0                             # touched once: a long-lived buffer has its pages
-        pin_ev = nf.PinnedRecords(m2 // 2 + 8192)
-        def account(dev):
-            if dev == 1:
-                rc, c, ends = tab.account_device(d_recs.data_ptr(), m2, d_ev.data_ptr(), m2 + 8192, ends_cap)
-                n_ep, flows = len(ends), (ends[-1] if ends else 0)
-            else:
-                rc, c, epochs = (tab.account(host[:m2], out=h_ev, max_epochs=ends_cap) if dev == 0 else
-                                 tab.account(pin_in.records[:m2], out=pin_ev.records, max_epochs=ends_cap))
-                n_ep, flows = len(epochs), sum(len(e) for e in epochs)
-            assert rc == nf.OK and c == m2, (rc, c)
-            flows += len(tab.evict(nf.REASON_CLOSING, cap=8192))
-            return n_ep + 1, flows
-        for dev in (0, 2, 1):
-            account(dev)
-            t0 = time.perf_counter()
-            evs, flows = account(dev)
-            dt = time.perf_counter() - t0
-            res[("account_host_path", "account_device_resident", "account_host_path_page_locked")[dev]] = {
-                "ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m2 / dt / 1e6, 1), "evictions": evs, "evicted_flows": int(flows), "us_per_epoch": round(dt / evs * 1e6, 1)}
-        del d_ev
-        pin_ev.close()
+
+    def account_leg(variant, into):
+        with nf.FlowTable(max_entries=5000, device=torch.cuda.current_device(), ingest_variant=variant) as tab:
+            d_ev = torch.empty((m2 + 8192) * 144, dtype=torch.uint8, device="cuda")
+            h_ev = np.empty(m2 // 2 + 8192, dtype=nf.FLOW_RECORD)   # the caller's buffer for the evicted flows, reused call after call
+            h_ev.view(np.uint8)[::4096] = 0                         # touched once: a long-lived buffer has its pages
+            pin_ev = nf.PinnedRecords(m2 // 2 + 8192)
+            def account(dev):
+                if dev == 1:
+                    rc, c, ends = tab.account_device(d_recs.data_ptr(), m2, d_ev.data_ptr(), m2 + 8192, ends_cap)
+                    n_ep, flows = len(ends), (ends[-1] if ends else 0)
+                else:
+                    rc, c, epochs = (tab.account(host[:m2], out=h_ev, max_epochs=ends_cap) if dev == 0 else
+                                     tab.account(pin_in.records[:m2], out=pin_ev.records, max_epochs=ends_cap))
+                    n_ep, flows = len(epochs), sum(len(e) for e in epochs)
+                assert rc == nf.OK and c == m2, (rc, c)
+                flows += len(tab.evict(nf.REASON_CLOSING, cap=8192))
+                return n_ep + 1, flows
+            try:
+                for dev in (0, 2, 1):
+                    account(dev)
+                    t0 = time.perf_counter()
+                    evs, flows = account(dev)
+                    dt = time.perf_counter() - t0
+                    into[("account_host_path", "account_device_resident", "account_host_path_page_locked")[dev]] = {
+                        "ms": round(dt * 1e3, 2), "Mrecords_per_s": round(m2 / dt / 1e6, 1), "evictions": evs, "evicted_flows": int(flows), "us_per_epoch": round(dt / evs * 1e6, 1)}
+            finally:
+                del d_ev
+                pin_ev.close()
+
+    account_leg(0, res)
+    # ingest_variant 31 (csrc/nfagg_epoch_par.hip): the epochs of a call found first — previous-occurrence links, a
+    # prefix count per epoch — then the complete ones folded together; same evictions, in the same order
+    try:
+        res["epochs_found_first_variant_31"] = {}
+        account_leg(31, res["epochs_found_first_variant_31"])
+    except Exception as exc:
+        res["epochs_found_first_variant_31"] = {"error": repr(exc)[:300]}
     tb5, tsrc5 = leg_traffic("cache_max_flows_5000", m2)           # the PMC passes of tools/account_5000_prof.py (same records, same call)
     if tb5 and "account_device_resident" in res:
         r5 = res["account_device_resident"]

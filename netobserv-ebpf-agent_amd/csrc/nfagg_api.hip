@@ -135,6 +135,12 @@ struct nfagg_handle {
     void* d_join = nullptr;         // slot_of[]: the J slot of every live sub-flow
     size_t d_join_cap = 0;
     struct { bool valid = false, dirty = false; uint32_t n_shards = 0, shard_id = 0; uint64_t flows = 0, claimed = 0; } join;   // dirty: J may hold claims
+    // epoch-parallel evict-on-full loop (ingest_variant 31, nfagg_account_par.inc): scratch table, analysis arrays, pinned mirrors
+    TableView pv{};
+    DevCounters* h_pctr = nullptr;
+    uint32_t* h_par = nullptr;      // pinned: control words, then the cuts
+    void* d_par[9] = {};            // hashes, sorted hashes, indices, sorted indices, prev, sort scratch, control + cuts, tagged copy, scratch eviction
+    size_t d_par_cap[9] = {};
     nfagg_stats stats{};
     std::vector<EventPair> ev_pending;
     std::vector<EventPair> ev_free;
@@ -814,6 +820,13 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->tv.aux) hipFree(h->tv.aux);
     if (h->tv.live_list) hipFree(h->tv.live_list);
     if (h->tv.ctr) hipFree(h->tv.ctr);
+    if (h->pv.hot) hipFree(h->pv.hot);
+    if (h->pv.cold) hipFree(h->pv.cold);
+    if (h->pv.live_list) hipFree(h->pv.live_list);
+    if (h->pv.ctr) hipFree(h->pv.ctr);
+    if (h->h_pctr) hipHostFree(h->h_pctr);
+    if (h->h_par) hipHostFree(h->h_par);
+    for (int k = 0; k < 9; k++) if (h->d_par[k]) hipFree(h->d_par[k]);
     if (h->jv.hot) hipFree(h->jv.hot);
     if (h->jv.cold) hipFree(h->jv.cold);
     if (h->jv.aux) hipFree(h->jv.aux);
@@ -1462,6 +1475,8 @@ static int account_chain_launch(nfagg_handle* h, const void* d, size_t n, void* 
     return NFAGG_OK;
 }
 
+#include "nfagg_account_par.inc"
+
 // d_out: DEVICE. epoch_end: HOST. Evictions append to d_out; *n_epochs of them, the e-th ends at record epoch_end[e].
 static int account_device_core(nfagg_handle* h, const void* d_records, size_t n, void* d_out, size_t out_cap, uint64_t* epoch_end,
                                size_t max_epochs, size_t* n_epochs_out, size_t* consumed_out) {
@@ -1479,7 +1494,20 @@ static int account_device_core(nfagg_handle* h, const void* d_records, size_t n,
         return NFAGG_OK;
     };
     if (h->must_evict && n) rc = evict_pending();
+    bool par_declined = false;
     while (rc == NFAGG_OK && consumed < n) {
+        if (!par_declined && account_par_ok(h, n - consumed, out_cap - out_pos) && n_ep < max_epochs) {
+            // ingest_variant 31: the epochs of the call found first, then folded together (nfagg_account_par.inc)
+            size_t c = 0, e = 0, o = 0; uint32_t stop = 0;
+            rc = account_par_launch(h, base + consumed * kRecordBytes, n - consumed, obase + out_pos * kRecordBytes, out_cap - out_pos,
+                                    epoch_end + n_ep, max_epochs - n_ep, &c, &e, &o, &stop);
+            for (size_t k = 0; k < e; k++) epoch_end[n_ep + k] += out_pos;
+            consumed += c; n_ep += e; out_pos += o;
+            if (rc == kParDeclined) { rc = NFAGG_OK; par_declined = true; continue; }
+            if (rc != NFAGG_OK) break;
+            if (stop == 2) { rc = NFAGG_TRUNCATED; break; }
+            continue;
+        }
         if (account_fast_ok(h, n - consumed, out_cap - out_pos) && n_ep < max_epochs) {
             size_t c = 0, e = 0, o = 0; uint32_t stop = 0;
             rc = (h->cfg.ingest_variant == 30 ? account_fast_launch : account_chain_launch)(

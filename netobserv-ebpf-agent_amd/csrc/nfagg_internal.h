@@ -157,6 +157,21 @@ bool ingest_variant_supported(int variant);
 bool ingest_needs_spill(int mode, int variant, uint64_t n);
 hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                               uint64_t seq_base, int variant, hipStream_t s);
+// nfagg_epoch_par.hip / nfagg_account_par.inc (ingest_variant 31): the two-pass fold of a batch whose records carry an epoch number
+// in key byte 39 into a table keyed by it; the analysis and copy kernels of the epoch-parallel evict-on-full loop
+hipError_t launch_ingest_part_k39(const TableView& t, const SpillView& q, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
+hipError_t launch_par_hash(const void* d_records, uint64_t n, uint64_t* d_hash, uint32_t* d_idx, hipStream_t s);
+hipError_t launch_par_sort(void* temp, size_t* temp_bytes, const uint64_t* k_in, uint64_t* k_out, const uint32_t* v_in, uint32_t* v_out,
+                           uint64_t n, hipStream_t s);
+hipError_t launch_par_links(const void* d_records, const uint64_t* d_hash_s, const uint32_t* d_idx_s, uint64_t n, int32_t* d_prev,
+                            uint32_t* d_collision, hipStream_t s);
+hipError_t launch_par_live(const TableView& t, const void* d_records, int32_t* d_prev, uint64_t n, hipStream_t s);
+hipError_t launch_par_cuts(const int32_t* d_prev, uint64_t n, uint32_t max_entries, uint32_t live0, uint32_t* d_cuts, uint32_t max_cuts,
+                           uint32_t* d_n_cuts, hipStream_t s);
+hipError_t launch_par_tag_copy(const void* d_records, uint64_t first, uint64_t m, const uint32_t* d_cuts, uint32_t e0, uint32_t n_ep,
+                               void* d_dst, hipStream_t s);
+hipError_t launch_par_regroup(const void* d_evicted, uint64_t n_flows, uint32_t max_entries, uint32_t n_ep, void* d_out, uint32_t* d_cnt,
+                              uint32_t* d_bad, hipStream_t s);
 // Kernel-dedup mode: nfagg_dedup.hip (direct: a claim pass, then a fold pass) / nfagg_dedup_cached.hip (one streaming pass + partitions).
 hipError_t launch_ingest_dedup(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
 hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, int variant, hipStream_t s);

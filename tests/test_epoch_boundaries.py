@@ -29,10 +29,11 @@ def epoch_cuts(prev, max_entries, live_at_start=None):
     cuts, s = [], 0
     live_mask, live = (live_at_start if live_at_start is not None else (np.zeros(n, dtype=bool), 0))
     while True:
+        first = not cuts                                             # the epoch the table's live flows belong to (it may end at record 0)
         new = prev[s:] < s
-        if s == 0:
-            new &= ~live_mask                                        # a flow the table already holds is no new entry
-        budget = max_entries - (live if s == 0 else 0)               # entries the epoch may still create
+        if first:
+            new &= ~live_mask[s:]                                    # a flow the table already holds is no new entry
+        budget = max_entries - (live if first else 0)                # entries the epoch may still create
         c = np.cumsum(new)
         over = np.nonzero(c == budget + 1)[0]
         if len(over) == 0:
@@ -71,8 +72,9 @@ def test_an_epoch_that_spans_calls(O):
     recs = O.gen_stream(12_000, seed=5, n_keys=500, thresholds=O.zipf_thresholds(500, 1.1), variant=1)
     k = key_ids(recs)
     whole = epoch_cuts(prev_links(k), max_entries)
-    for split in (1, 37, 5_000, 11_999):
-        first = [c for c in whole if c <= split]
+    full_at = [c - 1 for c in whole[:3]]                             # calls that end with the map exactly full: the next record evicts
+    for split in (1, 37, 5_000, 11_999, *whole[:2], *full_at):
+        first = [c for c in whole if c < split]                      # (a cut AT the split is the second call's: its first record finds the map full)
         start = first[-1] if first else 0                            # the epoch in progress when the second call starts
         live_keys = np.unique(k[start:split])
         k2 = k[split:]

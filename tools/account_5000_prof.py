@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The device-resident nfagg_account_device leg of bench.py's extra.cache_max_flows_5000 on its own (8 M records of the configs[1]
 stream, CACHE_MAX_FLOWS = 5000, the evict-on-full loop on the device), for the rocprofv3 passes of tools/profile_bench.sh
-(PROF_PROG="python tools/account_5000_prof.py"): prints one bench-shaped JSON line. usage: account_5000_prof.py [--steps K]"""
+(PROF_PROG="python tools/account_5000_prof.py"): prints one bench-shaped JSON line. usage: account_5000_prof.py [--steps K] [--variant V]"""
 import json
 import os
 import sys
@@ -16,6 +16,7 @@ import netobserv_ebpf_agent_amd as nf
 from netobserv_ebpf_agent_amd import synth
 
 steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 1
+variant = int(sys.argv[sys.argv.index("--variant") + 1]) if "--variant" in sys.argv else 0     # 31: the epoch-parallel loop (experimental)
 n, keys = 8_000_000, 1_000_000
 th = synth.zipf_thresholds(keys, 1.1)
 d_th = torch.from_numpy(th.view(np.int64)).cuda()
@@ -25,7 +26,7 @@ torch.cuda.synchronize()
 synth.stream_device(d.data_ptr(), n, seed=2, n_keys=keys, d_thresholds=d_th.data_ptr())
 torch.cuda.synchronize()
 ends_cap = n // 5000 + 16
-with nf.FlowTable(max_entries=5000) as tab:
+with nf.FlowTable(max_entries=5000, ingest_variant=variant) as tab:
     t0 = time.perf_counter()
     flows = evs = 0
     for _ in range(steps):
@@ -35,6 +36,6 @@ with nf.FlowTable(max_entries=5000) as tab:
         evs += len(ends) + 1
     dt = time.perf_counter() - t0
 print(json.dumps({"config": {"workload": "extra.cache_max_flows_5000.account_device_resident: %d M records, CACHE_MAX_FLOWS 5000" % (n // 1_000_000),
-                             "hot_permille": 0, "stream_variant": 0, "mode": "accounter", "max_entries": 5000,
+                             "hot_permille": 0, "stream_variant": 0, "mode": "accounter", "max_entries": 5000, "ingest_variant": variant,
                              "evicted_flows_per_step": flows // steps},
                   "roofline": {"launches": steps, "records_per_launch": n}, "ms_per_call": round(dt / steps * 1e3, 3), "evictions_per_call": evs // steps}))
