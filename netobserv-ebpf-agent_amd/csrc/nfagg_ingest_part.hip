@@ -252,6 +252,13 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
 #define NF_TICK(k) do { if (TIMING) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
     if (TIMING) tp = __builtin_readcyclecounter();
     const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
+    // Tiles go round the workgroups (every workgroup's cache sees the whole stream's hot flows) — except K39: the scratch batch of
+    // the epoch-parallel account path is a sequence of epochs of a few tiles each, and a flow of epoch e exists in those tiles only:
+    // a workgroup takes CONSECUTIVE tiles there, so that the records of a flow meet in one cache.
+    const uint64_t tiles_each = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const uint64_t tile_first = K39 ? (uint64_t)blockIdx.x * tiles_each : (uint64_t)blockIdx.x;
+    const uint64_t tile_end = K39 ? (tile_first + tiles_each < n_tiles ? tile_first + tiles_each : n_tiles) : n_tiles;
+    const uint64_t tile_step = K39 ? 1ull : (uint64_t)gridDim.x;
     unsigned long long skipped = 0, spilled = 0;
     const bool tag_on = n <= (uint64_t)kIdxMask;                       // the index leaves room for the sub-partition bits
     const uint32_t sub_shift = sub_shift_of(q);
@@ -271,14 +278,14 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
     // a tile. Loads are unconditional on a clamped index; `valid` only gates the fold.
     bool valid; uint64_t i; Rec r;
     {
-        const uint64_t pos = (uint64_t)blockIdx.x * kBlock + tid;
+        const uint64_t pos = tile_first * kBlock + tid;
         valid = pos < n; i = valid ? pos : 0;
         load_record_head(recs, i, r);
     }
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (uint64_t tile = tile_first; tile < tile_end; tile += tile_step) {
         bool valid_n; uint64_t i_n; Rec r_n;
         {
-            const uint64_t pos = (tile + gridDim.x) * kBlock + tid;
+            const uint64_t pos = (tile + tile_step) * kBlock + tid;
             valid_n = pos < n; i_n = valid_n ? pos : 0;
             load_record_head(recs, i_n, r_n);
         }
@@ -675,7 +682,7 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     hipLaunchKernelGGL((k_pass2<SKETCH, T2, K39>), dim3(q.n_parts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_merge_overflow<SKETCH, K39>), dim3(32), dim3(256), 0, s, t, sk, q, d_records, n, seq_base);   // normally empty
+    hipLaunchKernelGGL((k_merge_overflow<SKETCH, K39>), dim3(K39 ? 256 : 32), dim3(256), 0, s, t, sk, q, d_records, n, seq_base);   // normally empty (K39: a percent of an all-miss batch)
     return hipGetLastError();              // the overflow tail is reset by k_finalize, the last launch of every ingest call
 }
 
