@@ -394,6 +394,9 @@ int nfagg_evict_device(nfagg_handle* h, int reason, void* d_out, size_t cap, siz
  * thousand records; here that whole loop — split search, fold, eviction, next epoch — runs on the device (max_entries <= 32768,
  * NFAGG_MODE_ACCOUNTER: a chain of small kernels driven by a control block in device memory, replayed from a hipGraph;
  * ingest_variant 30 = one persistent cooperative kernel instead), the host reads the control block back once per 24 windows.
+ * ingest_variant 31 (opt-in, round 4; no sketches): WHERE the epochs of a call end is found first — previous-occurrence links from one
+ * sort of (key hash, index) pairs, one prefix count per epoch — and the complete epochs are then folded TOGETHER by the large-batch
+ * kernels (csrc/nfagg_epoch_par.hip): same evictions in the same order, 2.3 x the chain's rate device-resident.
  * All pointers HOST memory: */
 int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, size_t out_cap, uint64_t* epoch_end,
                   size_t max_epochs, size_t* n_epochs, size_t* consumed);
