@@ -758,13 +758,12 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
                 pin_ev.close()
 
     account_leg(0, res)
-    # ingest_variant 31 (csrc/nfagg_epoch_par.hip): the epochs of a call found first — previous-occurrence links, a
-    # prefix count per epoch — then the complete ones folded together; same evictions, in the same order
+    # the same through the kernel chain alone (ingest_variant 30: what calls of a few epochs take, and the fallback of the default path)
     try:
-        res["epochs_found_first_variant_31"] = {}
-        account_leg(31, res["epochs_found_first_variant_31"])
+        res["kernel_chain_variant_30"] = {}
+        account_leg(30, res["kernel_chain_variant_30"])
     except Exception as exc:
-        res["epochs_found_first_variant_31"] = {"error": repr(exc)[:300]}
+        res["kernel_chain_variant_30"] = {"error": repr(exc)[:300]}
     tb5, tsrc5 = leg_traffic("cache_max_flows_5000", m2)           # the PMC passes of tools/account_5000_prof.py (same records, same call)
     if tb5 and "account_device_resident" in res:
         r5 = res["account_device_resident"]

@@ -113,14 +113,13 @@ struct nfagg_handle {
     void* d_exp = nullptr;          // 64 owner counts + 64 segment cursors + the owned-flows count
     size_t d_exp_cap = 0;
     unsigned long long* h_exp = nullptr;   // pinned mirror of the counts
-    // nfagg_account*: control block of the persistent epoch kernel (device + pinned mirror), epoch ends, ring scratch
+    // nfagg_account*: control block of the epoch kernel chain (device + pinned mirror), epoch ends, slot scratch
     void* d_ep[3] = {};             // [0] control block, [1] epoch ends, [2] live-list scratch
     size_t d_ep_cap[3] = {};
     void* d_ep_out = nullptr;       // second device buffer for evictions (nfagg_account alternates with d_evict)
     size_t d_ep_out_cap = 0;
     void* h_ep = nullptr;           // pinned: control block, then the epoch ends
     size_t h_ep_cap = 0;
-    uint64_t ep_phase[8] = {};      // diagnostics: accumulated phase ticks of the epoch kernel
     // device -> pageable host memory through two pinned bounce buffers (d2h_copy): a plain hipMemcpy to pageable memory runs at
     // ~13 GB/s here, this at the PCIe rate
     void* h_bounce[2] = {nullptr, nullptr};
@@ -135,12 +134,13 @@ struct nfagg_handle {
     void* d_join = nullptr;         // slot_of[]: the J slot of every live sub-flow
     size_t d_join_cap = 0;
     struct { bool valid = false, dirty = false; uint32_t n_shards = 0, shard_id = 0; uint64_t flows = 0, claimed = 0; } join;   // dirty: J may hold claims
-    // epoch-parallel evict-on-full loop (ingest_variant 31, nfagg_account_par.inc): scratch table, analysis arrays, pinned mirrors
-    TableView pv{};
-    DevCounters* h_pctr = nullptr;
+    // the evict-on-full loop with its epochs found first (nfagg_account_par.inc): analysis arrays, pinned mirror, the stream the
+    // middle epochs are folded on while the table takes the first and the last
     uint32_t* h_par = nullptr;      // pinned: control words, then the cuts
-    void* d_par[9] = {};            // hashes, sorted hashes, indices, sorted indices, prev, sort scratch, control + cuts, tagged copy, scratch eviction
-    size_t d_par_cap[9] = {};
+    void* d_par[7] = {};            // sort keys, sorted keys, prev, pos, long segments, sort scratch, control + cuts
+    size_t d_par_cap[7] = {};
+    hipStream_t par_stream = nullptr;
+    hipEvent_t par_done = nullptr;
     nfagg_stats stats{};
     std::vector<EventPair> ev_pending;
     std::vector<EventPair> ev_free;
@@ -820,13 +820,10 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->tv.aux) hipFree(h->tv.aux);
     if (h->tv.live_list) hipFree(h->tv.live_list);
     if (h->tv.ctr) hipFree(h->tv.ctr);
-    if (h->pv.hot) hipFree(h->pv.hot);
-    if (h->pv.cold) hipFree(h->pv.cold);
-    if (h->pv.live_list) hipFree(h->pv.live_list);
-    if (h->pv.ctr) hipFree(h->pv.ctr);
-    if (h->h_pctr) hipHostFree(h->h_pctr);
     if (h->h_par) hipHostFree(h->h_par);
-    for (int k = 0; k < 9; k++) if (h->d_par[k]) hipFree(h->d_par[k]);
+    for (int k = 0; k < 7; k++) if (h->d_par[k]) hipFree(h->d_par[k]);
+    if (h->par_done) hipEventDestroy(h->par_done);
+    if (h->par_stream) hipStreamDestroy(h->par_stream);
     if (h->jv.hot) hipFree(h->jv.hot);
     if (h->jv.cold) hipFree(h->jv.cold);
     if (h->jv.aux) hipFree(h->jv.aux);
@@ -1335,75 +1332,20 @@ int nfagg_window_restart_device(nfagg_handle* h, uint32_t n_shards, uint32_t sha
 // ---------------------------------------------------------------- nfagg_account*: the record arm WITH its evictions on "full"
 constexpr uint64_t kAccountFastMaxEntries = 32768;   // beyond that an epoch is long enough for the optimistic fold of nfagg_ingest
 
-// May the persistent epoch kernel (nfagg_epochs.hip) take this batch?
+constexpr uint32_t kVariantAccountChain = 30;        // ingest_variant (tests): nfagg_account always takes the kernel chain
+
+// May the device-resident epoch loop (the kernel chain, nfagg_epoch_chain.hip) take this batch?
 static bool account_fast_ok(const nfagg_handle* h, size_t n, size_t out_cap) {
     // (a handle that filters its input by shard takes the host-driven loop: the chain counts the records it skips per window, and a
     // window that ends on "full" is looked at again from the split on)
     return h->cfg.mode == NFAGG_MODE_ACCOUNTER && h->cfg.n_shards <= 1 && h->cfg.max_entries <= kAccountFastMaxEntries && !h->must_evict && !h->exported &&
-           h->cfg.max_entries + epoch_window() + 16 <= h->tv.claim_limit && out_cap >= h->cfg.max_entries &&
-           h->epoch_seq - h->seq_origin + n < kSeqWindow - epoch_window() && (h->tv.epoch_bits >> 48) < 0xFFFFull;
+           h->cfg.max_entries + chain_window() + 16 <= h->tv.claim_limit && out_cap >= h->cfg.max_entries &&
+           h->epoch_seq - h->seq_origin + n < kSeqWindow - chain_window() && (h->tv.epoch_bits >> 48) < 0xFFFFull;
 }
 
-// One launch of the epoch kernel over d[0..n). *consumed / *n_ep / *n_out: records consumed, evictions performed, records written
-// to d_out (epoch e ends at epoch_end[e] records); *stop as the kernel reports it.
-static int account_fast_launch(nfagg_handle* h, const void* d, size_t n, void* d_out, size_t out_cap, uint64_t* epoch_end, size_t max_epochs,
-                               size_t* consumed, size_t* n_ep, size_t* n_out, uint32_t* stop) {
-    int rc;
-    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;                       // exact len(entries), n_live, n_finalized
-    if (h->h_ctr->n_finalized != h->h_ctr->n_live) return fail(h, NFAGG_ESTATE, "account: unfinalized slots at the start of a batch");
-    const uint32_t me = max_epochs > 0xFFFFu ? 0xFFFFu : (uint32_t)max_epochs;
-    const size_t ctlb = (epoch_ctl_bytes() + 63) & ~(size_t)63;
-    if ((rc = ensure_bytes(h, &h->d_ep[0], &h->d_ep_cap[0], ctlb)) != NFAGG_OK) return rc;
-    if ((rc = ensure_bytes(h, &h->d_ep[1], &h->d_ep_cap[1], (size_t)(me + 1) * sizeof(uint64_t))) != NFAGG_OK) return rc;
-    if ((rc = ensure_bytes(h, &h->d_ep[2], &h->d_ep_cap[2], (size_t)(h->cfg.max_entries + epoch_window() + 64) * sizeof(uint32_t))) != NFAGG_OK) return rc;
-    const size_t hb = ctlb + (size_t)(me + 1) * sizeof(uint64_t);
-    if (h->h_ep_cap < hb) {
-        if (h->h_ep) { hipHostFree(h->h_ep); h->h_ep = nullptr; h->h_ep_cap = 0; }
-        HIP_TRY(h, hipHostMalloc(&h->h_ep, hb + 4096, hipHostMallocDefault));
-        h->h_ep_cap = hb + 4096;
-    }
-    const uint64_t seq_start = h->epoch_seq - h->seq_origin, n_live0 = h->h_ctr->n_live;     // window-relative, as the slots carry it
-    epoch_ctl_fill(h->h_ep, seq_start, h->live, 0, n_live0, h->tv.epoch_bits);
-    HIP_TRY(h, hipMemcpyAsync(h->d_ep[0], h->h_ep, epoch_ctl_bytes(), hipMemcpyHostToDevice, h->stream));
-    EventPair ep{};
-    if (h->cfg.profile) prof_begin(h, ep, 0);
-    hipError_t e = launch_account_epochs(h->tv, h->sk, d, n, d_out, out_cap, (uint64_t*)h->d_ep[1], me, h->cfg.max_entries, h->d_ep[0], h->stream);
-    if (h->cfg.profile) prof_end(h, ep);
-    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "epoch kernel launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(h, hipMemcpyAsync(h->h_ep, h->d_ep[0], epoch_ctl_bytes(), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync((char*)h->h_ep + ctlb, h->d_ep[1], (size_t)me * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
-    h->counters_exact = false; h->mirror_fresh = false;
-    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;                       // synchronises: control block, epoch ends, counters
-    uint64_t v[9];
-    epoch_ctl_read(h->h_ep, v);
-    { uint64_t ph[8]; epoch_ctl_phases(h->h_ep, ph); for (int k = 0; k < 8; k++) h->ep_phase[k] += ph[k]; }
-    const uint64_t pos = v[0], seq = v[1], live = v[2], list_base = v[3], list_fin = v[4], out_pos = v[5], n_epochs = v[7];
-    const uint64_t n_abs = h->h_ctr->n_live;
-    if (n_abs < list_base || n_abs - list_base != live || list_fin < list_base)
-        return fail(h, NFAGG_EDEVICE, "epoch kernel: %llu claimed slots, len(entries) %llu", (unsigned long long)(n_abs - list_base), (unsigned long long)live);
-    for (uint64_t k = 0; k < n_epochs && k < max_epochs; k++) epoch_end[k] = ((const uint64_t*)((const char*)h->h_ep + ctlb))[k];
-    // the epoch in progress to the front of the live list; identity dwords of its slots claimed by this launch, from the
-    // batch: the epoch began at record pos - (seq - seq_at_its_start) of the batch
-    h->tv.epoch_bits = v[6];
-    e = launch_ring_to_front(h->tv, list_base, live, list_fin - list_base, (uint32_t*)h->d_ep[2], h->stream);
-    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "ring fix-up launch failed: %s", hipGetErrorString(e));
-    const uint64_t seq_at_start = n_epochs ? 0 : seq_start;
-    const uint64_t first_rec = pos - (seq - seq_at_start);
-    e = launch_finalize(h->tv, (const char*)d + first_rec * kRecordBytes, pos - first_rec, seq_at_start, h->stream);
-    if (e != hipSuccess) return fail(h, NFAGG_EDEVICE, "finalize launch failed: %s", hipGetErrorString(e));
-    if (n_epochs) h->seq_origin = 0;                            // an eviction inside the launch restarted the epoch: a fresh window
-    h->epoch_seq = h->seq_origin + seq; h->live = h->live_ub = live;
-    h->counters_exact = true;                                   // n_live = live: k_ring_counters wrote it
-    h->epoch_unclustered = true;
-    h->stats.records_ingested += pos;
-    h->stats.evictions[NFAGG_REASON_FULL] += n_epochs;
-    h->stats.evicted_flows[NFAGG_REASON_FULL] += out_pos;
-    *consumed = (size_t)pos; *n_ep = (size_t)n_epochs; *n_out = (size_t)out_pos; *stop = (uint32_t)v[8];
-    return NFAGG_OK;
-}
-
-// The same through the kernel chain (nfagg_epoch_chain.hip): windows are enqueued kChainBatch at a time, the control block is
-// read back after each batch of launches.
+// One pass of the kernel chain (nfagg_epoch_chain.hip) over d[0..n). *consumed / *n_ep / *n_out: records consumed, evictions
+// performed, records written to d_out (epoch e ends at epoch_end[e] records); *stop as the control block reports it.
+// Windows are enqueued kChainBatch at a time, the control block is read back after each batch of launches.
 static int account_chain_launch(nfagg_handle* h, const void* d, size_t n, void* d_out, size_t out_cap, uint64_t* epoch_end, size_t max_epochs,
                                 size_t* consumed, size_t* n_ep, size_t* n_out, uint32_t* stop) {
     constexpr int kChainBatch = 24;
@@ -1497,7 +1439,7 @@ static int account_device_core(nfagg_handle* h, const void* d_records, size_t n,
     bool par_declined = false;
     while (rc == NFAGG_OK && consumed < n) {
         if (!par_declined && account_par_ok(h, n - consumed, out_cap - out_pos) && n_ep < max_epochs) {
-            // ingest_variant 31: the epochs of the call found first, then folded together (nfagg_account_par.inc)
+            // the epochs of the call found first, then folded all at once (nfagg_account_par.inc)
             size_t c = 0, e = 0, o = 0; uint32_t stop = 0;
             rc = account_par_launch(h, base + consumed * kRecordBytes, n - consumed, obase + out_pos * kRecordBytes, out_cap - out_pos,
                                     epoch_end + n_ep, max_epochs - n_ep, &c, &e, &o, &stop);
@@ -1510,7 +1452,7 @@ static int account_device_core(nfagg_handle* h, const void* d_records, size_t n,
         }
         if (account_fast_ok(h, n - consumed, out_cap - out_pos) && n_ep < max_epochs) {
             size_t c = 0, e = 0, o = 0; uint32_t stop = 0;
-            rc = (h->cfg.ingest_variant == 30 ? account_fast_launch : account_chain_launch)(
+            rc = account_chain_launch(
                 h, base + consumed * kRecordBytes, n - consumed, obase + out_pos * kRecordBytes, out_cap - out_pos,
                 epoch_end + n_ep, max_epochs - n_ep, &c, &e, &o, &stop);
             if (rc != NFAGG_OK) break;
@@ -2135,11 +2077,6 @@ int nfagg_encode_pb_content(nfagg_handle* h, const void* records, size_t n, cons
 }
 
 #ifdef NFAGG_DIAG
-int nfagg_debug_epoch_phases(nfagg_handle* h, uint64_t out[8]) {
-    if (!h || !out) return NFAGG_EINVAL;
-    for (int k = 0; k < 8; k++) { out[k] = h->ep_phase[k]; h->ep_phase[k] = 0; }
-    return NFAGG_OK;
-}
 // libnfagg_diag.so only (not part of the drop-in ABI): per-phase wave-cycle sums of the phase-timing builds (variants 6/8/9).
 int nfagg_debug_phase_cycles(nfagg_handle* h, uint64_t out[8]) {
     if (!h || !out) return NFAGG_EINVAL;

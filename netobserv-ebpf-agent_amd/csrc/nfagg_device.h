@@ -88,13 +88,6 @@ struct Rec {
         d[26] &= 0x0000ffffu;
         d[35] = 0;
     }
-    // K39 (nfagg_epoch_par.hip: the scratch batch of the epoch-parallel account path carries an epoch number in key byte 39, and
-    // the scratch table keys its flows by it): everything canonicalize() does except that byte.
-    template <bool K39>
-    NF_DEV void canonicalize_as() {
-        if (K39) { d[26] &= 0x0000ffffu; d[35] = 0; }
-        else canonicalize();
-    }
     NF_DEV void key_words(uint64_t w[5]) const {
 #pragma unroll
         for (int i = 0; i < 5; i++) w[i] = q(i);

@@ -1,24 +1,33 @@
-// nfagg_epoch_par.hip — the evict-on-full loop of Accounter.Account (pkg/flow/account.go:81-96) WITHOUT its sequential chain
-// (ingest_variant 31 of nfagg_account[_device]; the rule is pinned on the CPU by tests/test_epoch_boundaries.py).
+// nfagg_epoch_par.hip — the evict-on-full loop of Accounter.Account (pkg/flow/account.go:81-96) WITHOUT its sequential chain: the
+// epochs of a call are found first, then every complete epoch is folded on its own, all of them at once, with no flow table at all.
+// What nfagg_account[_device] runs for calls of more than a few epochs (host side: nfagg_account_par.inc; the rule
+// is pinned on the CPU by tests/test_epoch_boundaries.py).
 //
-// The loop is sequential only in WHERE the epochs end. With prev(i) = the index of the previous record of record i's flow in the
+// The loop is sequential only in WHERE its epochs end. With prev(i) = the index of the previous record of record i's flow in the
 // call (-1: none), record i >= s starts a new flow in the epoch that began at record s exactly when prev(i) < s (first epoch of a
 // call: and the flow is not live in the table), so the epoch ends at the record where the count of such records reaches
-// max_entries + 1. Given the cuts every epoch is an independent, order-free fold, so the complete epochs in the
-// middle of a call are folded TOGETHER: their records are copied with the epoch's number (mod 256 within a group of at most 255
-// epochs) in key byte 39 — Go's blank field, which no key comparison of the reference sees and every kernel here clears — into a
-// scratch batch, folded by the ordinary two-pass kernels into a scratch table whose keys keep that byte (K39), evicted by the
-// ordinary eviction kernel and put into epoch order (byte 39 cleared again) by k_par_regroup. The first epoch of the call (it
-// continues what the table holds) and the last, incomplete one (it stays live) go through the ordinary ingest path.
+// max_entries + 1 — a prefix count over prev[], no table involved. Given the cuts, an epoch's eviction is the fold of every flow's
+// records between two cuts (AccumulateBase, pkg/model/flow_content.go:28-61, over the records in arrival order), and ONE sort
+// already brings them together: the call's records sorted by (key hash, index) hold each flow's records of one epoch as a
+// contiguous SEGMENT in arrival order. So:
 //
-//   k_par_hash      (key hash, index) per record
-//   rocPRIM radix sort of the pairs by hash (stable: equal hashes stay in index order)
-//   k_par_links     prev(i) from neighbours in the sorted order; full keys compared: two flows with one 64-bit hash raise a flag and
-//                   the call takes the kernel chain instead
-//   k_par_live      first occurrences whose flow is live in the table: prev = -2 (not new in the first epoch)
-//   k_par_cuts      ONE workgroup walks the epochs: a prefix count over prev[] from the epoch's first record on
-//   k_par_tag_copy  records of a group of complete epochs -> scratch batch, epoch number in byte 39
-//   k_par_regroup   evicted scratch flows -> the caller's buffer, epoch by epoch, byte 39 cleared
+//   k_par_hash      sort key per record: (top 32 bits of the key hash) << 32 | index
+//   rocPRIM radix sort of the keys on their top 32 bits (stable: equal hashes stay in index order — the array is sorted as 64-bit
+//                   numbers)
+//   k_par_links     prev(i) from the neighbours to the left in sorted order, FULL keys compared: flows that share their 32 hash
+//                   bits (a hundred pairs per million flows; any number when somebody crafts them) are told apart here and in the
+//                   fold — there is no collision fallback
+//   k_par_live      first occurrences whose flow is live in the table: prev = -2 (not new in the first epoch of the call)
+//   k_par_cuts      ONE workgroup streams prev[] once in blocks of 16 Ki records and walks the epochs over it: per step one
+//                   wave-level DPP scan, one 16-entry LDS exchange, one barrier (two when an epoch ends in the block)
+//   k_par_rank      one workgroup per complete epoch: the rank of every new flow among the epoch's new flows in arrival order =
+//                   its position in the epoch's eviction (exactly max_entries of them per epoch: checked)
+//   k_par_segfold   one lane per segment of at most kSegShort records: the records gathered in arrival order and folded
+//                   SEQUENTIALLY, literally as the reference does; the folded record goes straight to its place in the caller's buffer
+//   k_par_segfold_long   one wave per longer segment (the hot flows): an order-free partial per lane, combined across the wave
+//
+// The first epoch of the call (it continues what the table holds) and the last, incomplete one (it stays live) go through the
+// ordinary table fold; everything in between never touches a hash table.
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "nfagg_device.h"
@@ -26,7 +35,11 @@
 namespace nfagg {
 
 constexpr int kParBlock = 256;
-static inline int par_grid(uint64_t n, int per_block = kParBlock, int cap = 8192) {
+constexpr uint32_t kParNone = 0xffffffffu;
+constexpr int kLinkSearch = 64;                                       // flows sharing 32 hash bits that k_par_links looks through before it gives up
+constexpr uint32_t kSegShort = 16;                                    // records per segment the one-lane fold takes
+
+static inline int par_grid(uint64_t n, int per_block = kParBlock, int cap = 1 << 20) {
     uint64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
     if (g > (uint64_t)cap) g = cap;
@@ -40,34 +53,42 @@ NF_DEV void par_key(const void* recs, uint64_t i, uint64_t w[5]) {
     w[2] = (uint64_t)b.x | ((uint64_t)b.y << 32); w[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
     w[4] = ((uint64_t)c.x | ((uint64_t)c.y << 32)) & 0x00FFFFFFFFFFFFFFull;      // key byte 39: Go's blank field, not part of the key
 }
+NF_DEV bool par_same_key(const uint64_t a[5], const uint64_t b[5]) {
+    return ((a[0] ^ b[0]) | (a[1] ^ b[1]) | (a[2] ^ b[2]) | (a[3] ^ b[3]) | (a[4] ^ b[4])) == 0;
+}
 
-__global__ __launch_bounds__(kParBlock) void k_par_hash(const void* __restrict__ recs, uint64_t n, uint64_t* __restrict__ hash,
-                                                        uint32_t* __restrict__ idx) {
+__global__ __launch_bounds__(kParBlock) void k_par_hash(const void* __restrict__ recs, uint64_t n, uint64_t* __restrict__ keys) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint64_t w[5];
         par_key(recs, i, w);
-        hash[i] = key_hash(w);
-        idx[i] = (uint32_t)i;
+        keys[i] = (key_hash(w) & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)i;
     }
 }
 
-// sorted position p: the record idx_s[p]. Same hash as its left neighbour -> same flow (checked) -> that neighbour is its previous
-// occurrence (the sort is stable: equal hashes are in index order).
-__global__ __launch_bounds__(kParBlock) void k_par_links(const void* __restrict__ recs, const uint64_t* __restrict__ hash_s,
-                                                         const uint32_t* __restrict__ idx_s, uint64_t n, int32_t* __restrict__ prev,
-                                                         uint32_t* __restrict__ collision) {
+// Sorted position p holds record i. Its previous occurrence is the nearest position to the left with the same 32 hash bits AND the
+// same key (equal hash bits are in index order). Nearly always that is position p - 1 or nothing; flows that share their hash bits
+// interleave, and the search walks over the other flows' records (at most kLinkSearch of them: beyond that *overflow is raised and
+// the call takes the kernel chain).
+__global__ __launch_bounds__(kParBlock) void k_par_links(const void* __restrict__ recs, const uint64_t* __restrict__ ks, uint64_t n,
+                                                         int32_t* __restrict__ prev, uint32_t* __restrict__ overflow) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
-        const uint32_t i = idx_s[p];
+        const uint64_t key = ks[p];
+        const uint32_t i = (uint32_t)key, hb = (uint32_t)(key >> 32);
         int32_t pv = -1;
-        if (p > 0 && hash_s[p] == hash_s[p - 1]) {
-            const uint32_t j = idx_s[p - 1];
+        if (p > 0 && (uint32_t)(ks[p - 1] >> 32) == hb) {
             uint64_t a[5], b[5];
-            par_key(recs, i, a); par_key(recs, j, b);
-            const bool same = ((a[0] ^ b[0]) | (a[1] ^ b[1]) | (a[2] ^ b[2]) | (a[3] ^ b[3]) | (a[4] ^ b[4])) == 0;
-            if (same) pv = (int32_t)j;
-            else atomicExch(collision, 1u);                          // two flows, one 64-bit hash: the links of this call are not to be trusted
+            par_key(recs, i, a);
+            uint64_t q = p;
+            int looked = 0;
+            while (q > 0) {
+                const uint64_t k2 = ks[--q];
+                if ((uint32_t)(k2 >> 32) != hb) break;
+                if (++looked > kLinkSearch) { atomicExch(overflow, 1u); break; }
+                par_key(recs, (uint32_t)k2, b);
+                if (par_same_key(a, b)) { pv = (int32_t)(uint32_t)k2; break; }
+            }
         }
         prev[i] = pv;
     }
@@ -103,205 +124,369 @@ __global__ __launch_bounds__(kParBlock) void k_par_live(TableView t, const void*
     }
 }
 
-// ONE workgroup. Epoch by epoch: from its first record s on, count the records that start a new flow in it — prev < s; in the
-// first epoch of the call: prev == -1 (a flow the table holds, prev == -2, is no new entry) — until the count passes `budget`
-// (max_entries less what is live, for the first epoch): that record finds the map full (account.go:85): the epoch is evicted and
-// the record opens the next one. cuts[k] = that record; at most max_cuts of them (*n_cuts says how many were found; the walk stops
-// there, and the caller treats the rest of the call as the last, incomplete epoch of this launch).
-// (Tried and dropped, per 8 M-record call with 557 epochs, this version 3.2 ms: a streaming walk by the same workgroup — the call
-// walked once, the next step's values in flight, every epoch end inside a step found without new loads — 4.2 ms: a step costs
-// ~4 us whatever it loads, and the streaming walk makes steps + cuts of them; ONE wave walking 4096 records per step with
-// wave-uniform counts, no LDS and no barrier — 49 ms: 64 rows per lane in registers, nothing to hide a latency behind.)
+// ---- the cut walk ---------------------------------------------------------------------------------------------------------------
+// Inclusive prefix sum over the 64 lanes of a wave with DPP: inside each row of 16 (row_shr 1, 2, 4, 8, zeroes shifted in), then
+// row 0's total into row 1 and row 2's into row 3 (row_bcast:15), then the total of rows 0-1 into rows 2-3 (row_bcast:31). Every
+// lane must be active.
+template <int CTRL, int ROW_MASK>
+NF_DEV uint32_t dpp_add_u32(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+NF_DEV uint32_t wave_scan_u32(uint32_t v) {
+    v = dpp_add_u32<0x111, 0xf>(v);
+    v = dpp_add_u32<0x112, 0xf>(v);
+    v = dpp_add_u32<0x114, 0xf>(v);
+    v = dpp_add_u32<0x118, 0xf>(v);
+    v = dpp_add_u32<0x142, 0xa>(v);
+    v = dpp_add_u32<0x143, 0xc>(v);
+    return v;
+}
+
+// ONE workgroup. prev[] is streamed ONCE in aligned blocks of kCutSpan records (a lane holds kCutPer consecutive ones in
+// registers; the next two blocks are in flight while one is worked on), and the epochs are walked over the resident block: from
+// the epoch's first record s on, the records that start a new flow in it — prev < s; in the first epoch of the call: prev == -1 (a
+// flow the table holds, prev == -2, is no new entry) — are counted; the one that sees exactly `budget` new flows before it
+// (max_entries; less what is live, for the first epoch) finds the map full (account.go:85): it ends the epoch and opens the next,
+// which is walked over the SAME registers. A step is a block that is counted through or an epoch that ends: popcount of 16 flags
+// per lane, one DPP scan per wave, the 16 wave totals through LDS, one barrier — and a second one only when the epoch ends in the
+// block (the lane that holds the cut tells the others).
+// (Round 4's walk re-read every epoch from its first record on, 16 Ki records per step with a 256-entry scan by one lane: 5.8 us
+// per epoch, 3.2 ms per 8 M-record call with 557 epochs — a third of the whole call.)
+// cuts[k] = the record that ends epoch k; at most max_cuts of them. ctl[0] = how many were found; ctl[3] = the new flows of the
+// epoch in progress when the records ended (what the table holds once that epoch's records are folded; meaningless when the walk
+// stopped at max_cuts).
 constexpr int kCutBlock = 1024;
-constexpr int kCutPer = 16;                                           // records per lane and step: 16 Ki records per step — about one epoch at 5000 entries
+constexpr int kCutPer = 16;
+constexpr uint64_t kCutSpan = (uint64_t)kCutBlock * kCutPer;
+
+NF_DEV void cut_load(const int32_t* __restrict__ prev, uint64_t n, uint64_t base, int32_t v[kCutPer]) {
+    if (base + kCutPer <= n) {
+        const int4* p = reinterpret_cast<const int4*>(prev + base);
+#pragma unroll
+        for (int q = 0; q < kCutPer / 4; q++) { const int4 x = p[q]; v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kCutPer; j++) v[j] = base + j < n ? prev[base + j] : 0x7fffffff;     // beyond the call: never new
+    }
+}
+
 __global__ __launch_bounds__(kCutBlock) void k_par_cuts(const int32_t* __restrict__ prev, uint64_t n, uint32_t max_entries, uint32_t live0,
-                                                        uint32_t* __restrict__ cuts, uint32_t max_cuts, uint32_t* __restrict__ n_cuts) {
+                                                        uint32_t* __restrict__ cuts, uint32_t max_cuts, uint32_t* __restrict__ ctl) {
     constexpr int kWaves = kCutBlock / 64;
-    __shared__ uint32_t cnt[kCutPer * kWaves];                        // new flows per (row j, wave): record order is row-major
-    __shared__ uint32_t found;                                        // index of the record that ends the epoch, or 0xffffffff
-    __shared__ uint32_t step_total;
+    __shared__ uint32_t wtot[2][kWaves];                              // double-buffered by step parity: one barrier per step
+    __shared__ uint32_t fnd[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint64_t s = 0;
-    uint32_t k = 0;
-    while (k < max_cuts && s < n) {
-        const bool first = k == 0;                                    // the epoch the table's live flows belong to (it may end at record 0)
-        uint32_t budget = max_entries;
-        if (first) budget = live0 >= max_entries ? 0u : max_entries - live0;
-        uint32_t before = 0;                                          // new flows of the epoch in the steps already walked
-        bool ended = false;
-        for (uint64_t t0 = s; t0 < n; t0 += (uint64_t)kCutPer * kCutBlock) {
-            // row j of the step: records t0 + j * 1024 + tid; all sixteen loads of a lane are in flight together
-            int32_t pv[kCutPer];
+    const uint64_t n_blocks = (n + kCutSpan - 1) / kCutSpan;
+    uint64_t s = 0;                                                   // first record of the epoch being walked
+    uint32_t k = 0, before = 0, par = 0;
+    bool first = true;                                                // the epoch the table's live flows belong to (it may end at record 0)
+    uint32_t budget = live0 >= max_entries ? 0u : max_entries - live0;
+    int32_t cur[kCutPer], nx1[kCutPer], nx2[kCutPer];
+    cut_load(prev, n, (uint64_t)tid * kCutPer, cur);
+    cut_load(prev, n, kCutSpan + (uint64_t)tid * kCutPer, nx1);
+    cut_load(prev, n, 2 * kCutSpan + (uint64_t)tid * kCutPer, nx2);
+    uint64_t b = 0;
+    while (b < n_blocks && k < max_cuts) {
+        const uint64_t base = b * kCutSpan + (uint64_t)tid * kCutPer;
+        uint32_t bits = 0;
 #pragma unroll
-            for (int j = 0; j < kCutPer; j++) {
-                const uint64_t i = t0 + (uint64_t)j * kCutBlock + tid;
-                pv[j] = i < n ? prev[i] : 0x7fffffff;                 // beyond the call: never new
-            }
-            uint32_t bits = 0;
-#pragma unroll
-            for (int j = 0; j < kCutPer; j++) {
-                const bool is_new = first ? (pv[j] == -1) : ((int64_t)pv[j] < (int64_t)s);
-                bits |= (is_new ? 1u : 0u) << j;
-                const unsigned long long m = __ballot(is_new);
-                if (lane == 0) cnt[j * kWaves + wv] = (uint32_t)__popcll(m);
-            }
-            if (tid == 0) found = 0xffffffffu;
-            __syncthreads();
-            if (tid == 0) {                                           // exclusive prefix over the 256 (row, wave) counts, in record order
-                uint32_t run = 0;
-                for (int q = 0; q < kCutPer * kWaves; q++) { const uint32_t c = cnt[q]; cnt[q] = run; run += c; }
-                step_total = run;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < kCutPer; j++) {
-                const bool is_new = (bits >> j) & 1u;
-                const unsigned long long m = __ballot(is_new);
-                const uint32_t mine = before + cnt[j * kWaves + wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));   // new flows of the epoch before this record
-                if (is_new && mine == budget) found = (uint32_t)(t0 + (uint64_t)j * kCutBlock + tid);   // entry number budget + 1: exactly one record
-            }
-            __syncthreads();
-            const uint32_t f = found, tot = step_total;
-            __syncthreads();                                          // (found, cnt and step_total are rewritten in the next step)
-            if (f != 0xffffffffu) {
-                if (tid == 0) cuts[k] = f;
-                k++;
-                s = f;
-                ended = true;
-                break;
-            }
-            before += tot;
+        for (int j = 0; j < kCutPer; j++) {
+            const bool is_new = base + j >= s && (first ? cur[j] == -1 : (int64_t)cur[j] < (int64_t)s);
+            bits |= (is_new ? 1u : 0u) << j;
         }
-        if (!ended) break;                                            // the call ends inside this epoch
+        const uint32_t c = (uint32_t)__popc(bits);
+        const uint32_t incl = wave_scan_u32(c);
+        if (lane == 63) wtot[par][wv] = incl;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < kWaves; q++) { const uint32_t x = wtot[par][q]; total += x; woff += q < wv ? x : 0u; }
+        if (before + total > budget) {                                // entry number budget + 1 is in this block: exactly one lane holds it
+            const uint32_t need = budget - (before + woff + incl - c);   // which of this lane's new records it is (wraps when it is another lane's)
+            if (need < c) {
+                uint32_t m = bits;
+                for (uint32_t q = 0; q < need; q++) m &= m - 1;       // drop the `need` lowest set bits
+                fnd[par] = (uint32_t)(base + (uint64_t)(__ffs((int)m) - 1));
+            }
+            __syncthreads();
+            const uint32_t f = fnd[par];
+            if (tid == 0) cuts[k] = f;
+            k++; s = f; before = 0; first = false; budget = max_entries;   // the next epoch is walked over the same block
+        } else {
+            before += total;
+            b++;
+#pragma unroll
+            for (int j = 0; j < kCutPer; j++) { cur[j] = nx1[j]; nx1[j] = nx2[j]; }
+            cut_load(prev, n, (b + 2) * kCutSpan + (uint64_t)tid * kCutPer, nx2);
+        }
+        par ^= 1u;
     }
-    if (tid == 0) *n_cuts = k;
+    if (tid == 0) { ctl[0] = k; ctl[3] = before; }
 }
 
-// Records [first, first + m) of the call belong to the epochs e0 .. e0 + n_ep - 1 (cuts[e] = first record of epoch e + 1, i.e.
-// epoch e + 1 starts at cuts[e]; epoch e0 starts at `first`): copy them to dst with the epoch's number within the group in key
-// byte 39.
-__global__ __launch_bounds__(kParBlock) void k_par_tag_copy(const void* __restrict__ recs, uint64_t first, uint64_t m,
-                                                            const uint32_t* __restrict__ cuts, uint32_t e0, uint32_t n_ep,
-                                                            void* __restrict__ dst) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += stride) {
-        const uint64_t i = first + r;
-        // the epoch of record i: the number of cuts at or below i, among cuts[e0 .. e0 + n_ep - 1) (epoch e0 + j starts at cuts[e0 + j - 1])
-        uint32_t lo = 0, hi = n_ep - 1;                               // j in [0, n_ep - 1]: the largest j with start(j) <= i
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) >> 1;
-            if ((uint64_t)cuts[e0 + mid - 1] <= i) lo = mid; else hi = mid - 1;
+// One workgroup per complete epoch t of the middle: records [cuts[t], cuts[t + 1]). pos[i] = t * max_entries + the number of new
+// flows of the epoch before record i, for the records that start one (prev < the epoch's first record); kParNone for the others.
+// The eviction of the epoch is what the records with a position fold to, in that order (Go's map order is random: any order is
+// the reference's). Every such epoch holds exactly max_entries new flows — that is how its end was found: *bad otherwise.
+__global__ __launch_bounds__(kParBlock) void k_par_rank(const int32_t* __restrict__ prev, const uint32_t* __restrict__ cuts, uint32_t n_mid,
+                                                        uint32_t max_entries, uint32_t* __restrict__ pos, uint32_t* __restrict__ bad) {
+    constexpr int kWaves = kParBlock / 64;
+    __shared__ uint32_t wcnt[2][kWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (uint32_t t = blockIdx.x; t < n_mid; t += gridDim.x) {
+        const uint32_t s = cuts[t], e = cuts[t + 1];
+        uint32_t running = 0, par = 0;
+        for (uint32_t base = s; base < e; base += kParBlock) {
+            const uint32_t i = base + tid;
+            const bool head = i < e && (int64_t)prev[i] < (int64_t)s;
+            const unsigned long long m = __ballot(head);
+            if (lane == 0) wcnt[par][wv] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t woff = 0, total = 0;
+#pragma unroll
+            for (int q = 0; q < kWaves; q++) { const uint32_t x = wcnt[par][q]; total += x; woff += q < wv ? x : 0u; }
+            if (i < e) pos[i] = head ? t * max_entries + running + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) : kParNone;
+            running += total;
+            par ^= 1u;
         }
-        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + i * kRecordBytes);
-        uint4* o = reinterpret_cast<uint4*>(reinterpret_cast<char*>(dst) + r * kRecordBytes);
-        uint4 v[9];
-#pragma unroll
-        for (int q = 0; q < 9; q++) v[q] = src[q];
-        v[2].y = (v[2].y & 0x00ffffffu) | (lo << 24);                 // dword 9, byte 39
-#pragma unroll
-        for (int q = 0; q < 9; q++) o[q] = v[q];
+        if (tid == 0 && running != max_entries) atomicExch(bad, 1u);
+        __syncthreads();                                              // wcnt[] of the last tile is read before the next epoch rewrites it
     }
 }
 
-// Evicted scratch flows (any order; byte 39 = the epoch's number in the group) -> out, epoch j at out[j * max_entries ...). A block
-// takes kRegroupPer consecutive flows per thread: it counts them by epoch in LDS (the LDS atomic hands every flow its rank inside
-// the block), reserves one range per epoch with ONE global atomic (a returning atomic on one address retires every ~14 ns: one
-// per flow was 0.6 ms per group), and writes.
-constexpr int kRegroupPer = 8;
-__global__ __launch_bounds__(kParBlock) void k_par_regroup(const void* __restrict__ ev, uint64_t n_flows, uint32_t max_entries, uint32_t n_ep,
-                                                           void* __restrict__ out, uint32_t* __restrict__ cnt, uint32_t* __restrict__ bad) {
-    __shared__ uint32_t lcnt[256], lbase[256];
-    const uint64_t chunk = (uint64_t)kParBlock * kRegroupPer;
-    for (uint64_t c0 = (uint64_t)blockIdx.x * chunk; c0 < n_flows; c0 += (uint64_t)gridDim.x * chunk) {
-        lcnt[threadIdx.x] = 0;                                        // kParBlock == 256 epochs' worth of counters
-        __syncthreads();
-        uint32_t ep[kRegroupPer], rank[kRegroupPer];
+// ---- the fold of a segment --------------------------------------------------------------------------------------------------------
+// model.AccumulateBase(p, other) (pkg/model/flow_content.go:28-61) on whole records, p = the stored first record (account.go:95).
+NF_DEV void accumulate_base(Rec& p, const Rec& o) {
+    const uint64_t ps = p.start(), os = o.start();
+    if (ps == 0 || (ps > os && os != 0)) { p.d[10] = o.d[10]; p.d[11] = o.d[11]; }                  // :36-38
+    const uint64_t pe = p.end(), oe = o.end();
+    if (pe == 0 || pe < oe) { p.d[12] = o.d[12]; p.d[13] = o.d[13]; }                               // :39-41
+    const uint64_t by = p.bytes() + o.bytes();                                                      // :42
+    p.d[14] = (uint32_t)by; p.d[15] = (uint32_t)(by >> 32);
+    p.d[16] += o.d[16];                                                                             // :43
+    p.d[17] |= o.d[17] & 0xffff0000u;                                                               // :44 flags
+    if (o.eth()) p.d[17] = (p.d[17] & 0xffff0000u) | o.eth();                                       // :45-47
+    if (p.smac() == 0) { p.d[18] = o.d[18]; p.d[19] = (p.d[19] & 0xffff0000u) | (o.d[19] & 0x0000ffffu); }   // :48-50
+    if (p.dmac() == 0) { p.d[19] = (p.d[19] & 0x0000ffffu) | (o.d[19] & 0xffff0000u); p.d[20] = o.d[20]; }   // :51-53
+    if (o.dscp()) p.d[24] = (p.d[24] & 0xff00ffffu) | (o.d[24] & 0x00ff0000u);                      // :54-56
+    if (o.sampling()) p.d[23] = o.d[23];                                                            // :57-59
+}
+
+// bytes 0..111 of a record: key and every field AccumulateBase reads (the rest of `r` stays as it is)
+NF_DEV void load_record_head(const void* base, uint64_t i, Rec& r) {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + i * kRecordBytes);
 #pragma unroll
-        for (int q = 0; q < kRegroupPer; q++) {
-            const uint64_t f = c0 + (uint64_t)q * kParBlock + threadIdx.x;
-            ep[q] = 0xffffffffu; rank[q] = 0;
-            if (f < n_flows) {
-                const uint32_t d9 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ev) + f * kRecordBytes)[9];
-                const uint32_t j = d9 >> 24;
-                if (j >= n_ep) atomicExch(bad, 1u);
-                else { ep[q] = j; rank[q] = atomicAdd(&lcnt[j], 1u); }
-            }
+    for (int k = 0; k < 7; k++) {
+        const uint4 v = p[k];
+        r.d[4 * k] = v.x; r.d[4 * k + 1] = v.y; r.d[4 * k + 2] = v.z; r.d[4 * k + 3] = v.w;
+    }
+}
+NF_DEV void store_record(void* base, uint64_t i, const Rec& r) {
+    uint4* p = reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + i * kRecordBytes);
+#pragma unroll
+    for (int k = 0; k < 9; k++) p[k] = make_uint4(r.d[4 * k], r.d[4 * k + 1], r.d[4 * k + 2], r.d[4 * k + 3]);
+}
+
+// One lane per sorted position p whose record i starts a flow in a middle epoch (pos[i] != kParNone). Its segment: the positions
+// from p up to (not including) the first whose sort key reaches (hash bits, first record of the next epoch) — the array is sorted
+// by (hash bits, index), so that is where the flow's records of this epoch end — less the records of other flows with the same
+// hash bits (full keys compared). Up to kSegShort positions: folded here, in arrival order, exactly as account.go:82-95 does;
+// longer ones are listed for k_par_segfold_long.
+// mid_base: pos[] counts from the first middle epoch, whose cut is cuts[0].
+template <bool SKETCH>
+__global__ __launch_bounds__(kParBlock) void k_par_segfold(const void* __restrict__ recs, const uint64_t* __restrict__ ks, uint64_t n,
+                                                           const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cuts,
+                                                           uint32_t max_entries, SketchView sk, void* __restrict__ out,
+                                                           uint32_t* __restrict__ long_list, uint32_t* __restrict__ n_long) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t key = ks[p];
+    const uint32_t i = (uint32_t)key;
+    const uint32_t ps = pos[i];
+    if (ps == kParNone) return;
+    const uint64_t limit = (key & 0xFFFFFFFF00000000ull) | (uint64_t)cuts[ps / max_entries + 1];     // (hash bits, end of the epoch)
+    if (p + kSegShort < n && ks[p + kSegShort] < limit) {             // more than kSegShort positions: a wave takes it
+        long_list[atomicAdd(n_long, 1u)] = (uint32_t)p;
+        return;
+    }
+    Rec acc;
+    load_record(recs, i, acc);
+    acc.canonicalize();
+    uint64_t w[5];
+    acc.key_words(w);
+    for (uint64_t q = p + 1; q < n; q++) {
+        const uint64_t k2 = ks[q];
+        if (k2 >= limit) break;
+        Rec r;
+        load_record_head(recs, (uint32_t)k2, r);
+        r.d[9] &= 0x00ffffffu;
+        uint64_t w2[5];
+        r.key_words(w2);
+        if (!par_same_key(w, w2)) continue;                           // another flow with these hash bits
+        accumulate_base(acc, r);
+    }
+    if (SKETCH) sketch_add(sk, w, acc.bytes());                       // Count-Min is linear, HyperLogLog idempotent: once per segment
+    store_record(out, ps, acc);
+}
+
+// What a run of records of one flow contributes, in a form that combines in any order: the index of the record decides what
+// "first" and "last" mean (the tagged words of the table, nfagg_device.h, in registers).
+struct SegAcc {
+    uint64_t bytes, end, start_inv, eth_tag, dscp_tag, samp_tag, smac, dmac;
+    uint32_t packets, flags, smac_at, dmac_at;
+    NF_DEV void clear() {
+        bytes = end = start_inv = eth_tag = dscp_tag = samp_tag = smac = dmac = 0;
+        packets = flags = 0; smac_at = dmac_at = kParNone;
+    }
+    NF_DEV void add(const Rec& r, uint32_t idx) {
+        bytes += r.bytes(); packets += r.packets(); flags |= r.flags();
+        if (r.end() > end) end = r.end();
+        const uint64_t si = r.start() ? ~r.start() : 0ull;
+        if (si > start_inv) start_inv = si;
+        const uint64_t s1 = (uint64_t)idx + 1;
+        if (r.eth()) { const uint64_t v = (s1 << 16) | r.eth(); if (v > eth_tag) eth_tag = v; }
+        if (r.dscp()) { const uint64_t v = (s1 << 8) | r.dscp(); if (v > dscp_tag) dscp_tag = v; }
+        if (r.sampling()) { const uint64_t v = (s1 << 32) | r.sampling(); if (v > samp_tag) samp_tag = v; }
+        if (r.smac() && idx < smac_at) { smac_at = idx; smac = r.smac(); }
+        if (r.dmac() && idx < dmac_at) { dmac_at = idx; dmac = r.dmac(); }
+    }
+    NF_DEV void combine(const SegAcc& o) {
+        bytes += o.bytes; packets += o.packets; flags |= o.flags;
+        if (o.end > end) end = o.end;
+        if (o.start_inv > start_inv) start_inv = o.start_inv;
+        if (o.eth_tag > eth_tag) eth_tag = o.eth_tag;
+        if (o.dscp_tag > dscp_tag) dscp_tag = o.dscp_tag;
+        if (o.samp_tag > samp_tag) samp_tag = o.samp_tag;
+        if (o.smac_at < smac_at) { smac_at = o.smac_at; smac = o.smac; }
+        if (o.dmac_at < dmac_at) { dmac_at = o.dmac_at; dmac = o.dmac; }
+    }
+    // the flow's first record (it is part of the run) becomes the eviction: every field AccumulateBase touches from the run
+    NF_DEV void apply(Rec& head) const {
+        const uint64_t st = start_inv ? ~start_inv : 0ull;
+        head.d[10] = (uint32_t)st; head.d[11] = (uint32_t)(st >> 32);
+        head.d[12] = (uint32_t)end; head.d[13] = (uint32_t)(end >> 32);
+        head.d[14] = (uint32_t)bytes; head.d[15] = (uint32_t)(bytes >> 32);
+        head.d[16] = packets;
+        head.d[17] = (flags << 16) | (uint32_t)(eth_tag & 0xffffu);
+        head.d[18] = (uint32_t)smac;
+        head.d[19] = (uint32_t)((smac >> 32) & 0xffffu) | ((uint32_t)(dmac & 0xffffu) << 16);
+        head.d[20] = (uint32_t)(dmac >> 16);
+        head.d[23] = (uint32_t)samp_tag;
+        head.d[24] = (head.d[24] & 0xff00ffffu) | ((uint32_t)(dscp_tag & 0xffu) << 16);
+    }
+};
+
+NF_DEV uint64_t shfl_xor_u64(uint64_t v, int m) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// One wave per listed segment. Its end: the first position whose sort key reaches (hash bits, end of the epoch) — a binary search,
+// the array is sorted. The lanes take the positions 64 at a time; what they hold is combined with xor-shuffles; lane 0 applies it
+// to the first record and stores.
+template <bool SKETCH>
+__global__ __launch_bounds__(kParBlock) void k_par_segfold_long(const void* __restrict__ recs, const uint64_t* __restrict__ ks, uint64_t n,
+                                                                const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cuts,
+                                                                uint32_t max_entries, SketchView sk, void* __restrict__ out,
+                                                                const uint32_t* __restrict__ long_list, const uint32_t* __restrict__ n_long) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * (kParBlock / 64);
+    const uint32_t count = *n_long;
+    for (uint32_t e = blockIdx.x * (kParBlock / 64) + (threadIdx.x >> 6); e < count; e += waves) {
+        const uint64_t p = long_list[e];
+        const uint64_t key = ks[p];
+        const uint32_t i = (uint32_t)key;
+        const uint32_t ps = pos[i];
+        const uint64_t limit = (key & 0xFFFFFFFF00000000ull) | (uint64_t)cuts[ps / max_entries + 1];
+        uint64_t lo = p + 1, hi = n;                                  // first position in (p, n] whose key is >= limit
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ks[mid] < limit) lo = mid + 1; else hi = mid; }
+        const uint64_t end = lo;
+        Rec head;
+        load_record(recs, i, head);
+        head.canonicalize();
+        uint64_t w[5];
+        head.key_words(w);
+        SegAcc a;
+        a.clear();
+        for (uint64_t q = p + lane; q < end; q += 64) {
+            const uint32_t i2 = (uint32_t)ks[q];
+            Rec r;
+            load_record_head(recs, i2, r);
+            r.d[9] &= 0x00ffffffu;
+            uint64_t w2[5];
+            r.key_words(w2);
+            if (par_same_key(w, w2)) a.add(r, i2);
         }
-        __syncthreads();
-        {
-            const uint32_t c = lcnt[threadIdx.x];
-            lbase[threadIdx.x] = c ? atomicAdd(&cnt[threadIdx.x], c) : 0u;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            SegAcc o;
+            o.bytes = shfl_xor_u64(a.bytes, m); o.end = shfl_xor_u64(a.end, m); o.start_inv = shfl_xor_u64(a.start_inv, m);
+            o.eth_tag = shfl_xor_u64(a.eth_tag, m); o.dscp_tag = shfl_xor_u64(a.dscp_tag, m); o.samp_tag = shfl_xor_u64(a.samp_tag, m);
+            o.smac = shfl_xor_u64(a.smac, m); o.dmac = shfl_xor_u64(a.dmac, m);
+            o.packets = (uint32_t)__shfl_xor((int)a.packets, m); o.flags = (uint32_t)__shfl_xor((int)a.flags, m);
+            o.smac_at = (uint32_t)__shfl_xor((int)a.smac_at, m); o.dmac_at = (uint32_t)__shfl_xor((int)a.dmac_at, m);
+            a.combine(o);
         }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < kRegroupPer; q++) {
-            if (ep[q] == 0xffffffffu) continue;
-            const uint64_t f = c0 + (uint64_t)q * kParBlock + threadIdx.x;
-            const uint32_t at = lbase[ep[q]] + rank[q];
-            if (at >= max_entries) { atomicExch(bad, 2u); continue; }  // an epoch of the middle holds exactly max_entries flows
-            const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(ev) + f * kRecordBytes);
-            uint4* o = reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + ((uint64_t)ep[q] * max_entries + at) * kRecordBytes);
-            uint4 v[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) v[k] = src[k];
-            v[2].y &= 0x00ffffffu;                                    // byte 39 back to what the reference sees
-#pragma unroll
-            for (int k = 0; k < 9; k++) o[k] = v[k];
+        if (lane == 0) {
+            a.apply(head);
+            if (SKETCH) sketch_add(sk, w, a.bytes);
+            store_record(out, ps, head);
         }
-        __syncthreads();                                              // lcnt / lbase are reused by the next chunk
     }
 }
 
 // ---- launch wrappers ----------------------------------------------------------------------------------------------------------
-hipError_t launch_par_hash(const void* d_records, uint64_t n, uint64_t* d_hash, uint32_t* d_idx, hipStream_t s) {
+hipError_t launch_par_hash(const void* d_records, uint64_t n, uint64_t* d_keys, hipStream_t s) {
     if (n == 0) return hipSuccess;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_par_hash, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, n, d_hash, d_idx);
+    hipLaunchKernelGGL(k_par_hash, dim3(par_grid(n, kParBlock, 8192)), dim3(kParBlock), 0, s, d_records, n, d_keys);
     return hipGetLastError();
 }
 
-// temp == nullptr: only *temp_bytes is written
-hipError_t launch_par_sort(void* temp, size_t* temp_bytes, const uint64_t* k_in, uint64_t* k_out, const uint32_t* v_in, uint32_t* v_out,
-                           uint64_t n, hipStream_t s) {
-    return rocprim::radix_sort_pairs(temp, *temp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, 64, s);
+// temp == nullptr: only *temp_bytes is written. Sorted on the hash bits only: the indices below them are in order already.
+hipError_t launch_par_sort(void* temp, size_t* temp_bytes, const uint64_t* k_in, uint64_t* k_out, uint64_t n, hipStream_t s) {
+    return rocprim::radix_sort_keys(temp, *temp_bytes, k_in, k_out, (size_t)n, 32, 64, s);
 }
 
-hipError_t launch_par_links(const void* d_records, const uint64_t* d_hash_s, const uint32_t* d_idx_s, uint64_t n, int32_t* d_prev,
-                            uint32_t* d_collision, hipStream_t s) {
+hipError_t launch_par_links(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, int32_t* d_prev, uint32_t* d_overflow, hipStream_t s) {
     if (n == 0) return hipSuccess;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_par_links, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_hash_s, d_idx_s, n, d_prev, d_collision);
+    hipLaunchKernelGGL(k_par_links, dim3(par_grid(n, kParBlock, 8192)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, d_prev, d_overflow);
     return hipGetLastError();
 }
 
 hipError_t launch_par_live(const TableView& t, const void* d_records, int32_t* d_prev, uint64_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_par_live, dim3(par_grid(n)), dim3(kParBlock), 0, s, t, d_records, d_prev, n);
+    hipLaunchKernelGGL(k_par_live, dim3(par_grid(n, kParBlock, 8192)), dim3(kParBlock), 0, s, t, d_records, d_prev, n);
     return hipGetLastError();
 }
 
 hipError_t launch_par_cuts(const int32_t* d_prev, uint64_t n, uint32_t max_entries, uint32_t live0, uint32_t* d_cuts, uint32_t max_cuts,
-                           uint32_t* d_n_cuts, hipStream_t s) {
+                           uint32_t* d_ctl, hipStream_t s) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_par_cuts, dim3(1), dim3(kCutBlock), 0, s, d_prev, n, max_entries, live0, d_cuts, max_cuts, d_n_cuts);
+    hipLaunchKernelGGL(k_par_cuts, dim3(1), dim3(kCutBlock), 0, s, d_prev, n, max_entries, live0, d_cuts, max_cuts, d_ctl);
     return hipGetLastError();
 }
 
-hipError_t launch_par_tag_copy(const void* d_records, uint64_t first, uint64_t m, const uint32_t* d_cuts, uint32_t e0, uint32_t n_ep,
-                               void* d_dst, hipStream_t s) {
-    if (m == 0) return hipSuccess;
+// The middle epochs of a walk that found n_cuts cuts: positions, then both folds. d_out: where the first middle epoch's eviction
+// begins. d_long: room for n / kSegShort + 1 positions; d_n_long / d_bad: zero on entry.
+hipError_t launch_par_middle(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, const int32_t* d_prev, const uint32_t* d_cuts,
+                             uint32_t n_cuts, uint32_t max_entries, const SketchView& sk, uint32_t* d_pos, void* d_out, uint32_t* d_long,
+                             uint32_t* d_n_long, uint32_t* d_bad, hipStream_t s) {
+    if (n_cuts < 2) return hipSuccess;
+    const uint32_t n_mid = n_cuts - 1;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_par_tag_copy, dim3(par_grid(m)), dim3(kParBlock), 0, s, d_records, first, m, d_cuts, e0, n_ep, d_dst);
+    hipLaunchKernelGGL(k_par_rank, dim3(n_mid < 65535u ? n_mid : 65535u), dim3(kParBlock), 0, s, d_prev, d_cuts, n_mid, max_entries, d_pos, d_bad);
+    if (sk.flags) {
+        hipLaunchKernelGGL(k_par_segfold<true>, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, d_long, d_n_long);
+        hipLaunchKernelGGL(k_par_segfold_long<true>, dim3(2048), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_long, (const uint32_t*)d_n_long);
+    } else {
+        hipLaunchKernelGGL(k_par_segfold<false>, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, d_long, d_n_long);
+        hipLaunchKernelGGL(k_par_segfold_long<false>, dim3(2048), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_long, (const uint32_t*)d_n_long);
+    }
     return hipGetLastError();
 }
-
-hipError_t launch_par_regroup(const void* d_evicted, uint64_t n_flows, uint32_t max_entries, uint32_t n_ep, void* d_out, uint32_t* d_cnt,
-                              uint32_t* d_bad, hipStream_t s) {
-    if (n_flows == 0) return hipSuccess;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(k_par_regroup, dim3(par_grid(n_flows, kParBlock * kRegroupPer)), dim3(kParBlock), 0, s, d_evicted, n_flows, max_entries, n_ep, d_out, d_cnt, d_bad);
-    return hipGetLastError();
-}
+uint32_t par_seg_short() { return kSegShort; }
 
 }  // namespace nfagg

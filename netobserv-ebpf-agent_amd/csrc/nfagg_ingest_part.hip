@@ -234,7 +234,7 @@ NF_DEV uint32_t sub_shift_of(const SpillView& q) { return q.part_shift >= (uint3
 // staged four at a time in LDS so that a spill costs one 16-byte store and a quarter of an atomic.
 // ABL (libnfagg_diag.so only, ingest_variant 20..27: timing experiments, results are WRONG): bit 0 = spills are counted but not
 // queued, bit 1 = no fold into the cache entry, bit 2 = no cache claim (every record counts as a miss).
-template <bool SKETCH, bool TIMING, bool DOOR, int ABL = 0, bool K39 = false>
+template <bool SKETCH, bool TIMING, bool DOOR, int ABL = 0>
 __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
                                                   uint64_t n, uint64_t seq_base) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -252,13 +252,8 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
 #define NF_TICK(k) do { if (TIMING) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
     if (TIMING) tp = __builtin_readcyclecounter();
     const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
-    // Tiles go round the workgroups (every workgroup's cache sees the whole stream's hot flows) — except K39: the scratch batch of
-    // the epoch-parallel account path is a sequence of epochs of a few tiles each, and a flow of epoch e exists in those tiles only:
-    // a workgroup takes CONSECUTIVE tiles there, so that the records of a flow meet in one cache.
-    const uint64_t tiles_each = (n_tiles + gridDim.x - 1) / gridDim.x;
-    const uint64_t tile_first = K39 ? (uint64_t)blockIdx.x * tiles_each : (uint64_t)blockIdx.x;
-    const uint64_t tile_end = K39 ? (tile_first + tiles_each < n_tiles ? tile_first + tiles_each : n_tiles) : n_tiles;
-    const uint64_t tile_step = K39 ? 1ull : (uint64_t)gridDim.x;
+    // Tiles go round the workgroups: every workgroup's cache sees the whole stream's hot flows.
+    const uint64_t tile_first = (uint64_t)blockIdx.x, tile_end = n_tiles, tile_step = (uint64_t)gridDim.x;
     unsigned long long skipped = 0, spilled = 0;
     const bool tag_on = n <= (uint64_t)kIdxMask;                       // the index leaves room for the sub-partition bits
     const uint32_t sub_shift = sub_shift_of(q);
@@ -292,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
         uint64_t w[5];
         uint64_t h = 0;
         if (valid) {
-            r.template canonicalize_as<K39>();
+            r.canonicalize();
             r.key_words(w);
             h = key_hash(w);
             if (t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id) { valid = false; skipped++; }
@@ -410,7 +405,7 @@ struct Pass2Lds {                 // after the Cache
 
 // Fold the `count` queue entries at `queue` (0xffffffff = padding). RETRY: misses go back to retry_to[] (tagged with their
 // sub-partition) instead of being merged on their own; COHERENT: the entries were written by this workgroup (read past L1).
-template <bool SKETCH, bool TIMING, bool RETRY, bool COHERENT, bool K39 = false>
+template <bool SKETCH, bool TIMING, bool RETRY, bool COHERENT>
 NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass2Lds& P, const uint32_t* queue, uint32_t count,
                         uint32_t* retry_to, const void* recs, uint64_t seq_base, uint32_t idx_mask, unsigned long long& direct,
                         unsigned long long* ph, unsigned long long& tp) {
@@ -440,7 +435,7 @@ NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass
         }
         uint64_t w[5];
         uint64_t h = 0;
-        if (valid) { r.template canonicalize_as<K39>(); r.key_words(w); h = key_hash(w); }
+        if (valid) { r.canonicalize(); r.key_words(w); h = key_hash(w); }
         const uint32_t seq32 = seq_base32 + i;
         if (TIMING) { asm volatile("" :: "v"(h)); NF_TICK2(0); }
         int ent = valid ? cache_claim<false>(L, nullptr, h, w, COHERENT ? &P.fill : nullptr) : -1;   // (COHERENT = the retry rounds)
@@ -460,7 +455,7 @@ NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass
                 direct++;
                 Rec full;
                 load_record(recs, i, full);
-                full.template canonicalize_as<K39>();
+                full.canonicalize();
                 Partial p;
                 partial_from_record(full, seq_base + i, p);
                 upsert_partial(t, w, h, p);
@@ -523,7 +518,7 @@ NF_DEV void pass2_flush(const TableView& t, const SketchView& sk, Cache& L, Pass
     __syncthreads();
 }
 
-template <bool SKETCH, bool TIMING, bool K39 = false>
+template <bool SKETCH, bool TIMING>
 __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
                                                   uint64_t n, uint64_t seq_base) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -548,8 +543,8 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
     const uint32_t idx_mask = tagged ? kIdxMask : 0xffffffffu;
     const uint32_t sorted_at = (count + 3u) & ~3u;
     const bool retry_ok = tagged && (uint64_t)sorted_at + count <= q.qcap;
-    if (retry_ok) pass2_round<SKETCH, TIMING, true, false, K39>(t, sk, L, P, my_queue, count, my_queue, recs, seq_base, idx_mask, direct, ph, tp);
-    else pass2_round<SKETCH, TIMING, false, false, K39>(t, sk, L, P, my_queue, count, nullptr, recs, seq_base, idx_mask, direct, ph, tp);
+    if (retry_ok) pass2_round<SKETCH, TIMING, true, false>(t, sk, L, P, my_queue, count, my_queue, recs, seq_base, idx_mask, direct, ph, tp);
+    else pass2_round<SKETCH, TIMING, false, false>(t, sk, L, P, my_queue, count, nullptr, recs, seq_base, idx_mask, direct, ph, tp);
 #define NF_TICK3(k) do { if (TIMING) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
     pass2_flush<SKETCH>(t, sk, L, P, recs, seq_base32);
     NF_TICK3(4);                                                      // phase 4 = the flushes, phase 6 = sort + cache set-up
@@ -607,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
             }
             const uint32_t c = P.sub_off[e] - P.sub_off[s];
             if (c) {
-                pass2_round<SKETCH, TIMING, false, true, K39>(t, sk, L, P, sorted + P.sub_off[s], c, nullptr, recs, seq_base, idx_mask, direct, ph, tp);
+                pass2_round<SKETCH, TIMING, false, true>(t, sk, L, P, sorted + P.sub_off[s], c, nullptr, recs, seq_base, idx_mask, direct, ph, tp);
                 open = true;
             }
             runs += e - s;
@@ -628,7 +623,7 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
 }
 
 // pass 3: the (normally empty) overflow list, one record per lane, merged directly.
-template <bool SKETCH, bool K39 = false>
+template <bool SKETCH>
 __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
                                                         uint64_t n, uint64_t seq_base) {
     const uint32_t idx_mask = n <= (uint64_t)kIdxMask ? kIdxMask : 0xffffffffu;
@@ -640,7 +635,7 @@ __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView 
         if (qi == 0xffffffffu) continue;
         const uint32_t i = qi & idx_mask;
         Rec r; uint64_t w[5];
-        load_record(recs, i, r); r.template canonicalize_as<K39>(); r.key_words(w);
+        load_record(recs, i, r); r.canonicalize(); r.key_words(w);
         Partial p;
         partial_from_record(r, seq_base + i, p);
         upsert_partial(t, w, key_hash(w), p);
@@ -650,7 +645,7 @@ __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView 
     if (direct) aadd(&t.ctr->n_direct, direct);
 }
 
-template <bool SKETCH, bool T1 = false, bool T2 = false, bool DOOR = true, int ABL = 0, bool K39 = false>
+template <bool SKETCH, bool T1 = false, bool T2 = false, bool DOOR = true, int ABL = 0>
 static hipError_t run(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                       uint64_t seq_base, hipStream_t s) {
     const size_t lds1 = sizeof(Cache) + sizeof(Stage) + (DOOR ? sizeof(Door) : 0), lds2 = sizeof(Cache) + sizeof(Pass2Lds);
@@ -660,10 +655,10 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     (void)hipGetDevice(&dev_);
     std::atomic<bool>& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<SKETCH, T1, DOOR, ABL, K39>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<SKETCH, T1, DOOR, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<SKETCH, T2, K39>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<SKETCH, T2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) return e;
         attr_set.store(true, std::memory_order_release);
@@ -676,34 +671,17 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     if (grid > 256) grid = 256;
     if (grid > tiles) grid = tiles;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_pass1<SKETCH, T1, DOOR, ABL, K39>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
+    hipLaunchKernelGGL((k_pass1<SKETCH, T1, DOOR, ABL>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_pass2<SKETCH, T2, K39>), dim3(q.n_parts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
+    hipLaunchKernelGGL((k_pass2<SKETCH, T2>), dim3(q.n_parts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_merge_overflow<SKETCH, K39>), dim3(K39 ? 256 : 32), dim3(256), 0, s, t, sk, q, d_records, n, seq_base);   // normally empty (K39: a percent of an all-miss batch)
+    hipLaunchKernelGGL((k_merge_overflow<SKETCH>), dim3(32), dim3(256), 0, s, t, sk, q, d_records, n, seq_base);   // normally empty
     return hipGetLastError();              // the overflow tail is reset by k_finalize, the last launch of every ingest call
 }
 
 }  // namespace part
-
-// The scratch fold of the epoch-parallel account path (nfagg_epoch_par.hip): the same two passes over a batch whose records carry
-// an epoch number in key byte 39, into a table that keys its flows by it. No sketches (the caller folds them over the caller's
-// own records), always 2048 partitions (the batch is a group of epochs: millions of records).
-hipError_t launch_ingest_part_k39(const TableView& t, const SpillView& q_in, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s) {
-    if (!q_in.queue || !q_in.qtail || !q_in.ovf || !q_in.ovf_tail || q_in.qcap < 4 || (q_in.qcap & 3u)) return hipErrorInvalidValue;
-    SpillView q = q_in;
-    int bits = 0;
-    while ((1ull << bits) <= t.mask) bits++;
-    q.n_parts = kSpillParts;
-    q.part_shift = (uint32_t)(bits - 11);
-    q.error = &t.ctr->error;
-    TableView tq = t;
-    tq.spill = q;
-    SketchView none{};
-    return part::run<false, false, false, true, 0, true>(tq, none, q, d_records, n, seq_base, s);
-}
 
 hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const SpillView& q_in, const void* d_records, uint64_t n,
                               uint64_t seq_base, int variant, hipStream_t s) {

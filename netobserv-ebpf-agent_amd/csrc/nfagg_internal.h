@@ -157,21 +157,19 @@ bool ingest_variant_supported(int variant);
 bool ingest_needs_spill(int mode, int variant, uint64_t n);
 hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                               uint64_t seq_base, int variant, hipStream_t s);
-// nfagg_epoch_par.hip / nfagg_account_par.inc (ingest_variant 31): the two-pass fold of a batch whose records carry an epoch number
-// in key byte 39 into a table keyed by it; the analysis and copy kernels of the epoch-parallel evict-on-full loop
-hipError_t launch_ingest_part_k39(const TableView& t, const SpillView& q, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
-hipError_t launch_par_hash(const void* d_records, uint64_t n, uint64_t* d_hash, uint32_t* d_idx, hipStream_t s);
-hipError_t launch_par_sort(void* temp, size_t* temp_bytes, const uint64_t* k_in, uint64_t* k_out, const uint32_t* v_in, uint32_t* v_out,
-                           uint64_t n, hipStream_t s);
-hipError_t launch_par_links(const void* d_records, const uint64_t* d_hash_s, const uint32_t* d_idx_s, uint64_t n, int32_t* d_prev,
-                            uint32_t* d_collision, hipStream_t s);
+// nfagg_epoch_par.hip / nfagg_account_par.inc: the evict-on-full loop of nfagg_account with its epochs found first — sort keys
+// ((hash bits) << 32 | index), their sort, previous-occurrence links, live flags, the cut walk; then the complete epochs of the
+// middle: positions and segment folds (no table)
+hipError_t launch_par_hash(const void* d_records, uint64_t n, uint64_t* d_keys, hipStream_t s);
+hipError_t launch_par_sort(void* temp, size_t* temp_bytes, const uint64_t* k_in, uint64_t* k_out, uint64_t n, hipStream_t s);
+hipError_t launch_par_links(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, int32_t* d_prev, uint32_t* d_overflow, hipStream_t s);
 hipError_t launch_par_live(const TableView& t, const void* d_records, int32_t* d_prev, uint64_t n, hipStream_t s);
 hipError_t launch_par_cuts(const int32_t* d_prev, uint64_t n, uint32_t max_entries, uint32_t live0, uint32_t* d_cuts, uint32_t max_cuts,
-                           uint32_t* d_n_cuts, hipStream_t s);
-hipError_t launch_par_tag_copy(const void* d_records, uint64_t first, uint64_t m, const uint32_t* d_cuts, uint32_t e0, uint32_t n_ep,
-                               void* d_dst, hipStream_t s);
-hipError_t launch_par_regroup(const void* d_evicted, uint64_t n_flows, uint32_t max_entries, uint32_t n_ep, void* d_out, uint32_t* d_cnt,
-                              uint32_t* d_bad, hipStream_t s);
+                           uint32_t* d_ctl, hipStream_t s);
+hipError_t launch_par_middle(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, const int32_t* d_prev, const uint32_t* d_cuts,
+                             uint32_t n_cuts, uint32_t max_entries, const SketchView& sk, uint32_t* d_pos, void* d_out, uint32_t* d_long,
+                             uint32_t* d_n_long, uint32_t* d_bad, hipStream_t s);
+uint32_t par_seg_short();
 // Kernel-dedup mode: nfagg_dedup.hip (direct: a claim pass, then a fold pass) / nfagg_dedup_cached.hip (one streaming pass + partitions).
 hipError_t launch_ingest_dedup(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
 hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, int variant, hipStream_t s);
@@ -229,18 +227,8 @@ hipError_t launch_export_scatter(const TableView& t, uint64_t n_live, uint64_t s
                                  unsigned long long* d_cursor, void* d_out, hipStream_t s);
 hipError_t launch_merge_raw(const TableView& t, const void* d_partials, uint64_t n, hipStream_t s);
 hipError_t launch_count_owned(const TableView& t, uint64_t n_live, uint64_t seq_limit, unsigned long long* d_count, hipStream_t s);
-// Accounter.Account with its evictions on "full" as one persistent cooperative kernel (nfagg_epochs.hip), for small max_entries.
-// The control block lives in device memory (epoch_ctl_bytes()); the API fills / reads a host copy through the two helpers:
-// read -> {pos, seq, live, list_base, list_fin, out_pos, epoch_bits, n_epochs, stop (1 batch consumed, 2 no room for another
-// eviction, 3 epoch tags wrap next)}.
-size_t epoch_ctl_bytes();
-uint32_t epoch_window();
-void epoch_ctl_fill(void* h_ctl, uint64_t seq, uint64_t live, uint64_t list_base, uint64_t list_fin, uint64_t epoch_bits);
-void epoch_ctl_read(const void* h_ctl, uint64_t out[9]);
-void epoch_ctl_phases(const void* h_ctl, uint64_t out[8]);   // diagnostics: 100 MHz ticks per phase (lane 0)
-hipError_t launch_account_epochs(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, void* d_out, uint64_t out_cap,
-                                 uint64_t* d_epoch_end, uint32_t max_epochs, uint64_t max_entries, void* d_ctl, hipStream_t s);
-// The same loop as a chain of four small kernels per window (nfagg_epoch_chain.hip; the default): control block helpers and one
+// Accounter.Account with its evictions on "full" on the device, as a chain of four small kernels per window (nfagg_epoch_chain.hip;
+// what nfagg_account runs for calls of a few epochs and whenever the epochs-found-first path declines): control block helpers and one
 // window's launches. chain_ctl_read -> {pos, seq, live, out_pos, epoch_bits, n_epochs, stop, epoch_first, epoch_began_here}.
 size_t chain_ctl_bytes();
 uint32_t chain_window();
@@ -248,8 +236,6 @@ void chain_ctl_fill(void* h_ctl, const void* d_records, void* d_out, uint64_t n,
                     uint64_t epoch_bits, uint64_t max_entries, uint32_t max_epochs);
 void chain_ctl_read(const void* h_ctl, uint64_t out[9]);
 hipError_t launch_epoch_chain_window(const TableView& t, const SketchView& sk, void* d_ctl, uint32_t* d_slot_idx, uint64_t* d_epoch_end, hipStream_t s);
-// the epoch in progress, ring positions [base, base + cnt) of the live list, to the front; device counters n_live / n_finalized
-hipError_t launch_ring_to_front(const TableView& t, uint64_t base, uint64_t cnt, uint64_t n_finalized, uint32_t* d_tmp, hipStream_t s);
 // The sequence window (nfagg_rebase.hip): the tags of the live slots rebased in place; the new window starts at rebase_keep().
 hipError_t launch_rebase(const TableView& t, hipStream_t s);
 uint32_t rebase_keep();

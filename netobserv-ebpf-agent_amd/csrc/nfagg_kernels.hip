@@ -300,7 +300,7 @@ hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const 
 constexpr uint64_t kDirectMaxBatch = 6144;
 constexpr uint64_t kPartMinBatch = 3u << 17;   // 384 Ki (round 3: 0.114 against 0.128 ms at 256 Ki, 0.18 against 0.23 at 512 Ki)
 constexpr uint64_t kDedupCachedMinBatch = 1u << 16;
-static bool takes_two_pass(int variant, uint64_t n) { return (variant >= 8 && variant <= 11) || (variant >= 20 && variant <= 27) || ((variant == 0 || variant == 30 || variant == 31) && n >= kPartMinBatch); }
+static bool takes_two_pass(int variant, uint64_t n) { return (variant >= 8 && variant <= 11) || (variant >= 20 && variant <= 27) || ((variant == 0 || variant == 30) && n >= kPartMinBatch); }
 // Shipping variants: 0 (by batch size), 1 direct, 3/4/5/7 geometries of the single-pass cached kernel, 10/11 two-pass
 // (with / without the admission filter). 6/8/9 are the phase-timing builds and exist only in libnfagg_diag.so (-DNFAGG_DIAG).
 bool ingest_variant_supported(int variant) {
@@ -309,16 +309,15 @@ bool ingest_variant_supported(int variant) {
 #endif
     return variant == 0 || variant == 1 || variant == 3 || variant == 4 || variant == 5 || variant == 7 || variant == 10 || variant == 11 || variant == 12 ||
            variant == 16 ||   // 16 (kernel-dedup mode, tests): the cached passes always, the partition pass always sorts its items first
-           variant == 30 ||   // 30: nfagg_account's persistent epoch kernel instead of the kernel chain (everything else as 0)
-           variant == 31;     // 31 (EXPERIMENTAL, nfagg_account_par.inc): nfagg_account finds the epochs of a call first and folds them together
+           variant == 30;     // 30 (tests): everything as 0, but nfagg_account always takes its kernel chain — the fallback of the epochs-found-first path
 }
 static bool takes_direct(int variant, uint64_t n, uint32_t sketch_flags) {
-    return variant == 1 || ((variant == 0 || variant == 30 || variant == 31) && n < kDirectMaxBatch && sketch_flags == 0);   // with sketches on, the cached kernel fuses them: one launch
+    return variant == 1 || ((variant == 0 || variant == 30) && n < kDirectMaxBatch && sketch_flags == 0);   // with sketches on, the cached kernel fuses them: one launch
 }
 static bool dedup_takes_cached(int variant, uint64_t n) { return !(variant == 1 || (variant != 10 && (variant < 12 || variant > 16) && n < kDedupCachedMinBatch)); }
 bool ingest_needs_spill(int mode, int variant, uint64_t n) { return mode == 0 ? takes_two_pass(variant, n) : dedup_takes_cached(variant, n); }
 bool ingest_fuses_sketches(int mode, int variant, uint64_t n, uint32_t sketch_flags) {
-    return mode == 0 && !takes_direct(variant, n, sketch_flags) && variant != 6 && variant != 8 && variant != 9 && (variant < 20 || variant == 30 || variant == 31);
+    return mode == 0 && !takes_direct(variant, n, sketch_flags) && variant != 6 && variant != 8 && variant != 9 && (variant < 20 || variant == 30);
 }
 
 hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base,

@@ -1,6 +1,7 @@
 """nfagg_account / nfagg_account_device (include/nfagg.h): the record arm of Accounter.Account WITH its evictions on "full"
-(pkg/flow/account.go:81-96) in one call — for small CACHE_MAX_FLOWS one persistent cooperative kernel runs the whole loop on
-the device (csrc/nfagg_epochs.hip). Every eviction must be bit-identical, in order, to the oracle's Accounter driven the way
+(pkg/flow/account.go:81-96) in one call — for small CACHE_MAX_FLOWS the whole loop runs on the device: calls of more than a few
+epochs have their epochs found first (csrc/nfagg_epoch_par.hip, tests/test_account_par_gpu.py), the others — most of the calls
+here — take the kernel chain (csrc/nfagg_epoch_chain.hip). Every eviction must be bit-identical, in order, to the oracle's Accounter driven the way
 the reference's TestEvict_MaxEntries drives it (pkg/flow/account_test.go:47-128: the (maxEntries+1)-th distinct key flushes
 exactly maxEntries flows)."""
 import numpy as np
@@ -38,11 +39,11 @@ def _check(nf, O, tab, recs, max_entries, batches, mode=0):
     return len(want)
 
 
-@pytest.mark.parametrize("variant", [0, 30])      # 0: the kernel chain (default); 30: the one persistent cooperative kernel
+@pytest.mark.parametrize("variant", [0, 30])      # 0: the default (by call size: epochs found first / the kernel chain); 30: the kernel chain always
 @pytest.mark.parametrize("max_entries,keys,n", [(5000, 100_000, 400_000), (100, 3_000, 60_000), (2, 50, 3_000), (20_000, 400_000, 500_000),
                                                  (5000, 4_000, 100_000)])
 def test_account_equals_the_reference_loop(nf, O, max_entries, keys, n, variant):
-    """Whole stream in one call (windows of 16 384 records on the device; epochs from 3 records to longer than a window;
+    """Whole stream in one call (the chain's windows are 16 384 records; epochs from 3 records to longer than a window;
     a map that never fills)."""
     recs = _stream(O, n, keys, seed=7 + max_entries)
     with nf.FlowTable(max_entries=max_entries, ingest_variant=variant) as tab:

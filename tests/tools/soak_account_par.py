@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Test infrastructure: ingest_variant 31 (the epoch-parallel evict-on-full loop) with fresh seeds for a time budget — table sizes
-from 1 to 20 000 entries, ragged calls, hot flows, every eviction against the oracle. Usage: python tests/tools/soak_account_par.py [seconds] [first seed]"""
+"""Test infrastructure: nfagg_account on its default path (calls of more than a few epochs: epochs found first, csrc/nfagg_epoch_par.hip;
+the others: the kernel chain) with fresh seeds for a time budget — table sizes from 1 to 20 000 entries, ragged calls, hot flows, the
+sketches fed along, every eviction against the oracle. Usage: python tests/tools/soak_account_par.py [seconds] [first seed]"""
 import os, sys, time, traceback
 import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -26,8 +27,14 @@ while time.time() < t_end:
     batches = [int(rng.choice([1, 777, 70_000, 150_000, 400_000, 1 << 30])) for _ in range(600)]
     desc = dict(seed=seed, max_entries=max_entries, keys=keys, n=n)
     try:
-        with nf.FlowTable(max_entries=max_entries, ingest_variant=31, staging_records=int(rng.choice([0, 1 << 18, 1 << 21]))) as tab:
+        sk = bool(rng.integers(0, 2))
+        with nf.FlowTable(max_entries=max_entries, staging_records=int(rng.choice([0, 1 << 18, 1 << 21])),
+                          sketches=(nf.SKETCH_CM | nf.SKETCH_HLL) if sk else 0, cm_log2_width=12, hll_p=8) as tab:
             _check(nf, O, tab, recs, max_entries, batches)
+            if sk:
+                cs, cd, hs, hd = O.sketches(recs, 4, 12, 8)
+                assert np.array_equal(tab.sketch_snapshot(nf.CM_SRC), cs) and np.array_equal(tab.sketch_snapshot(nf.CM_DST), cd)
+                assert np.array_equal(tab.sketch_snapshot(nf.HLL_SRC), hs) and np.array_equal(tab.sketch_snapshot(nf.HLL_DST), hd)
     except Exception:
         print("FAILED:", desc, flush=True)
         traceback.print_exc()

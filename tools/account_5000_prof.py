@@ -16,7 +16,7 @@ import netobserv_ebpf_agent_amd as nf
 from netobserv_ebpf_agent_amd import synth
 
 steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 1
-variant = int(sys.argv[sys.argv.index("--variant") + 1]) if "--variant" in sys.argv else 0     # 31: the epoch-parallel loop (experimental)
+variant = int(sys.argv[sys.argv.index("--variant") + 1]) if "--variant" in sys.argv else 0     # 30: the kernel chain always (the fallback)
 n, keys = 8_000_000, 1_000_000
 th = synth.zipf_thresholds(keys, 1.1)
 d_th = torch.from_numpy(th.view(np.int64)).cuda()
