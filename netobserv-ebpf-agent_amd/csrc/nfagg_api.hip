@@ -2077,6 +2077,22 @@ int nfagg_encode_pb_content(nfagg_handle* h, const void* records, size_t n, cons
 }
 
 #ifdef NFAGG_DIAG
+// libnfagg_diag.so only: what the last epochs-found-first launch of nfagg_account saw — its control words and its cuts (host copies)
+int nfagg_debug_last_cuts(nfagg_handle* h, uint32_t ctl[8], uint32_t* cuts, size_t cap) {
+    if (!h || !ctl || !h->h_par) return NFAGG_EINVAL;
+    for (int k = 0; k < 8; k++) ctl[k] = h->h_par[k];
+    for (size_t k = 0; k < cap && k < 65535; k++) cuts[k] = h->h_par[512 + k];
+    return NFAGG_OK;
+}
+int nfagg_debug_last_analysis(nfagg_handle* h, uint64_t* keys_sorted, int32_t* prev, uint32_t* pos, size_t n) {
+    if (!h || !h->d_par[1]) return NFAGG_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (keys_sorted) HIP_TRY(h, hipMemcpy(keys_sorted, h->d_par[1], n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (prev) HIP_TRY(h, hipMemcpy(prev, h->d_par[2], n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (pos) HIP_TRY(h, hipMemcpy(pos, h->d_par[3], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return NFAGG_OK;
+}
 // libnfagg_diag.so only (not part of the drop-in ABI): per-phase wave-cycle sums of the phase-timing builds (variants 6/8/9).
 int nfagg_debug_phase_cycles(nfagg_handle* h, uint64_t out[8]) {
     if (!h || !out) return NFAGG_EINVAL;

@@ -443,9 +443,14 @@ hipError_t launch_par_hash(const void* d_records, uint64_t n, uint64_t* d_keys, 
     return hipGetLastError();
 }
 
-// temp == nullptr: only *temp_bytes is written. Sorted on the hash bits only: the indices below them are in order already.
+// temp == nullptr: only *temp_bytes is written. Sorted on the hash bits only: the indices below them are in order already, and the
+// radix passes are stable. ALWAYS the one-sweep radix passes (MergeSortLimit 0): up to 2^20 keys rocPRIM would take its block-sort +
+// merge path, and with a partial bit range that path handed k_par_links an array in which a flow's records met only inside 1024-key
+// tiles (profiles/r05_sort_merge_path.txt: previous occurrences found only within a tile, every call below 1 Mi records wrong;
+// the array read back after the call was sorted).
+using ParSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
 hipError_t launch_par_sort(void* temp, size_t* temp_bytes, const uint64_t* k_in, uint64_t* k_out, uint64_t n, hipStream_t s) {
-    return rocprim::radix_sort_keys(temp, *temp_bytes, k_in, k_out, (size_t)n, 32, 64, s);
+    return rocprim::radix_sort_keys<ParSortConfig>(temp, *temp_bytes, k_in, k_out, (size_t)n, 32, 64, s);
 }
 
 hipError_t launch_par_links(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, int32_t* d_prev, uint32_t* d_overflow, hipStream_t s) {

@@ -121,3 +121,148 @@ size_t orc_partition_fold_mt(const void* records, size_t n, uint32_t T, uint64_t
     free(jobs); free(shard_of); free(counts); free(start); free(idx); free(shard_begin);
     return folded;
 }
+
+/* ================================================================================================================== */
+/* Local fold, then a key-sharded merge — the decomposition the GPU's own local fold uses (DESIGN.md §7 a'), on host    */
+/* cores: bench.py's cpu_baseline.multicore_local_fold. Where partition-then-fold is bound by the shard of the hottest  */
+/* flow (one folder gets 12 % of a Zipf(1.1) stream's records), here a hot flow costs every thread ONE table entry:     */
+/*   phase 1 (fold)   thread t folds its contiguous slice, in arrival order, into a table of its own (AccumulateBase,    */
+/*                    pkg/model/flow_content.go:28-61; first record stored whole, pkg/flow/account.go:95);               */
+/*   phase 2 (merge)  the entries of every table bucketed by key shard; thread k merges shard k's entries from the       */
+/*                    tables in slice order with the SAME AccumulateBase — it is its own ordered merge of partials: the  */
+/*                    earlier slice's entry is `p`, the later one's `other` (min non-zero start, max end, sums, OR, last */
+/*                    non-zero eth/dscp/sampling, first non-zero MACs, everything else from the earlier one).            */
+/* Accounter mode only, no eviction on "full" (the bench's table never fills): returns 0 when a shard would exceed       */
+/* max_entries. Not a reference path (pkg/flow.Accounter is ONE goroutine, account.go:58); bit-exact against the one-    */
+/* core oracle in tests/test_oracle_mt.py.                                                                              */
+/* ================================================================================================================== */
+typedef struct { orc_flow_id key; uint32_t used; orc_flow_metrics m; } lf_slot;      /* 40 + 4 (+4 pad) + 104 */
+typedef struct { lf_slot* slots; size_t cap, len; } lf_table;
+
+static uint64_t lf_hash(const orc_flow_id* id) {
+    uint64_t w[5]; memcpy(w, id, 40); w[4] &= 0x00FFFFFFFFFFFFFFull;
+    uint64_t h = (w[0] ^ (w[1] * 0x9E3779B97F4A7C15ull)) + (w[2] ^ (w[3] * 0xC2B2AE3D27D4EB4Full)) + w[4] * 0x165667B19E3779F9ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; h *= 0x94D049BB133111EBull; h ^= h >> 31;
+    return h;
+}
+static uint32_t lf_shard(uint64_t h, uint32_t T) { return (uint32_t)(((h >> 40) * (uint64_t)T) >> 24); }   /* top 24 bits: not the slot bits */
+
+static void lf_init(lf_table* t, size_t cap) { t->cap = cap; t->len = 0; t->slots = (lf_slot*)calloc(cap, sizeof(lf_slot)); }
+static lf_slot* lf_find(lf_table* t, const orc_flow_id* k, uint64_t h) {
+    size_t m = t->cap - 1, i = (size_t)h & m;
+    while (t->slots[i].used && memcmp(&t->slots[i].key, k, 40) != 0) i = (i + 1) & m;
+    return &t->slots[i];
+}
+static void lf_grow(lf_table* t) {
+    lf_slot* old = t->slots; const size_t oc = t->cap, len = t->len;
+    lf_init(t, oc * 2);
+    for (size_t i = 0; i < oc; i++) if (old[i].used) *lf_find(t, &old[i].key, lf_hash(&old[i].key)) = old[i];
+    t->len = len;
+    free(old);
+}
+/* p = what the table holds for the key (earlier), other = what arrives (later); first = other is a record, not a partial */
+static void lf_upsert(lf_table* t, const orc_flow_id* key, const orc_flow_metrics* other) {
+    const uint64_t h = lf_hash(key);
+    lf_slot* s = lf_find(t, key, h);
+    if (s->used) { orc_accumulate_base(&s->m, other); return; }
+    if ((t->len + 1) * 2 > t->cap) { lf_grow(t); s = lf_find(t, key, h); }
+    s->key = *key; s->used = 1; s->m = *other;
+    memset(s->m.pad2, 0, 2); memset(s->m.pad4, 0, 4);          /* binary.Read skips blank fields: padding never reaches Go */
+    t->len++;
+}
+
+typedef struct {
+    const orc_flow_record* recs;
+    size_t n;
+    uint32_t T, t;
+    lf_table local, merged;
+    uint32_t* items;            /* this thread's entries (slot indices) grouped by shard */
+    size_t* shard_start;        /* T + 1 */
+    struct lf_job_s* all;
+    uint64_t max_entries;
+    int overflow;
+} lf_job_body;
+typedef struct lf_job_s { lf_job_body b; } lf_job;
+
+static void* lf_fold(void* p) {
+    lf_job_body* j = &((lf_job*)p)->b;
+    const size_t per = (j->n + j->T - 1) / j->T;
+    size_t lo = (size_t)j->t * per, hi = lo + per;
+    if (lo > j->n) lo = j->n;
+    if (hi > j->n) hi = j->n;
+    lf_init(&j->local, 1024);
+    for (size_t i = lo; i < hi; i++) {
+        orc_flow_id key = j->recs[i].id;
+        key.pad = 0;                                            /* Go's blank field: not part of map identity */
+        lf_upsert(&j->local, &key, &j->recs[i].metrics);
+    }
+    /* bucket the entries by key shard (counting sort of slot indices) */
+    j->shard_start = (size_t*)calloc(j->T + 1, sizeof(size_t));
+    j->items = (uint32_t*)malloc((j->local.len ? j->local.len : 1) * sizeof(uint32_t));
+    for (size_t i = 0; i < j->local.cap; i++) if (j->local.slots[i].used) j->shard_start[lf_shard(lf_hash(&j->local.slots[i].key), j->T) + 1]++;
+    for (uint32_t s = 0; s < j->T; s++) j->shard_start[s + 1] += j->shard_start[s];
+    size_t* at = (size_t*)malloc(j->T * sizeof(size_t));
+    memcpy(at, j->shard_start, j->T * sizeof(size_t));
+    for (size_t i = 0; i < j->local.cap; i++) if (j->local.slots[i].used) j->items[at[lf_shard(lf_hash(&j->local.slots[i].key), j->T)]++] = (uint32_t)i;
+    free(at);
+    return 0;
+}
+
+static void* lf_merge(void* p) {
+    lf_job_body* j = &((lf_job*)p)->b;
+    lf_init(&j->merged, 1024);
+    for (uint32_t t = 0; t < j->T; t++) {                       /* slice order = arrival order between the tables */
+        const lf_job_body* src = &j->all[t].b;
+        for (size_t k = src->shard_start[j->t]; k < src->shard_start[j->t + 1]; k++) {
+            const lf_slot* e = &src->local.slots[src->items[k]];
+            lf_upsert(&j->merged, &e->key, &e->m);
+        }
+    }
+    if (j->merged.len > j->max_entries) j->overflow = 1;
+    return 0;
+}
+
+static int lf_rec_cmp(const void* x, const void* y) { return memcmp(x, y, 40); }
+
+/* Returns n (0 on overflow / bad arguments); *flows = distinct flows; seconds[0] = local folds, seconds[1] = bucket + merge,
+ * seconds[2] = the largest shard's share of the merged entries. out (may be NULL): room for out_cap records; the merged flows,
+ * sorted by key, when they fit. T <= 256; the local tables hold what their slices hold (memory: ~300 B per distinct flow and slice). */
+size_t orc_local_fold_mt(const void* records, size_t n, uint32_t T, uint64_t max_entries, size_t* flows, double seconds[3], void* out, size_t out_cap) {
+    if (T == 0 || T > 256 || n >= 0xFFFFFFFFull) return 0;
+    lf_job* jobs = (lf_job*)calloc(T, sizeof *jobs);
+    for (uint32_t t = 0; t < T; t++) {
+        jobs[t].b.recs = (const orc_flow_record*)records; jobs[t].b.n = n; jobs[t].b.T = T; jobs[t].b.t = t;
+        jobs[t].b.all = jobs; jobs[t].b.max_entries = max_entries;
+    }
+    pthread_t* th = (pthread_t*)malloc(T * sizeof *th);
+    const double t0 = now_s();
+    for (uint32_t t = 0; t < T; t++) pthread_create(&th[t], 0, lf_fold, &jobs[t]);
+    for (uint32_t t = 0; t < T; t++) pthread_join(th[t], 0);
+    const double t1 = now_s();
+    for (uint32_t t = 0; t < T; t++) pthread_create(&th[t], 0, lf_merge, &jobs[t]);
+    for (uint32_t t = 0; t < T; t++) pthread_join(th[t], 0);
+    const double t2 = now_s();
+    size_t fl = 0, entries = 0, biggest = 0;
+    int overflow = 0;
+    for (uint32_t t = 0; t < T; t++) {
+        fl += jobs[t].b.merged.len; overflow |= jobs[t].b.overflow;
+        size_t mine = 0;
+        for (uint32_t s = 0; s < T; s++) mine += jobs[s].b.shard_start[t + 1] - jobs[s].b.shard_start[t];
+        entries += mine;
+        if (mine > biggest) biggest = mine;
+    }
+    if (fl > max_entries) overflow = 1;
+    if (flows) *flows = fl;
+    if (seconds) { seconds[0] = t1 - t0; seconds[1] = t2 - t1; seconds[2] = entries ? (double)biggest / (double)entries : 0.0; }
+    if (out && fl <= out_cap && !overflow) {
+        orc_flow_record* o = (orc_flow_record*)out;
+        size_t k = 0;
+        for (uint32_t t = 0; t < T; t++)
+            for (size_t i = 0; i < jobs[t].b.merged.cap; i++)
+                if (jobs[t].b.merged.slots[i].used) { o[k].id = jobs[t].b.merged.slots[i].key; o[k].metrics = jobs[t].b.merged.slots[i].m; k++; }
+        qsort(o, k, sizeof(orc_flow_record), lf_rec_cmp);
+    }
+    for (uint32_t t = 0; t < T; t++) { free(jobs[t].b.local.slots); free(jobs[t].b.merged.slots); free(jobs[t].b.items); free(jobs[t].b.shard_start); }
+    free(jobs); free(th);
+    return overflow ? 0 : n;
+}

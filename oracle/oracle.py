@@ -43,6 +43,7 @@ def lib():
             "orc_acc_evict": (_sz, [_vp, _vp, _sz]),
             "orc_acc_ingest_shard": (_sz, [_vp, _vp, _sz, C.c_uint32, C.c_uint32]),
             "orc_partition_fold_mt": (_sz, [_vp, _sz, C.c_uint32, _u64, C.c_int, C.POINTER(_sz), C.POINTER(C.c_double)]),
+            "orc_local_fold_mt": (_sz, [_vp, _sz, C.c_uint32, _u64, C.POINTER(_sz), C.POINTER(C.c_double), _vp, _sz]),
             "orc_record_times": (None, [C.c_int64, _u64, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
             "orc_key_hash": (_u64, [_vp]), "orc_ip_hash": (_u64, [_vp, C.c_uint32]),
             "orc_shard_of": (C.c_uint32, [_vp, C.c_uint32]),
@@ -170,6 +171,19 @@ def partition_fold_mt(records, threads, max_entries, mode=0):
     secs = (C.c_double * 3)()
     folded = lib().orc_partition_fold_mt(_p(r), r.nbytes // 144, threads, max_entries, mode, C.byref(flows), secs)
     return folded, flows.value, secs[0], secs[1], secs[2]
+
+
+def local_fold_mt(records, threads, max_entries, want_flows=False):
+    """nfagg_oracle_mt.c orc_local_fold_mt: thread-local folds over contiguous slices, then a key-sharded merge. Returns (records
+    folded, distinct flows, fold seconds, merge seconds, largest shard's share of the merged entries[, the flows sorted by key])."""
+    r = np.ascontiguousarray(records)
+    n = r.nbytes // 144
+    flows = C.c_size_t(0)
+    secs = (C.c_double * 3)()
+    out = np.zeros(min(n, max_entries) if want_flows else 0, dtype=FLOW_RECORD)
+    folded = lib().orc_local_fold_mt(_p(r), n, threads, max_entries, C.byref(flows), secs, _p(out) if want_flows else None, len(out))
+    res = (folded, flows.value, secs[0], secs[1], secs[2])
+    return res + (out[:flows.value],) if want_flows else res
 
 
 def gen_stream(n, j0=0, seed=1, n_keys=1000, thresholds=None, hot_permille=0, variant=0, pop_index=None):
