@@ -1417,6 +1417,16 @@ static int account_chain_launch(nfagg_handle* h, const void* d, size_t n, void* 
     return NFAGG_OK;
 }
 
+#ifdef NFAGG_DIAG
+#include <chrono>
+static double diag_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define NF_DIAG_T(var) const double var = diag_now_ms()
+#define NF_DIAG_PRINT(...) fprintf(stderr, __VA_ARGS__)
+#else
+#define NF_DIAG_T(var)
+#define NF_DIAG_PRINT(...)
+#endif
+
 #include "nfagg_account_par.inc"
 
 // d_out: DEVICE. epoch_end: HOST. Evictions append to d_out; *n_epochs of them, the e-th ends at record epoch_end[e].
@@ -1494,11 +1504,19 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
     const size_t cap = (size_t)h->cfg.staging_records;
     size_t consumed = 0, n_ep = 0, out_pos = 0;
     // Pinned ring, double buffered as in nfagg_ingest: chunk k+1 is copied into its pinned buffer and sent up on the copy
-    // stream while the epoch kernel works on chunk k. A chunk that stops early (no room for another eviction) ends the call.
+    // stream while the device works on chunk k. A chunk that stops early (no room for another eviction) ends the call.
+    // The first chunks are short (a quarter, then half a staging buffer): nothing overlaps the first upload, so it should not be a
+    // whole buffer's (2.6 ms of a 20 ms call for 8 M records over a 57 GB/s link).
     size_t staged_lo[2] = {0, 0}, staged_n[2] = {0, 0};
     const bool pinned_src = host_is_pinned(records);            // page-locked caller buffer: sent up as it is, no host copy
+    const bool pinned_out = out_cap != 0 && host_is_pinned(out); // page-locked output: the evictions come down by DMA, asynchronously
+    size_t n_staged = 0;
     auto stage = [&](int b, size_t lo) -> int {
-        const size_t m = (n - lo) < cap ? (n - lo) : cap;
+        size_t want = cap;
+        if (n_staged < 2 && n > cap + cap / 2) want = cap >> (2 - n_staged);        // ramp: cap / 4, cap / 2, cap, cap, ...
+        if (want < (size_t)(4 * h->cfg.max_entries + 65536)) want = cap;            // (never so short that the chunk leaves the epochs-found-first path)
+        n_staged++;
+        const size_t m = (n - lo) < want ? (n - lo) : want;
         HIP_TRY(h, hipEventSynchronize(h->stage_free[b]));
         const void* up = src + lo * kRecordBytes;
         if (!pinned_src) { staged_copy(h->pinned[b], up, m * kRecordBytes, h->cfg.copy_threads); up = h->pinned[b]; }
@@ -1509,9 +1527,19 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
     };
     int b = h->stage_next;
     if (n && (rc = stage(b, 0)) != NFAGG_OK) return rc;
-    // Three things overlap per chunk k: this thread drives the epoch kernel over chunk k (synchronous); a helper thread brings
-    // the evictions of chunk k-1 down into the caller's buffer and sends chunk k+1 up. Two device buffers take the evictions
-    // in turn; a chunk of m records delivers at most m + max_entries flows.
+    // Three things overlap per chunk k: this thread drives the device over chunk k (synchronous); the evictions of chunk k-1
+    // come down into the caller's buffer; chunk k+1 goes up. Two device buffers take the evictions in turn; a chunk of m records
+    // delivers at most m + max_entries flows.
+    //   page-locked output: an asynchronous copy on a stream of its own, waited for only when its device buffer comes round
+    //     again (a blocking hipMemcpy from a helper thread was served only after the upload in flight: 3 ms of every second
+    //     chunk, 27.6 ms for the 8 M-record call where the link needs 20.2 — profiles/r05_account_host_pipeline.txt);
+    //   pageable output: a helper thread (pinned bounce buffers + host copies, d2h_copy).
+    if (pinned_out) {
+        if (!h->d2h_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++)
+            if (!h->bounce_ev[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->bounce_ev[k], hipEventDisableTiming));
+    }
+    bool down_pending[2] = {false, false};                      // pinned_out: a download from eviction buffer [k] is in flight
     struct { bool has = false; const void* d = nullptr; size_t got = 0, at = 0; } prev;
     auto bring_down = [&]() -> int {
         int rd = NFAGG_OK;
@@ -1530,24 +1558,40 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
         if (room > m + 2 * (size_t)h->cfg.max_entries) room = m + 2 * (size_t)h->cfg.max_entries;
         void** dbuf = ebuf ? &h->d_ep_out : &h->d_evict;
         size_t capb = ebuf ? h->d_ep_out_cap : (size_t)h->d_evict_cap;
+        if (down_pending[ebuf]) { HIP_TRY(h, hipEventSynchronize(h->bounce_ev[ebuf])); down_pending[ebuf] = false; }   // its last download has left
         rc = ensure_bytes(h, dbuf, &capb, room * kRecordBytes + 16);
         if (ebuf) h->d_ep_out_cap = capb; else h->d_evict_cap = capb;
         if (rc != NFAGG_OK) break;
         size_t c = 0, e = 0;
         int rc_helper = NFAGG_OK, rc_helper2 = NFAGG_OK;
-        std::thread helper, helper2;                            // one brings chunk k-1's evictions down, one sends chunk k+1 up
-        const bool down = prev.has && prev.got != 0;
+        std::thread helper, helper2;                            // one brings chunk k-1's evictions down (pageable output), one sends chunk k+1 up
+        const bool down = !pinned_out && prev.has && prev.got != 0;
         if (down) helper = std::thread([&] { (void)hipSetDevice(h->device); rc_helper = bring_down(); });
         else prev.has = false;
         if (more) helper2 = std::thread([&] { (void)hipSetDevice(h->device); rc_helper2 = stage(b ^ 1, lo + m); });
+        NF_DIAG_T(t_a);
         rc = account_device_core(h, h->d_stage[b], m, *dbuf, room, epoch_end + n_ep, max_epochs - n_ep, &e, &c);
+        NF_DIAG_T(t_b);
         if (down) helper.join();
+        NF_DIAG_T(t_c);
         if (more) helper2.join();
+        NF_DIAG_T(t_d);
+        NF_DIAG_PRINT("[account] chunk at %zu: %zu records, core %.2f ms (%zu evictions), wait down %.2f, wait up %.2f\n", lo, m, t_b - t_a, e, t_c - t_b, t_d - t_c);
         if (rc_helper == NFAGG_OK) rc_helper = rc_helper2;
         if (rc == NFAGG_OK && rc_helper != NFAGG_OK) rc = rc_helper;
         HIP_TRY(h, hipEventRecord(h->stage_free[b], h->stream));
         const size_t got = e ? (size_t)epoch_end[n_ep + e - 1] : 0;
-        prev.has = true; prev.d = *dbuf; prev.got = got; prev.at = out_pos;
+        if (pinned_out) {
+            if (got && rc >= 0) {
+                // account_device_core has synchronised the fold stream for everything it wrote into *dbuf
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                HIP_TRY(h, hipMemcpyAsync((char*)out + out_pos * kRecordBytes, *dbuf, got * kRecordBytes, hipMemcpyDeviceToHost, h->d2h_stream));
+                HIP_TRY(h, hipEventRecord(h->bounce_ev[ebuf], h->d2h_stream));
+                down_pending[ebuf] = true;
+            }
+        } else {
+            prev.has = true; prev.d = *dbuf; prev.got = got; prev.at = out_pos;
+        }
         for (size_t k = 0; k < e; k++) epoch_end[n_ep + k] += out_pos;
         n_ep += e; out_pos += got; consumed += c;
         h->stage_next = b ^ 1;
@@ -1556,7 +1600,9 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
         b ^= 1;
     }
     {
-        const int rc_down = bring_down();
+        int rc_down = bring_down();
+        if (pinned_out && (down_pending[0] || down_pending[1]) && hipStreamSynchronize(h->d2h_stream) != hipSuccess)
+            rc_down = fail(h, NFAGG_EDEVICE, "eviction download failed");
         if (rc == NFAGG_OK || rc == NFAGG_TRUNCATED) { if (rc_down != NFAGG_OK) rc = rc_down; }
     }
     if (pinned_src) (void)hipStreamSynchronize(h->copy_stream);       // a chunk staged ahead may still be on its way: the caller's buffer is its own again

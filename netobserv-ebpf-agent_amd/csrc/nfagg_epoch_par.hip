@@ -143,21 +143,26 @@ NF_DEV uint32_t wave_scan_u32(uint32_t v) {
 }
 
 // ONE workgroup. prev[] is streamed ONCE in aligned blocks of kCutSpan records (a lane holds kCutPer consecutive ones in
-// registers; the next two blocks are in flight while one is worked on), and the epochs are walked over the resident block: from
-// the epoch's first record s on, the records that start a new flow in it — prev < s; in the first epoch of the call: prev == -1 (a
-// flow the table holds, prev == -2, is no new entry) — are counted; the one that sees exactly `budget` new flows before it
-// (max_entries; less what is live, for the first epoch) finds the map full (account.go:85): it ends the epoch and opens the next,
-// which is walked over the SAME registers. A step is a block that is counted through or an epoch that ends: popcount of 16 flags
-// per lane, one DPP scan per wave, the 16 wave totals through LDS, one barrier — and a second one only when the epoch ends in the
-// block (the lane that holds the cut tells the others).
+// registers; FOUR blocks rotate through four register sets, so the loads of the next three are in flight while one is worked on —
+// a rotation by register copies would wait for the youngest load at every block), and the epochs are walked over the resident
+// block: from the epoch's first record s on, the records that start a new flow in it — prev < s; in the first epoch of the call:
+// prev == -1 (a flow the table holds, prev == -2, is no new entry) — are counted; the one that sees exactly `budget` new flows
+// before it (max_entries; less what is live, for the first epoch) finds the map full (account.go:85): it ends the epoch and opens
+// the next, which is walked over the SAME registers. A step is a block that is counted through or an epoch that ends: two
+// instructions per record (compare, add with carry), one DPP scan per wave, the 16 wave totals through LDS, one barrier — and a
+// second one only when the epoch ends in the block (the lane that holds the cut tells the others). Records before s are dead for
+// good (s only grows): waves wholly before it skip their counting, the lane that holds s overwrites its dead records with "never new".
+// One CU evaluates 16 Ki records per step: the walk is bound by that arithmetic (~0.2 us per step), not by the 4 bytes per record.
 // (Round 4's walk re-read every epoch from its first record on, 16 Ki records per step with a 256-entry scan by one lane: 5.8 us
-// per epoch, 3.2 ms per 8 M-record call with 557 epochs — a third of the whole call.)
+// per epoch, 3.2 ms per 8 M-record call with 557 epochs; this kernel's first form — six instructions per record, the blocks rotated
+// by register copies — 2.67 ms: profiles/r05_account_par_kernel_stats_first.csv.)
 // cuts[k] = the record that ends epoch k; at most max_cuts of them. ctl[0] = how many were found; ctl[3] = the new flows of the
 // epoch in progress when the records ended (what the table holds once that epoch's records are folded; meaningless when the walk
 // stopped at max_cuts).
 constexpr int kCutBlock = 1024;
 constexpr int kCutPer = 16;
 constexpr uint64_t kCutSpan = (uint64_t)kCutBlock * kCutPer;
+constexpr int32_t kCutNever = 0x7fffffff;
 
 NF_DEV void cut_load(const int32_t* __restrict__ prev, uint64_t n, uint64_t base, int32_t v[kCutPer]) {
     if (base + kCutPer <= n) {
@@ -166,62 +171,99 @@ NF_DEV void cut_load(const int32_t* __restrict__ prev, uint64_t n, uint64_t base
         for (int q = 0; q < kCutPer / 4; q++) { const int4 x = p[q]; v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
     } else {
 #pragma unroll
-        for (int j = 0; j < kCutPer; j++) v[j] = base + j < n ? prev[base + j] : 0x7fffffff;     // beyond the call: never new
+        for (int j = 0; j < kCutPer; j++) v[j] = base + j < n ? prev[base + j] : kCutNever;     // beyond the call: never new
+    }
+}
+
+struct CutState {
+    uint32_t s, k, before, par, budget, max_entries, max_cuts;
+    bool first;
+};
+
+// The epochs over one resident block (cur[]: this lane's records base .. base + kCutPer - 1). Returns when the block is counted
+// through or max_cuts are found.
+NF_DEV void cut_block(int32_t cur[kCutPer], uint32_t base, uint32_t wave_end, CutState& st, uint32_t (*wtot)[kCutBlock / 64], uint32_t* fnd,
+                      uint32_t* __restrict__ cuts) {
+    constexpr int kWaves = kCutBlock / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    while (st.k < st.max_cuts) {
+        uint32_t c = 0;
+        if (wave_end > st.s) {                                        // (wave-uniform) some record of this wave is at or after s
+            if (st.first) {
+#pragma unroll
+                for (int j = 0; j < kCutPer; j++) c += cur[j] == -1 ? 1u : 0u;
+            } else {
+                const int32_t s32 = (int32_t)st.s;
+#pragma unroll
+                for (int j = 0; j < kCutPer; j++) c += cur[j] < s32 ? 1u : 0u;
+            }
+            if (base + kCutPer <= st.s) c = 0;                        // a lane wholly before s (the lane that holds s has its dead records overwritten)
+        }
+        const uint32_t incl = wave_scan_u32(c);
+        if (lane == 63) wtot[st.par][wv] = incl;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < kWaves; q++) { const uint32_t x = wtot[st.par][q]; total += x; woff += q < wv ? x : 0u; }
+        if (st.before + total <= st.budget) {                         // the epoch goes on beyond this block
+            st.before += total;
+            st.par ^= 1u;
+            return;
+        }
+        // entry number budget + 1 is in this block: exactly one lane holds it
+        const uint32_t need = st.budget - (st.before + woff + incl - c);   // which of this lane's new records it is (wraps when it is another lane's)
+        if (need < c) {
+            uint32_t seen = 0, at = 0;
+            const int32_t s32 = (int32_t)st.s;
+#pragma unroll
+            for (int j = 0; j < kCutPer; j++) {
+                const bool is_new = st.first ? cur[j] == -1 : cur[j] < s32;
+                if (is_new) { if (seen == need) at = (uint32_t)j; seen++; }
+            }
+            fnd[st.par] = base + at;
+        }
+        __syncthreads();
+        const uint32_t f = fnd[st.par];
+        if (tid == 0) cuts[st.k] = f;
+        st.k++; st.s = f; st.before = 0; st.first = false; st.budget = st.max_entries;   // the next epoch is walked over the same block
+        st.par ^= 1u;
+        if (f >= base && f < base + kCutPer) {                        // the lane that holds the new s: its records before s never count again
+#pragma unroll
+            for (int j = 0; j < kCutPer; j++) if (base + (uint32_t)j < f) cur[j] = kCutNever;
+        }
     }
 }
 
 __global__ __launch_bounds__(kCutBlock) void k_par_cuts(const int32_t* __restrict__ prev, uint64_t n, uint32_t max_entries, uint32_t live0,
                                                         uint32_t* __restrict__ cuts, uint32_t max_cuts, uint32_t* __restrict__ ctl) {
-    constexpr int kWaves = kCutBlock / 64;
-    __shared__ uint32_t wtot[2][kWaves];                              // double-buffered by step parity: one barrier per step
+    __shared__ uint32_t wtot[2][kCutBlock / 64];                      // double-buffered by step parity: one barrier per step
     __shared__ uint32_t fnd[2];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, wv = tid >> 6;
     const uint64_t n_blocks = (n + kCutSpan - 1) / kCutSpan;
-    uint64_t s = 0;                                                   // first record of the epoch being walked
-    uint32_t k = 0, before = 0, par = 0;
-    bool first = true;                                                // the epoch the table's live flows belong to (it may end at record 0)
-    uint32_t budget = live0 >= max_entries ? 0u : max_entries - live0;
-    int32_t cur[kCutPer], nx1[kCutPer], nx2[kCutPer];
-    cut_load(prev, n, (uint64_t)tid * kCutPer, cur);
-    cut_load(prev, n, kCutSpan + (uint64_t)tid * kCutPer, nx1);
-    cut_load(prev, n, 2 * kCutSpan + (uint64_t)tid * kCutPer, nx2);
-    uint64_t b = 0;
-    while (b < n_blocks && k < max_cuts) {
-        const uint64_t base = b * kCutSpan + (uint64_t)tid * kCutPer;
-        uint32_t bits = 0;
-#pragma unroll
-        for (int j = 0; j < kCutPer; j++) {
-            const bool is_new = base + j >= s && (first ? cur[j] == -1 : (int64_t)cur[j] < (int64_t)s);
-            bits |= (is_new ? 1u : 0u) << j;
-        }
-        const uint32_t c = (uint32_t)__popc(bits);
-        const uint32_t incl = wave_scan_u32(c);
-        if (lane == 63) wtot[par][wv] = incl;
-        __syncthreads();
-        uint32_t woff = 0, total = 0;
-#pragma unroll
-        for (int q = 0; q < kWaves; q++) { const uint32_t x = wtot[par][q]; total += x; woff += q < wv ? x : 0u; }
-        if (before + total > budget) {                                // entry number budget + 1 is in this block: exactly one lane holds it
-            const uint32_t need = budget - (before + woff + incl - c);   // which of this lane's new records it is (wraps when it is another lane's)
-            if (need < c) {
-                uint32_t m = bits;
-                for (uint32_t q = 0; q < need; q++) m &= m - 1;       // drop the `need` lowest set bits
-                fnd[par] = (uint32_t)(base + (uint64_t)(__ffs((int)m) - 1));
-            }
-            __syncthreads();
-            const uint32_t f = fnd[par];
-            if (tid == 0) cuts[k] = f;
-            k++; s = f; before = 0; first = false; budget = max_entries;   // the next epoch is walked over the same block
-        } else {
-            before += total;
-            b++;
-#pragma unroll
-            for (int j = 0; j < kCutPer; j++) { cur[j] = nx1[j]; nx1[j] = nx2[j]; }
-            cut_load(prev, n, (b + 2) * kCutSpan + (uint64_t)tid * kCutPer, nx2);
-        }
-        par ^= 1u;
+    CutState st;
+    st.s = 0; st.k = 0; st.before = 0; st.par = 0; st.first = true;   // the first epoch: the one the table's live flows belong to (it may end at record 0)
+    st.budget = live0 >= max_entries ? 0u : max_entries - live0;
+    st.max_entries = max_entries; st.max_cuts = max_cuts;
+    const uint64_t lane_off = (uint64_t)tid * kCutPer;
+    const uint32_t wave_off = (uint32_t)(wv + 1) * 64u * kCutPer;    // first record after this wave's, relative to the block
+    int32_t A[kCutPer], B[kCutPer], C[kCutPer], D[kCutPer];
+    cut_load(prev, n, lane_off, A);
+    cut_load(prev, n, kCutSpan + lane_off, B);
+    cut_load(prev, n, 2 * kCutSpan + lane_off, C);
+    cut_load(prev, n, 3 * kCutSpan + lane_off, D);
+#define NF_CUT_BLOCK(BUF, BIDX)                                                                                                      \
+    if ((BIDX) < n_blocks && st.k < st.max_cuts) {                                                                                   \
+        cut_block(BUF, (uint32_t)((BIDX) * kCutSpan + lane_off), (uint32_t)((BIDX) * kCutSpan) + wave_off, st, wtot, fnd, cuts);      \
+        cut_load(prev, n, ((BIDX) + 4) * kCutSpan + lane_off, BUF);                                                                  \
     }
-    if (tid == 0) { ctl[0] = k; ctl[3] = before; }
+    for (uint64_t b0 = 0; b0 < n_blocks && st.k < st.max_cuts; b0 += 4) {
+        NF_CUT_BLOCK(A, b0)
+        NF_CUT_BLOCK(B, b0 + 1)
+        NF_CUT_BLOCK(C, b0 + 2)
+        NF_CUT_BLOCK(D, b0 + 3)
+    }
+#undef NF_CUT_BLOCK
+    if (tid == 0) { ctl[0] = st.k; ctl[3] = st.before; }
 }
 
 // One workgroup per complete epoch t of the middle: records [cuts[t], cuts[t + 1]). pos[i] = t * max_entries + the number of new
