@@ -67,6 +67,9 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1: nccl (= RCCL, the product path) or gloo "
                     "(rehearsal of the N>1 code path on a 1-GPU box together with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1 through the N > 1 code path: init_process_group(backend) with ONE rank, the sketch "
+                    "all-reduce (int64 SUM, uint8 MAX), all_to_all_single with split sizes on device tensors, partials export / merge / "
+                    "evict_owned — the multi-GPU preflight on the one GPU there is (tests/test_dist_preflight_gpu.py)")
     ap.add_argument("--group-local-fold", action="store_true", help="with --group-devices: NFAGG_GROUP_LOCAL_FOLD (no routing; every member "
                     "folds its own slice, the members' slots are merged into their owners at the eviction)")
     ap.add_argument("--group-threads", action="store_true", help="with --group-devices --group-local-fold: one host thread per member "
@@ -155,6 +158,10 @@ def rank_main(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
+    dist_on = world > 1 or args.force_dist          # --force-dist: ONE rank through everything the N > 1 path does
+    if args.force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
     if args.same_device:
         local_rank = 0
@@ -162,7 +169,7 @@ def rank_main(args):
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (rehearse the N > 1 path on one GPU with --same-device --backend gloo)"
                          % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -172,7 +179,7 @@ def rank_main(args):
     if rank == 0:
         import __graft_entry__
         __graft_entry__.ensure_built()      # fresh checkout: compile the HIP library first (git-ignored artefact)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     import netobserv_ebpf_agent_amd as nf
     from netobserv_ebpf_agent_amd import synth
@@ -180,8 +187,8 @@ def rank_main(args):
     n, keys = resolve_sizes(args, world)
     # N > 1: ONE common stream, local fold — in both modes. With --dedup (configs[4]) the ranks' tables are keyed by (flow,
     # interface) and the flows are put together at their owners when the epoch ends (nfagg_config.local_fold, DESIGN.md §7 a')
-    local_fold = world > 1 and not args.presharded
-    sketches = args.sketches or (world > 1 and not args.no_sketches)
+    local_fold = dist_on and not args.presharded
+    sketches = args.sketches or (dist_on and not args.no_sketches)
     keys_total = keys * world if local_fold else keys
     # ---- synthetic stream, generated in HBM (seed 2)
     th = synth.zipf_thresholds(keys_total, args.zipf)
@@ -190,7 +197,7 @@ def rank_main(args):
     j0, seed = 0, 2
     if local_fold:
         j0 = rank * n                           # ONE stream of world x n records: this rank holds arrival positions [rank n, (rank + 1) n)
-    elif world > 1:
+    elif dist_on:
         pop = synth.shard_population(keys, world, rank)
         d_pop = torch.from_numpy(pop.view(np.int64)).cuda()
         seed = 2 + 1000 * rank
@@ -278,7 +285,7 @@ def rank_main(args):
             assert rc == nf.OK and c == m, (rc, c)
             off += m
         t = mark("fold_ms", t)
-        if sketches and world > 1:
+        if sketches and dist_on:
             tab.sync()          # the sketch kernels run on the table's stream
             nf.distributed.merge_sketches(cm_t, hll_t)
             torch.cuda.synchronize()
@@ -303,7 +310,7 @@ def rank_main(args):
         return flows
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         tab.sync()
@@ -320,7 +327,7 @@ def rank_main(args):
     dt = time.perf_counter() - t0
     st = tab.stats()
     records_folded = [int(st.records_ingested)]
-    if world > 1:
+    if dist_on:
         mdev = "cuda" if args.backend == "nccl" else "cpu"          # bookkeeping collectives (gloo rehearsal: host tensors)
         t = torch.tensor([dt], dtype=torch.float64, device=mdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -344,7 +351,7 @@ def rank_main(args):
         recs_per_launch = n * steps / max(st.ingest_launches, 1)
         alg_bytes = ALG_BYTES_INGEST + (ALG_BYTES_SKETCH if sketches else 0)   # 392 B/record, 522 with the sketches
         achieved = alg_bytes * recs_per_launch / (ingest_ms * 1e-3) / 1e9 if ingest_ms > 0 else 0.0
-        cfg_no = 4 if args.dedup else (3 if world > 1 else (2 if sketches else 1))
+        cfg_no = 4 if args.dedup else (3 if dist_on else (2 if sketches else 1))
         if local_fold and args.dedup:
             workload = ("configs[4]: ONE %dM-record stream, %d permille of the records one flow alternating over two interfaces, the rest "
                         "Zipf(%.1f) over %dk unique flows on two interfaces each, %dM records per GPU resident on the GPU they arrived at, "
@@ -399,13 +406,13 @@ def rank_main(args):
                 "frac_traffic": None,
                 "alg_bytes_per_record": alg_bytes, "records_per_launch": int(recs_per_launch),
                 "launch_ms": round(ingest_ms, 4), "launches": int(st.ingest_launches),
-                "lds_cache_hit_rate": round(1.0 - st.records_bypassed / max(1, n * (args.steps + args.warmup + (1 if world > 1 else 0))), 4),
+                "lds_cache_hit_rate": round(1.0 - st.records_bypassed / max(1, n * (args.steps + args.warmup + (1 if dist_on else 0))), 4),
                 "kernel_Mrecords_per_s": round(recs_per_launch / (ingest_ms * 1e-3) / 1e6, 1) if ingest_ms > 0 else None,
                 "evict_launch_ms": round(st.evict_kernel_ms / max(st.evict_launches, 1), 4),
                 "sketch_launch_ms": round(st.sketch_kernel_ms / max(st.sketch_launches, 1), 4) if st.sketch_launches else None,
             },
         }
-        if world > 1:
+        if dist_on:
             out["config"]["rccl_ranks"] = world if args.backend == "nccl" else 0
             out["config"]["backend"] = args.backend
             out["config"]["member_records_folded"] = records_folded
@@ -439,18 +446,19 @@ def rank_main(args):
                 out["roofline"]["traffic"] = round(tj["traffic_bytes_per_call"] / (ingest_ms * 1e-3) / 1e9, 1)
                 out["roofline"]["frac_traffic"] = round(out["roofline"]["traffic"] / HBM_PEAK_GBS, 4)
                 out["roofline"]["traffic_bytes_per_launch"] = int(tj["traffic_bytes_per_call"])
-                out["roofline"]["traffic_source"] = os.path.relpath(tf, ROOT)
+                out["roofline"]["traffic_source"] = traffic_source(tf, tj)
+                out["roofline"]["traffic_stale"] = out["roofline"]["traffic_source"]["traffic_stale"]
                 if "roofline_evict" in out and tj.get("evict_traffic_bytes_per_call") and tj.get("evicted_flows") == out["roofline_evict"]["flows_per_launch"]:
                     out["roofline_evict"]["traffic"] = round(tj["evict_traffic_bytes_per_call"] / (ev_ms * 1e-3) / 1e9, 1)
                     out["roofline_evict"]["traffic_bytes_per_flow"] = round(tj["evict_traffic_bytes_per_call"] / tj["evicted_flows"], 1)
                 break
         # ---- CPU baseline: the oracle (C restatement of pkg/flow.Accounter), 1 core, bounded sample
-        if args.cpu_sample > 0 and world == 1:     # rank 0 at N=1 only
+        if args.cpu_sample > 0 and not dist_on:     # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, d_recs, n, max_entries)
         # ---- the chip's copy bandwidth in this very run (state the peak used, confirm it with a D2D copy):
         # up to 4 GiB device-to-device (the stream's first half over its second: nothing reads the stream after this point),
         # read + written bytes over the time of the copy
-        default_workload = (world == 1 and not args.dedup and not args.sketches and not args.hot_permille and args.variant == 0
+        default_workload = (not dist_on and not args.dedup and not args.sketches and not args.hot_permille and args.variant == 0
                             and not args.chunk and not args.max_entries)
         if default_workload and not args.no_extras:
             # the extra legs regenerate streams into d_recs: before the copy test overwrites half of it
@@ -473,7 +481,7 @@ def rank_main(args):
         quiet.emit(json.dumps(out))
     if tab is not None:
         tab.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     return 0
@@ -535,6 +543,20 @@ def cpu_baseline(args, d_recs, n, max_entries):
                         "partition_s": round(part_s, 4), "fold_s": round(fold_s, 4),
                         "largest_shard_share": round(biggest, 4),      # a key lives in ONE shard: the hottest flow's shard bounds the fold
                         "sample": "same sample, %.2f s" % (part_s + fold_s)}
+    # ... and the decomposition that is not bound by the hottest flow's shard — the GPU's own local fold on host cores
+    # (oracle/nfagg_oracle_mt.c orc_local_fold_mt): every thread folds its contiguous slice into a table of its own, in arrival
+    # order; then thread k merges key shard k's entries from the tables in slice order with the same AccumulateBase (it is its own
+    # ordered merge of partials). Bit-exact against one Accounter: tests/test_oracle_mt.py. Accounter mode only.
+    if not args.dedup:
+        for threads in sorted({T, max(2, min(256, os.cpu_count() or 2))}):
+            folded, lf_flows, fold_s, merge_s, share = O.local_fold_mt(sample, threads, max_entries)
+            assert folded == m and lf_flows == len(ev), (folded, m, lf_flows, len(ev))
+            key = "multicore_local_fold" if threads == T else "multicore_local_fold_all_cores"
+            res[key] = {"value": round(m / (fold_s + merge_s) / 1e6, 3), "unit": "Mrecords/s", "cores": threads, "kind": "port",
+                        "what": "local fold then key-sharded merge: %d threads fold their slices into tables of their own, then merge one key shard "
+                                "each, slice order = arrival order (oracle/nfagg_oracle_mt.c orc_local_fold_mt)" % threads,
+                        "fold_s": round(fold_s, 4), "merge_s": round(merge_s, 4), "largest_shard_share_of_merged_entries": round(share, 4),
+                        "sample": "same sample, %.2f s" % (fold_s + merge_s)}
     return res
 
 
@@ -548,8 +570,28 @@ def leg_traffic(leg, records_per_call):
         except Exception:
             continue
         if tj.get("leg") == leg and tj.get("records_per_call") == int(records_per_call) and tj.get("traffic_bytes_per_call"):
-            return int(tj["traffic_bytes_per_call"]), os.path.relpath(tf, ROOT)
+            return int(tj["traffic_bytes_per_call"]), traffic_source(tf, tj)
     return None, None
+
+
+_LIB_SHA = None
+
+
+def loaded_lib_sha256():
+    """sha256 of the libnfagg.so this process loaded: what a committed traffic measurement must have been taken on."""
+    global _LIB_SHA
+    if _LIB_SHA is None:
+        import hashlib
+        from netobserv_ebpf_agent_amd import _lib
+        _LIB_SHA = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    return _LIB_SHA
+
+
+def traffic_source(path, tj):
+    """Where a traffic figure comes from, and whether it is STALE: taken on another build of the library than the one loaded now
+    (tools/profile_bench.sh records the hash on the GPU box; files from before round 5 carry none and count as stale)."""
+    return {"file": os.path.relpath(path, ROOT), "git_head": tj.get("git_head"), "lib_sha256": tj.get("lib_sha256"),
+            "traffic_stale": tj.get("lib_sha256") != loaded_lib_sha256()}
 
 
 def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):

@@ -136,8 +136,13 @@ size_t orc_partition_fold_mt(const void* records, size_t n, uint32_t T, uint64_t
 /* max_entries. Not a reference path (pkg/flow.Accounter is ONE goroutine, account.go:58); bit-exact against the one-    */
 /* core oracle in tests/test_oracle_mt.py.                                                                              */
 /* ================================================================================================================== */
-typedef struct { orc_flow_id key; uint32_t used; orc_flow_metrics m; } lf_slot;      /* 40 + 4 (+4 pad) + 104 */
-typedef struct { lf_slot* slots; size_t cap, len; } lf_table;
+/* A table that never moves: 4-byte slots (index + 1 of a dense entry; sized once for the most items it can meet) over entries
+ * appended in chunks — no rehash, no realloc, nothing freed while the threads run (every munmap is a TLB shoot-down for all of them:
+ * the first version, which doubled its tables, got SLOWER with more threads). */
+typedef struct { orc_flow_id key; orc_flow_metrics m; } lf_entry;                    /* 144 bytes */
+#define LF_CHUNK_LOG2 14
+#define LF_CHUNK (1u << LF_CHUNK_LOG2)
+typedef struct { uint32_t* slots; size_t cap, len, n_chunks; lf_entry** chunks; } lf_table;
 
 static uint64_t lf_hash(const orc_flow_id* id) {
     uint64_t w[5]; memcpy(w, id, 40); w[4] &= 0x00FFFFFFFFFFFFFFull;
@@ -147,75 +152,86 @@ static uint64_t lf_hash(const orc_flow_id* id) {
 }
 static uint32_t lf_shard(uint64_t h, uint32_t T) { return (uint32_t)(((h >> 40) * (uint64_t)T) >> 24); }   /* top 24 bits: not the slot bits */
 
-static void lf_init(lf_table* t, size_t cap) { t->cap = cap; t->len = 0; t->slots = (lf_slot*)calloc(cap, sizeof(lf_slot)); }
-static lf_slot* lf_find(lf_table* t, const orc_flow_id* k, uint64_t h) {
+static int lf_init(lf_table* t, size_t max_items) {
+    size_t cap = 1024;
+    while (cap < 2 * max_items) cap <<= 1;
+    t->cap = cap; t->len = 0;
+    t->n_chunks = max_items / LF_CHUNK + 2;
+    t->slots = (uint32_t*)calloc(cap, sizeof(uint32_t));
+    t->chunks = (lf_entry**)calloc(t->n_chunks, sizeof(lf_entry*));
+    return t->slots && t->chunks;
+}
+static void lf_free(lf_table* t) {
+    if (t->chunks) for (size_t c = 0; c < t->n_chunks; c++) free(t->chunks[c]);
+    free(t->chunks); free(t->slots);
+}
+static lf_entry* lf_at(const lf_table* t, size_t i) { return &t->chunks[i >> LF_CHUNK_LOG2][i & (LF_CHUNK - 1)]; }
+/* p = what the table holds for the key (earlier), other = what arrives (later): a record's metrics or a later slice's partial */
+static int lf_upsert(lf_table* t, const orc_flow_id* key, const orc_flow_metrics* other, uint64_t h) {
     size_t m = t->cap - 1, i = (size_t)h & m;
-    while (t->slots[i].used && memcmp(&t->slots[i].key, k, 40) != 0) i = (i + 1) & m;
-    return &t->slots[i];
-}
-static void lf_grow(lf_table* t) {
-    lf_slot* old = t->slots; const size_t oc = t->cap, len = t->len;
-    lf_init(t, oc * 2);
-    for (size_t i = 0; i < oc; i++) if (old[i].used) *lf_find(t, &old[i].key, lf_hash(&old[i].key)) = old[i];
-    t->len = len;
-    free(old);
-}
-/* p = what the table holds for the key (earlier), other = what arrives (later); first = other is a record, not a partial */
-static void lf_upsert(lf_table* t, const orc_flow_id* key, const orc_flow_metrics* other) {
-    const uint64_t h = lf_hash(key);
-    lf_slot* s = lf_find(t, key, h);
-    if (s->used) { orc_accumulate_base(&s->m, other); return; }
-    if ((t->len + 1) * 2 > t->cap) { lf_grow(t); s = lf_find(t, key, h); }
-    s->key = *key; s->used = 1; s->m = *other;
-    memset(s->m.pad2, 0, 2); memset(s->m.pad4, 0, 4);          /* binary.Read skips blank fields: padding never reaches Go */
+    while (t->slots[i]) {
+        lf_entry* e = lf_at(t, t->slots[i] - 1);
+        if (memcmp(&e->key, key, 40) == 0) { orc_accumulate_base(&e->m, other); return 1; }
+        i = (i + 1) & m;
+    }
+    const size_t idx = t->len;
+    if ((idx >> LF_CHUNK_LOG2) >= t->n_chunks) return 0;
+    if (!t->chunks[idx >> LF_CHUNK_LOG2] && !(t->chunks[idx >> LF_CHUNK_LOG2] = (lf_entry*)malloc(sizeof(lf_entry) * LF_CHUNK))) return 0;
+    lf_entry* e = lf_at(t, idx);
+    e->key = *key; e->m = *other;
+    memset(e->m.pad2, 0, 2); memset(e->m.pad4, 0, 4);          /* binary.Read skips blank fields: padding never reaches Go */
+    t->slots[i] = (uint32_t)idx + 1;
     t->len++;
+    return 1;
 }
 
-typedef struct {
+typedef struct lf_job_s {
     const orc_flow_record* recs;
     size_t n;
     uint32_t T, t;
     lf_table local, merged;
-    uint32_t* items;            /* this thread's entries (slot indices) grouped by shard */
+    uint32_t* items;            /* this thread's entries (indices) grouped by shard */
     size_t* shard_start;        /* T + 1 */
     struct lf_job_s* all;
     uint64_t max_entries;
-    int overflow;
-} lf_job_body;
-typedef struct lf_job_s { lf_job_body b; } lf_job;
+    int overflow, failed;
+} lf_job;
 
 static void* lf_fold(void* p) {
-    lf_job_body* j = &((lf_job*)p)->b;
+    lf_job* j = (lf_job*)p;
     const size_t per = (j->n + j->T - 1) / j->T;
     size_t lo = (size_t)j->t * per, hi = lo + per;
     if (lo > j->n) lo = j->n;
     if (hi > j->n) hi = j->n;
-    lf_init(&j->local, 1024);
+    if (!lf_init(&j->local, hi - lo)) { j->failed = 1; return 0; }
     for (size_t i = lo; i < hi; i++) {
         orc_flow_id key = j->recs[i].id;
         key.pad = 0;                                            /* Go's blank field: not part of map identity */
-        lf_upsert(&j->local, &key, &j->recs[i].metrics);
+        if (!lf_upsert(&j->local, &key, &j->recs[i].metrics, lf_hash(&key))) { j->failed = 1; return 0; }
     }
-    /* bucket the entries by key shard (counting sort of slot indices) */
+    /* bucket the entries by key shard (counting sort of entry indices) */
     j->shard_start = (size_t*)calloc(j->T + 1, sizeof(size_t));
     j->items = (uint32_t*)malloc((j->local.len ? j->local.len : 1) * sizeof(uint32_t));
-    for (size_t i = 0; i < j->local.cap; i++) if (j->local.slots[i].used) j->shard_start[lf_shard(lf_hash(&j->local.slots[i].key), j->T) + 1]++;
-    for (uint32_t s = 0; s < j->T; s++) j->shard_start[s + 1] += j->shard_start[s];
     size_t* at = (size_t*)malloc(j->T * sizeof(size_t));
+    if (!j->shard_start || !j->items || !at) { j->failed = 1; free(at); return 0; }
+    for (size_t i = 0; i < j->local.len; i++) j->shard_start[lf_shard(lf_hash(&lf_at(&j->local, i)->key), j->T) + 1]++;
+    for (uint32_t s = 0; s < j->T; s++) j->shard_start[s + 1] += j->shard_start[s];
     memcpy(at, j->shard_start, j->T * sizeof(size_t));
-    for (size_t i = 0; i < j->local.cap; i++) if (j->local.slots[i].used) j->items[at[lf_shard(lf_hash(&j->local.slots[i].key), j->T)]++] = (uint32_t)i;
+    for (size_t i = 0; i < j->local.len; i++) j->items[at[lf_shard(lf_hash(&lf_at(&j->local, i)->key), j->T)]++] = (uint32_t)i;
     free(at);
     return 0;
 }
 
 static void* lf_merge(void* p) {
-    lf_job_body* j = &((lf_job*)p)->b;
-    lf_init(&j->merged, 1024);
+    lf_job* j = (lf_job*)p;
+    size_t mine = 0;
+    for (uint32_t t = 0; t < j->T; t++) mine += j->all[t].shard_start[j->t + 1] - j->all[t].shard_start[j->t];
+    if (!lf_init(&j->merged, mine)) { j->failed = 1; return 0; }
     for (uint32_t t = 0; t < j->T; t++) {                       /* slice order = arrival order between the tables */
-        const lf_job_body* src = &j->all[t].b;
+        const lf_job* src = &j->all[t];
         for (size_t k = src->shard_start[j->t]; k < src->shard_start[j->t + 1]; k++) {
-            const lf_slot* e = &src->local.slots[src->items[k]];
-            lf_upsert(&j->merged, &e->key, &e->m);
+            const lf_entry* e = lf_at(&src->local, src->items[k]);
+            if (!lf_upsert(&j->merged, &e->key, &e->m, lf_hash(&e->key))) { j->failed = 1; return 0; }
         }
     }
     if (j->merged.len > j->max_entries) j->overflow = 1;
@@ -231,23 +247,27 @@ size_t orc_local_fold_mt(const void* records, size_t n, uint32_t T, uint64_t max
     if (T == 0 || T > 256 || n >= 0xFFFFFFFFull) return 0;
     lf_job* jobs = (lf_job*)calloc(T, sizeof *jobs);
     for (uint32_t t = 0; t < T; t++) {
-        jobs[t].b.recs = (const orc_flow_record*)records; jobs[t].b.n = n; jobs[t].b.T = T; jobs[t].b.t = t;
-        jobs[t].b.all = jobs; jobs[t].b.max_entries = max_entries;
+        jobs[t].recs = (const orc_flow_record*)records; jobs[t].n = n; jobs[t].T = T; jobs[t].t = t;
+        jobs[t].all = jobs; jobs[t].max_entries = max_entries;
     }
     pthread_t* th = (pthread_t*)malloc(T * sizeof *th);
     const double t0 = now_s();
     for (uint32_t t = 0; t < T; t++) pthread_create(&th[t], 0, lf_fold, &jobs[t]);
     for (uint32_t t = 0; t < T; t++) pthread_join(th[t], 0);
+    int failed = 0;
+    for (uint32_t t = 0; t < T; t++) failed |= jobs[t].failed;
     const double t1 = now_s();
-    for (uint32_t t = 0; t < T; t++) pthread_create(&th[t], 0, lf_merge, &jobs[t]);
-    for (uint32_t t = 0; t < T; t++) pthread_join(th[t], 0);
+    if (!failed) {
+        for (uint32_t t = 0; t < T; t++) pthread_create(&th[t], 0, lf_merge, &jobs[t]);
+        for (uint32_t t = 0; t < T; t++) pthread_join(th[t], 0);
+    }
     const double t2 = now_s();
     size_t fl = 0, entries = 0, biggest = 0;
-    int overflow = 0;
-    for (uint32_t t = 0; t < T; t++) {
-        fl += jobs[t].b.merged.len; overflow |= jobs[t].b.overflow;
+    int overflow = failed;
+    for (uint32_t t = 0; t < T && !failed; t++) {
+        fl += jobs[t].merged.len; overflow |= jobs[t].overflow | jobs[t].failed;
         size_t mine = 0;
-        for (uint32_t s = 0; s < T; s++) mine += jobs[s].b.shard_start[t + 1] - jobs[s].b.shard_start[t];
+        for (uint32_t s = 0; s < T; s++) mine += jobs[s].shard_start[t + 1] - jobs[s].shard_start[t];
         entries += mine;
         if (mine > biggest) biggest = mine;
     }
@@ -258,11 +278,10 @@ size_t orc_local_fold_mt(const void* records, size_t n, uint32_t T, uint64_t max
         orc_flow_record* o = (orc_flow_record*)out;
         size_t k = 0;
         for (uint32_t t = 0; t < T; t++)
-            for (size_t i = 0; i < jobs[t].b.merged.cap; i++)
-                if (jobs[t].b.merged.slots[i].used) { o[k].id = jobs[t].b.merged.slots[i].key; o[k].metrics = jobs[t].b.merged.slots[i].m; k++; }
+            for (size_t i = 0; i < jobs[t].merged.len; i++) { const lf_entry* e = lf_at(&jobs[t].merged, i); o[k].id = e->key; o[k].metrics = e->m; k++; }
         qsort(o, k, sizeof(orc_flow_record), lf_rec_cmp);
     }
-    for (uint32_t t = 0; t < T; t++) { free(jobs[t].b.local.slots); free(jobs[t].b.merged.slots); free(jobs[t].b.items); free(jobs[t].b.shard_start); }
+    for (uint32_t t = 0; t < T; t++) { lf_free(&jobs[t].local); lf_free(&jobs[t].merged); free(jobs[t].items); free(jobs[t].shard_start); }
     free(jobs); free(th);
     return overflow ? 0 : n;
 }

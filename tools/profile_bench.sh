@@ -26,4 +26,6 @@ if [ -x $R/tools/pmc_calib ]; then
   done
 fi
 cd $R
+# what was profiled: the library this box ran (bench.py marks a traffic figure stale when the library it loads is another one)
+sha256sum $R/netobserv-ebpf-agent_amd/lib/libnfagg.so | cut -d' ' -f1 > $OUT/lib_sha256.txt
 find $OUT -name "*.csv" | wc -l

@@ -75,7 +75,7 @@ if f_read and f_write:
     except Exception:
         bench = None
     ingest = [k for k in per_kernel if any(s in k for s in ("k_fold", "k_pass1", "k_pass2", "k_merge_overflow", "k_ingest", "k_dedup_claim", "k_dedup_fold", "k_dedup_stream", "k_dedup_parts", "k_dedup_overflow", "k_finalize",
-                                                                "k_sketch_update", "k_ep_", "k_ring_to_front", "k_account_epochs"))]
+                                                                "k_sketch_update", "k_ep_", "k_par_", "radix_sort"))]
     if leg == "cache_max_flows_5000":                          # nfagg_account: the evictions are part of the call
         ingest += [k for k in per_kernel if "k_evict" in k and k not in ingest]
     evict = [k for k in per_kernel if "k_evict" in k]
@@ -86,8 +86,24 @@ if f_read and f_write:
     fetch_kib = sum(per_kernel[k].get("FETCH_SIZE", (0, 0))[1] for k in ingest)
     write_kib = sum(per_kernel[k].get("WRITE_SIZE", (0, 0))[1] for k in ingest)
     traffic = (fetch_kib * f_read + write_kib * f_write) * 1024.0 / calls
+    # the tree this was measured on: the library's hash as the GPU box saw it (tools/profile_bench.sh) and — summarised in the
+    # build container, where .git is — the commit and whether the tree was clean
+    import hashlib, subprocess
+    try:
+        lib_sha = open(f"{src}/lib_sha256.txt").read().strip()
+    except Exception:
+        lib_sha = None
+    def _git(*a):
+        try:
+            return subprocess.check_output(["git", *a], text=True, stderr=subprocess.DEVNULL).strip()
+        except Exception:
+            return None
+    local_lib = "netobserv-ebpf-agent_amd/lib/libnfagg.so"
+    local_sha = hashlib.sha256(open(local_lib, "rb").read()).hexdigest() if os.path.exists(local_lib) else None
     out = {
         "tag": tag, "leg": leg, "ingest_calls": calls, "kernels": ingest,
+        "lib_sha256": lib_sha or local_sha, "lib_sha256_source": "the GPU box" if lib_sha else "the build container at summary time",
+        "git_head": _git("rev-parse", "HEAD"), "git_dirty_files": len((_git("status", "--porcelain") or "").splitlines()),
         "fetch_kib_per_call": fetch_kib / calls, "write_kib_per_call": write_kib / calls,
         "factor_read": f_read, "factor_write": f_write,
         "traffic_bytes_per_call": traffic,
