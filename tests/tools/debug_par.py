@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""GPU debugging aid (libnfagg_diag.so): the cuts the epochs-found-first path of nfagg_account found against the prefix-count rule
+"""Test infrastructure: GPU debugging aid (libnfagg_diag.so): the cuts the epochs-found-first path of nfagg_account found against the prefix-count rule
 computed on the CPU (tests/test_epoch_boundaries.py)."""
 import ctypes as C
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/tools -> repo root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("NFAGG_LIB", os.path.join(ROOT, "netobserv-ebpf-agent_amd", "lib", "libnfagg_diag.so"))
 import netobserv_ebpf_agent_amd as nf
