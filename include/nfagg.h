@@ -245,8 +245,9 @@ typedef struct nfagg_config {
      * NULL -> the library allocates. Sizes as listed under NFAGG_CM_* above
      * (HLL: one byte per register, buffer 4-byte aligned). */
     void*    ext_sketch[4];
-    uint32_t copy_threads;       /* host threads that copy a caller buffer into the pinned staging ring in
-                                    nfagg_ingest (one core moves ~28 GB/s, PCIe Gen5 x16 takes ~50); 0 -> 4, 1 -> inline */
+    uint32_t copy_threads;       /* parts a caller buffer is cut into for the copy workers (nfagg_host_threads) on its way into
+                                    the pinned staging ring (one core moves ~28 GB/s, PCIe Gen5 x16 takes ~57); 0 -> what the
+                                    workers' calibration found best on this host, 1 -> inline */
     uint32_t group_flags;        /* nfagg_group_create only: NFAGG_GROUP_* */
     uint32_t local_fold;         /* nfagg_create only (a NFAGG_GROUP_LOCAL_FOLD group sets it for its members): 1 = this handle is
                                     one rank of a local-fold job (nfagg_set_sequence / nfagg_partials_* below): it folds whatever
@@ -348,6 +349,28 @@ int nfagg_ingest_device(nfagg_handle* h, const void* d_records, size_t n, size_t
  * ~30 GB/s instead of the link's ~50). A Go caller keeps its batch in such a buffer instead of a Go slice. */
 int nfagg_host_alloc(size_t bytes, void** p);
 void nfagg_host_free(void* p);
+
+/* The host side's copy workers (one pool per process; csrc/nfagg_hostpool.h): what moves records with host cores — a pageable
+ * caller buffer into the pinned staging ring (nfagg_ingest / nfagg_account), evictions out of the pinned bounce buffers, the BPF
+ * ring buffer into the staging buffer (nfagg_ringbuf_drain, the batch form of RingBufTracer's loop,
+ * pkg/flow/tracer_ringbuf.go:112-134). Created by the first nfagg_create: 16 workers bound to the CPUs of that handle's GPU's
+ * NUMA node, non-temporal copies, and the number of parts a large copy is cut into MEASURED on this host (a calibration of a few
+ * milliseconds) rather than assumed. nfagg_host_threads re-shapes the pool: `threads` workers (0 = keep the number), bound to
+ * `numa_node` (-1 = unbound); returns the workers running (>= 0) or NFAGG_EINVAL. An agent that wants its cores left alone
+ * calls nfagg_host_threads(2, -1) — or sets nfagg_config.copy_threads = 1 and drains the ring itself. */
+typedef struct nfagg_host_pool_info {
+    uint32_t struct_size;        /* sizeof(nfagg_host_pool_info) */
+    uint32_t workers;            /* threads in the pool (the calling thread always works too) */
+    uint32_t parts;              /* parts a large copy is cut into: the calibration's choice */
+    uint32_t bound;              /* 1: the workers are bound to numa_node's CPUs */
+    int32_t  numa_node;          /* -1: unbound */
+    uint32_t pad_;
+    double   calibrated_gbs;     /* what the best setting copied in the calibration, GB/s (host memory to host memory) */
+} nfagg_host_pool_info;
+int nfagg_host_threads(unsigned threads, int numa_node);
+int nfagg_host_info(nfagg_host_pool_info* out);
+/* The NUMA node `device` hangs off (/sys/bus/pci/devices/<bdf>/numa_node); -1 when unknown. */
+int nfagg_device_numa_node(int device);
 
 /* Zero-copy producer path: borrow the next pinned staging buffer
  * (capacity = cfg.staging_records), fill it (e.g. straight from the eBPF ring,

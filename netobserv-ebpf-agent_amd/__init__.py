@@ -12,7 +12,8 @@ from ._lib import (OK, FULL, TRUNCATED, REASON_TIMEOUT, REASON_FULL, REASON_CLOS
                    FEAT_ADDITIONAL, FEAT_DNS, FEAT_DROPS, FEAT_NETWORK_EVENTS, FEAT_XLAT, FEAT_QUIC)
 from .records import (FLOW_ID, FLOW_METRICS, FLOW_RECORD, ADDITIONAL, DNS, PKT_DROP, NETWORK_EVENTS, XLAT, QUIC,
                       ROLLUP_KINDS, sort_by_key, INTF_NAME, intf_table)
-from .table import (FlowTable, FlowGroup, NfaggError, PinnedRecords, key_hash, shard_of, ip_hash, hll_estimate_from_histogram, record_times)
+from .table import (FlowTable, FlowGroup, NfaggError, PinnedRecords, key_hash, shard_of, ip_hash, hll_estimate_from_histogram, record_times,
+                    host_threads, host_info, device_numa_node)
 from .accounter import (Accounter, NewAccounter, NewRecord, Record, IntfDirUdn, NewIntfDirUdn, Metrics, NoOp, CLOSE,
                         SetInterfaceNamer, SetGlobalIP)
 from . import synth

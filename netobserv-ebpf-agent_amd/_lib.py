@@ -107,6 +107,9 @@ SIGNATURES = {
     "nfagg_ingest_device": (C.c_int, [_vp, _vp, _sz, _psz]),
     "nfagg_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "nfagg_host_free": (None, [_vp]),
+    "nfagg_host_threads": (C.c_int, [C.c_uint, C.c_int]),
+    "nfagg_host_info": (C.c_int, [_vp]),
+    "nfagg_device_numa_node": (C.c_int, [C.c_int]),
     "nfagg_staging_acquire": (C.c_int, [_vp, C.POINTER(_vp), _psz]),
     "nfagg_staging_commit": (C.c_int, [_vp, _sz, _psz]),
     "nfagg_len": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),

@@ -17,6 +17,7 @@
 
 #include "../../include/nfagg.h"
 #include "nfagg_internal.h"
+#include "nfagg_hostpool.h"
 #include "nfagg_pb.h"
 
 using namespace nfagg;
@@ -655,6 +656,27 @@ int subflow_join(nfagg_handle* h, uint32_t n_shards, uint32_t shard_id) {
 
 }  // namespace
 
+// The NUMA node a device hangs off: /sys/bus/pci/devices/<domain:bus:dev.fn>/numa_node (-1: unknown / not a NUMA host).
+static int device_numa_node(int device) {
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char* c = bdf; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE* f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
+// First handle of the process: the copy workers, bound next to its GPU. Later handles (other GPUs of a group) share them.
+static void host_pool_for_device(int device) {
+    static std::once_flag once;
+    std::call_once(once, [device] { (void)HostPool::get().configure(0, device_numa_node(device)); });
+}
+
 extern "C" {
 
 uint32_t nfagg_abi_version(void) { return NFAGG_ABI_VERSION; }
@@ -688,8 +710,7 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
     if (cfg.cm_depth > 8 || cfg.cm_log2_width < 4 || cfg.cm_log2_width > 28 || cfg.hll_p < 4 || cfg.hll_p > 18)
         return fail(nullptr, NFAGG_EINVAL, "sketch parameters out of range");
     if (cfg.staging_records == 0) cfg.staging_records = 1ull << 20;
-    if (cfg.copy_threads == 0) cfg.copy_threads = 4;
-    if (cfg.copy_threads > 64) return fail(nullptr, NFAGG_EINVAL, "copy_threads > 64");
+    if (cfg.copy_threads > 64) return fail(nullptr, NFAGG_EINVAL, "copy_threads > 64");      // 0: what the copy workers' calibration found best
     if (cfg.n_shards == 0) cfg.n_shards = 1;
     if (cfg.shard_id >= cfg.n_shards) return fail(nullptr, NFAGG_EINVAL, "shard_id %u >= n_shards %u", cfg.shard_id, cfg.n_shards);
     if (cfg.local_fold > 1) return fail(nullptr, NFAGG_EINVAL, "local_fold must be 0 or 1");
@@ -713,6 +734,7 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
         }                                                                                        \
     } while (0)
     CREATE_TRY(hipSetDevice(h->device));
+    host_pool_for_device(h->device);            // the copy workers: created with the first handle, next to its GPU (nfagg_hostpool.h)
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATE_TRY(hipMalloc((void**)&h->tv.hot, slots * sizeof(SlotHot)));
     CREATE_TRY(hipMalloc((void**)&h->tv.cold, slots * sizeof(SlotCold)));
@@ -862,23 +884,13 @@ static int staging_alloc(nfagg_handle* h) {
     return NFAGG_OK;
 }
 
-// Caller buffer -> pinned staging buffer. One core's memcpy (~28 GB/s) is slower than the PCIe link the pinned
-// buffer feeds (~50 GB/s), so large copies are split over cfg.copy_threads threads on 4 KiB boundaries.
+// Caller buffer -> pinned staging buffer (and bounce buffer -> caller buffer). One core's memcpy (~28 GB/s) is slower than the PCIe
+// link the pinned buffer feeds (~57 GB/s), so large copies are cut into parts for the process's copy workers (nfagg_hostpool.h:
+// bound to the GPU's NUMA node, non-temporal stores). threads: cfg.copy_threads — 0 = the number of parts the workers' calibration
+// found best on this host, 1 = inline.
 static void staged_copy(void* dst, const void* src, size_t bytes, unsigned threads) {
-    constexpr size_t kMinPerThread = 4u << 20;
-    if (threads > bytes / kMinPerThread) threads = (unsigned)(bytes / kMinPerThread);
-    if (threads <= 1) { memcpy(dst, src, bytes); return; }
-    const size_t per = ((bytes / threads) + 4095) & ~(size_t)4095;
-    std::thread th[64];
-    unsigned started = 0;
-    for (unsigned t = 1; t < threads; t++) {
-        const size_t lo = per * t;
-        if (lo >= bytes) break;
-        const size_t len = (lo + per < bytes && t + 1 < threads) ? per : bytes - lo;
-        th[started++] = std::thread([=] { memcpy((char*)dst + lo, (const char*)src + lo, len); });
-    }
-    memcpy(dst, src, per < bytes ? per : bytes);
-    for (unsigned t = 0; t < started; t++) th[t].join();
+    if (threads == 1) { memcpy(dst, src, bytes); return; }
+    HostPool::get().copy(dst, src, bytes, threads);
 }
 
 // Device -> caller buffer (pageable). The data must be complete on the device (the caller synchronised the producing stream).
@@ -1619,6 +1631,21 @@ int nfagg_host_alloc(size_t bytes, void** p) {
     return NFAGG_OK;
 }
 void nfagg_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int nfagg_host_threads(unsigned threads, int numa_node) {
+    if (threads > 64) return NFAGG_EINVAL;
+    return (int)HostPool::get().configure(threads, numa_node);
+}
+
+int nfagg_host_info(nfagg_host_pool_info* out) {
+    if (!out || out->struct_size != sizeof(nfagg_host_pool_info)) return NFAGG_EINVAL;
+    HostPool& p = HostPool::get();
+    out->workers = p.workers(); out->parts = p.best_parts(); out->numa_node = p.node(); out->bound = p.bound() ? 1u : 0u;
+    out->calibrated_gbs = p.calibrated_gbs();
+    return NFAGG_OK;
+}
+
+int nfagg_device_numa_node(int device) { return device_numa_node(device); }
 
 // pkg/model/record.go:90-97
 void nfagg_record_times(int64_t now_unix_ns, uint64_t mono_now_ns, const nfagg_flow_metrics* m,

@@ -4,7 +4,7 @@
 // checks per sample (empty -> stop; short header -> error; busy -> stop without consuming;
 // discard -> skip; copy), one consumer-position store per batch instead of one per sample.
 #include <string.h>
-#include <thread>
+#include "nfagg_hostpool.h"
 #include "../../include/nfagg.h"
 
 namespace {
@@ -13,8 +13,8 @@ constexpr uint32_t kDiscard = 0x40000000u;   // BPF_RINGBUF_DISCARD_BIT
 constexpr uint64_t kHdr = 8;                 // BPF_RINGBUF_HDR_SZ
 constexpr uint32_t kRecord = 144;            // sizeof(flow_record_t), bpf/types.h:212-215
 constexpr uint64_t kStride = kHdr + kRecord; // a committed flow sample: header + 144 bytes (already a multiple of 8)
-constexpr size_t kBulkMin = 32768;           // samples from which a drain is worth splitting over threads
-constexpr unsigned kBulkThreads = 4;         // one core copies ~5 GB/s of 144-byte samples; the pinned buffer feeds a ~50 GB/s link. (Eight: faster on some boxes, 2-4 x slower on others — profiles/r04_ring_drain_threads.txt)
+constexpr size_t kBulkMin = 32768;           // samples from which a drain is worth splitting over the copy workers (nfagg_hostpool.h)
+constexpr unsigned kBulkMaxParts = 64;
 
 inline void copy_sample(const nfagg_ringbuf* rb, uint64_t dstart, uint8_t* o) {
     const uint64_t size = rb->mask + 1;
@@ -25,6 +25,15 @@ inline void copy_sample(const nfagg_ringbuf* rb, uint64_t dstart, uint8_t* o) {
         memcpy(o + first, rb->data, kRecord - first);
     }
 }
+// the same with non-temporal stores (o 16-byte aligned: the staging buffer is, and 144 is a multiple of 16): the sample is on its
+// way to the DMA engine, not to this core's cache
+inline void copy_sample_stream(const nfagg_ringbuf* rb, uint64_t dstart, uint8_t* o) {
+    if (dstart + kRecord > rb->mask + 1 || ((uintptr_t)o & 15)) { copy_sample(rb, dstart, o); return; }
+    const uint8_t* s = rb->data + dstart;
+    __m128i v[9];
+    for (int k = 0; k < 9; k++) v[k] = _mm_loadu_si128((const __m128i*)(s + 16 * k));
+    for (int k = 0; k < 9; k++) _mm_stream_si128((__m128i*)(o + 16 * k), v[k]);
+}
 
 // The ring of a busy agent holds nothing but committed 144-byte flow samples, 152 bytes apart. Under that assumption sample i of
 // a run starts at cons + 152 i, so a run can be split over threads: each verifies as it copies that every header in its range
@@ -32,37 +41,46 @@ inline void copy_sample(const nfagg_ringbuf* rb, uint64_t dstart, uint8_t* o) {
 // per-sample reader (ring.go:44-101) would have delivered up to the first such header of the first thread that met one; what later
 // threads copied beyond it is discarded, and the sequential loop takes over at that sample. Returns the samples delivered.
 size_t drain_uniform_run(const nfagg_ringbuf* rb, uint64_t cons, size_t want, uint8_t* out, uint64_t* errno_counts) {
-    unsigned T = (unsigned)(want / (kBulkMin / 2));
-    if (T > kBulkThreads) T = kBulkThreads;
+    nfagg::HostPool& pool = nfagg::HostPool::get();
+    unsigned T = pool.best_parts();
+    if (T > want / (kBulkMin / 4)) T = (unsigned)(want / (kBulkMin / 4));
+    if (T > kBulkMaxParts) T = kBulkMaxParts;
     if (T < 1) T = 1;
     const size_t per = (want + T - 1) / T;
-    size_t ok[kBulkThreads];
-    uint64_t err[kBulkThreads][256];
+    size_t ok[kBulkMaxParts];
+    // (per-part errno histograms only when asked for: 2 KiB each)
+    uint64_t* err = errno_counts ? static_cast<uint64_t*>(calloc((size_t)T * 256, sizeof(uint64_t))) : nullptr;
+    const bool count_errno = errno_counts && err;
     auto work = [&](unsigned t) {
         const size_t lo = per * t, hi = lo + per < want ? lo + per : want;
         size_t i = lo;
-        if (errno_counts) memset(err[t], 0, sizeof err[t]);
         for (; i < hi; i++) {
             const uint64_t at = cons + kStride * i;
             const uint32_t len = __atomic_load_n(reinterpret_cast<const uint32_t*>(rb->data + (at & rb->mask)), __ATOMIC_ACQUIRE);
             if (len != kRecord) break;                               // busy, discarded or another length: the sequential reader decides
             uint8_t* o = out + i * kRecord;
-            copy_sample(rb, (at + kHdr) & rb->mask, o);
-            if (errno_counts) err[t][o[40 + 57]]++;
+            const uint64_t dstart = (at + kHdr) & rb->mask;
+            copy_sample_stream(rb, dstart, o);
+            if (count_errno) err[(size_t)t * 256 + rb->data[(dstart + 40 + 57) & rb->mask]]++;
         }
+        _mm_sfence();
         ok[t] = i - lo;
     };
-    std::thread th[kBulkThreads];
-    for (unsigned t = 1; t < T; t++) th[t] = std::thread(work, t);
-    work(0);
-    for (unsigned t = 1; t < T; t++) th[t].join();
+    pool.parallel(T, work);
     size_t n = 0;
+    bool ended = false;
     for (unsigned t = 0; t < T; t++) {
         const size_t lo = per * t, hi = lo + per < want ? lo + per : want;
-        n += ok[t];
-        if (errno_counts) for (int e = 0; e < 256; e++) errno_counts[e] += err[t][e];
-        if (ok[t] < hi - lo) break;                                  // the run ends inside this thread's range
+        if (!ended) {
+            n += ok[t];
+            if (count_errno) for (int e = 0; e < 256; e++) errno_counts[e] += err[(size_t)t * 256 + e];
+            if (ok[t] < hi - lo) ended = true;                       // the run ends inside this part's range
+        }
     }
+    if (errno_counts && !err) {                                      // no memory for the per-part counts: count what was delivered, after the fact
+        for (size_t i = 0; i < n; i++) errno_counts[out[i * kRecord + 40 + 57]]++;
+    }
+    free(err);
     return n;
 }
 }
@@ -107,7 +125,7 @@ extern "C" int nfagg_ringbuf_drain(const nfagg_ringbuf* rb, void* dst, size_t ca
                 const size_t got = drain_uniform_run(rb, cons, want, out + n * kRecord, errno_counts);
                 n += got; cons += kStride * got;
                 if (got == want) continue;
-                bulk_holdoff = 1024;                                 // a ring full of odd samples is not worth a thread launch each
+                bulk_holdoff = 1024;                                 // a ring full of odd samples is not worth waking the workers each
                 remaining = prod - cons;                             // > 0: the run ended at a sample, not at the end of the content
             }
         }

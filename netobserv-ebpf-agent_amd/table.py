@@ -42,6 +42,33 @@ class PinnedRecords:
         self.close()
 
 
+class _HostPoolInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("workers", C.c_uint32), ("parts", C.c_uint32), ("bound", C.c_uint32),
+                ("numa_node", C.c_int32), ("pad_", C.c_uint32), ("calibrated_gbs", C.c_double)]
+
+
+def host_threads(threads: int = 0, numa_node: int = -1) -> int:
+    """nfagg_host_threads: (re)shape the process's copy workers; returns the workers running."""
+    rc = L.lib.nfagg_host_threads(threads, numa_node)
+    if rc < 0:
+        raise NfaggError(rc, "nfagg_host_threads")
+    return rc
+
+
+def host_info() -> dict:
+    """nfagg_host_info: workers, the calibrated number of parts per copy, NUMA binding, the calibration's best rate."""
+    info = _HostPoolInfo(struct_size=C.sizeof(_HostPoolInfo))
+    rc = L.lib.nfagg_host_info(C.byref(info))
+    if rc != L.OK:
+        raise NfaggError(rc, "nfagg_host_info")
+    return {"workers": info.workers, "parts": info.parts, "bound": bool(info.bound), "numa_node": info.numa_node,
+            "calibrated_GBs": round(info.calibrated_gbs, 1)}
+
+
+def device_numa_node(device: int = 0) -> int:
+    return int(L.lib.nfagg_device_numa_node(device))
+
+
 _ROLLUP_FN = {
     "additional": L.lib.nfagg_rollup_additional, "dns": L.lib.nfagg_rollup_dns, "drops": L.lib.nfagg_rollup_drops,
     "network_events": L.lib.nfagg_rollup_network_events, "xlat": L.lib.nfagg_rollup_xlat, "quic": L.lib.nfagg_rollup_quic,

@@ -20,13 +20,20 @@ else:
     out = np.empty(n * 144, dtype=np.uint8)
 out[:] = 0
 rb = L.RingBuf(data.ctypes.data, size - 1, prod.ctypes.data, cons.ctypes.data)
-best, rates = 0, []
-for rep in range(9):
-    cons[0] = 0
-    nn, sk = C.c_size_t(0), C.c_size_t(0)
-    t = time.perf_counter()
-    rc = L.lib.nfagg_ringbuf_drain(C.byref(rb), out.ctypes.data_as(C.c_void_p), n, C.byref(nn), C.byref(sk), None)
-    dt = time.perf_counter() - t
-    assert rc == 0 and nn.value == n
-    best = max(best, n / dt / 1e6); rates.append(round(n / dt / 1e6))
-print("drain into %s memory: best %.1f M records/s (%.1f GB/s); all passes: %s" % ("page-locked" if pinned else "pageable", best, best * 144 / 1e3, rates))
+node = nf.device_numa_node(0)
+for threads, bind in ((0, node), (4, node), (8, node), (16, node), (32, node), (16, -1)):
+    nf.host_threads(threads, bind)                   # what the first nfagg_create does: (0, the GPU's NUMA node)
+    info = nf.host_info()
+    rates = []
+    for rep in range(9):
+        cons[0] = 0
+        nn, sk = C.c_size_t(0), C.c_size_t(0)
+        t = time.perf_counter()
+        rc = L.lib.nfagg_ringbuf_drain(C.byref(rb), out.ctypes.data_as(C.c_void_p), n, C.byref(nn), C.byref(sk), None)
+        dt = time.perf_counter() - t
+        assert rc == 0 and nn.value == n
+        rates.append(round(n / dt / 1e6))
+    rates.sort()
+    print("drain into %s memory, pool %s: min/median/max %d / %d / %d M records/s (median %.1f GB/s); all passes: %s"
+          % ("page-locked" if pinned else "pageable", info, rates[0], rates[len(rates) // 2], rates[-1], rates[len(rates) // 2] * 144 / 1e3, rates))
+assert (out.reshape(n, 144) == np.arange(144, dtype=np.uint8)).all()
