@@ -127,6 +127,7 @@ struct nfagg_handle {
     hipStream_t d2h_stream = nullptr;
     hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     hipGraphExec_t ep_graph = nullptr;   // kChainBatch windows of the epoch kernel chain, captured once (their arguments never change)
+    bool ep_graph_off = false;           // the capture or the instantiation failed once: this handle launches its windows eagerly
     void* ep_graph_key[3] = {};          // the buffers the captured launches point at: re-capture when one was re-allocated
     // sub-flow table (kernel-dedup mode of a local-fold rank, nfagg_dedup.h): the flow-keyed table its epochs are joined into
     // (nfagg_dedup_join.hip), allocated at the first eviction; scratch; the join that has been made and not yet evicted
@@ -720,6 +721,13 @@ int nfagg_create(const nfagg_config* cfg_in, nfagg_handle** out) {
     if (slots < 2 * cfg.max_entries) return fail(nullptr, NFAGG_EINVAL, "table_log2_slots too small: need >= 2*max_entries slots");
     if (slots > (1ull << 31)) return fail(nullptr, NFAGG_EINVAL, "table larger than 2^31 slots not supported");
 
+    // caller-owned sketch buffers: Count-Min counters are 64-bit words; HyperLogLog registers are ONE BYTE each (round 4) and are
+    // raised by a CAS on the 32-bit word that holds them — a buffer that is not 4-byte aligned cannot be updated
+    for (int k = 0; k < 2; k++) {
+        if (((uintptr_t)cfg.ext_sketch[k] & 7u) != 0) return fail(nullptr, NFAGG_EINVAL, "ext_sketch[%d] (Count-Min, uint64 counters) must be 8-byte aligned", k);
+        if (((uintptr_t)cfg.ext_sketch[2 + k] & 3u) != 0)
+            return fail(nullptr, NFAGG_EINVAL, "ext_sketch[%d] (HyperLogLog: 1 << hll_p registers of one byte each) must be 4-byte aligned", 2 + k);
+    }
     nfagg_handle* h = new (std::nothrow) nfagg_handle();
     if (!h) return fail(nullptr, NFAGG_ENOMEM, "out of host memory");
     h->cfg = cfg; h->device = cfg.device; h->slots = slots;
@@ -908,8 +916,15 @@ static bool host_is_pinned(const void* p) {
 constexpr size_t kBounceBytes = 16u << 20;
 static int d2h_copy(nfagg_handle* h, void* dst, const void* d_src, size_t bytes) {
     if (bytes == 0) return NFAGG_OK;
-    if (bytes < (4u << 20) || host_is_pinned(dst)) { HIP_TRY(h, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost)); return NFAGG_OK; }
     if (!h->d2h_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking));
+    if (bytes < (4u << 20) || host_is_pinned(dst)) {
+        // NOT a blocking hipMemcpy: that one runs on the legacy stream, and nfagg_account calls this from a helper thread while the
+        // calling thread may be CAPTURING the epoch chain's graph on the handle's stream — the capture was invalidated now and then
+        // ("operation failed due to a previous error during capture", once in ~240 soak streams: profiles/r05_soak_account.txt)
+        HIP_TRY(h, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->d2h_stream));
+        HIP_TRY(h, hipStreamSynchronize(h->d2h_stream));
+        return NFAGG_OK;
+    }
     for (int b = 0; b < 2; b++) {                                // created on first use; a failure part-way is picked up by the next call
         if (!h->h_bounce[b]) HIP_TRY(h, hipHostMalloc(&h->h_bounce[b], kBounceBytes, hipHostMallocDefault));
         if (!h->bounce_ev[b]) HIP_TRY(h, hipEventCreateWithFlags(&h->bounce_ev[b], hipEventDisableTiming));
@@ -1380,25 +1395,38 @@ static int account_chain_launch(nfagg_handle* h, const void* d, size_t n, void* 
     HIP_TRY(h, hipMemcpyAsync(h->d_ep[0], h->h_ep, chain_ctl_bytes(), hipMemcpyHostToDevice, h->stream));
     // kChainBatch windows = 4 x kChainBatch launches whose arguments are the same in every call: captured into a graph once, one
     // hipGraphLaunch per batch afterwards (eager launches cost the host ~8 us each here: the chain was host-bound)
-    if (!h->ep_graph || h->ep_graph_key[0] != h->d_ep[0] || h->ep_graph_key[1] != h->d_ep[1] || h->ep_graph_key[2] != h->d_ep[2]) {
+    if (!h->ep_graph_off && (!h->ep_graph || h->ep_graph_key[0] != h->d_ep[0] || h->ep_graph_key[1] != h->d_ep[1] || h->ep_graph_key[2] != h->d_ep[2])) {
         if (h->ep_graph) { hipGraphExecDestroy(h->ep_graph); h->ep_graph = nullptr; }
         hipGraph_t g = nullptr;
-        HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        hipError_t ec = hipSuccess;
-        for (int k = 0; k < kChainBatch && ec == hipSuccess; k++)
-            ec = launch_epoch_chain_window(h->tv, h->sk, h->d_ep[0], (uint32_t*)h->d_ep[2], (uint64_t*)h->d_ep[1], h->stream);
-        const hipError_t ee = hipStreamEndCapture(h->stream, &g);
-        if (ec != hipSuccess || ee != hipSuccess) { if (g) hipGraphDestroy(g); return fail(h, NFAGG_EDEVICE, "epoch chain capture failed: %s", hipGetErrorString(ec != hipSuccess ? ec : ee)); }
-        const hipError_t ei = hipGraphInstantiate(&h->ep_graph, g, nullptr, nullptr, 0);
-        hipGraphDestroy(g);
-        if (ei != hipSuccess) { h->ep_graph = nullptr; return fail(h, NFAGG_EDEVICE, "epoch chain graph instantiation failed: %s", hipGetErrorString(ei)); }
-        h->ep_graph_key[0] = h->d_ep[0]; h->ep_graph_key[1] = h->d_ep[1]; h->ep_graph_key[2] = h->d_ep[2];
+        hipError_t ec = h->ep_graph_off ? hipErrorNotSupported : hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+        if (ec == hipSuccess) {
+            for (int k = 0; k < kChainBatch && ec == hipSuccess; k++)
+                ec = launch_epoch_chain_window(h->tv, h->sk, h->d_ep[0], (uint32_t*)h->d_ep[2], (uint64_t*)h->d_ep[1], h->stream);
+            const hipError_t ee = hipStreamEndCapture(h->stream, &g);
+            if (ec == hipSuccess) ec = ee;
+            if (ec == hipSuccess) ec = hipGraphInstantiate(&h->ep_graph, g, nullptr, nullptr, 0);
+            if (g) hipGraphDestroy(g);
+        }
+        if (ec != hipSuccess) {
+            // no graph (a capture that something in the process invalidated, an instantiation that failed): this handle launches
+            // its windows eagerly from now on — slower (~8 us of host time per launch), never wrong
+            (void)hipGetLastError();
+            h->ep_graph = nullptr; h->ep_graph_off = true;
+        } else {
+            h->ep_graph_key[0] = h->d_ep[0]; h->ep_graph_key[1] = h->d_ep[1]; h->ep_graph_key[2] = h->d_ep[2];
+        }
     }
     EventPair ep{};
     if (h->cfg.profile) prof_begin(h, ep, 0);
     uint64_t v[9];
     for (;;) {
-        HIP_TRY(h, hipGraphLaunch(h->ep_graph, h->stream));
+        if (h->ep_graph) HIP_TRY(h, hipGraphLaunch(h->ep_graph, h->stream));
+        else {
+            for (int k = 0; k < kChainBatch; k++) {
+                const hipError_t el = launch_epoch_chain_window(h->tv, h->sk, h->d_ep[0], (uint32_t*)h->d_ep[2], (uint64_t*)h->d_ep[1], h->stream);
+                if (el != hipSuccess) return fail(h, NFAGG_EDEVICE, "epoch chain launch failed: %s", hipGetErrorString(el));
+            }
+        }
         HIP_TRY(h, hipMemcpyAsync(h->h_ep, h->d_ep[0], chain_ctl_bytes(), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         chain_ctl_read(h->h_ep, v);

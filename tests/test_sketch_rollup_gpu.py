@@ -144,3 +144,17 @@ def test_wave_combined_sketch_updates_on_hot_endpoints(nf, O, hot, n):
             assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, n)
             assert np.array_equal(tab.sketch_snapshot(nf.CM_SRC), cs) and np.array_equal(tab.sketch_snapshot(nf.CM_DST), cd)
             assert np.array_equal(tab.sketch_snapshot(nf.HLL_SRC), hs) and np.array_equal(tab.sketch_snapshot(nf.HLL_DST), hd)
+
+
+def test_misaligned_caller_owned_sketch_buffers_are_refused(nf):
+    """HyperLogLog registers are one byte each and are raised by a CAS on the 32-bit word that holds them (csrc/nfagg_device.h
+    sketch_add_side): a caller-owned register buffer (nfagg_config.ext_sketch) must be 4-byte aligned, the Count-Min counters 8-byte."""
+    import torch
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    base = buf.data_ptr()
+    for ext in ([0, 0, base + 1, 0], [0, 0, 0, base + 2], [base + 4, 0, 0, 0]):
+        with pytest.raises(nf.NfaggError) as ei:
+            nf.FlowTable(max_entries=100, sketches=nf.SKETCH_CM | nf.SKETCH_HLL, cm_log2_width=4, hll_p=4, ext_sketch=ext)
+        assert "aligned" in str(ei.value)
+    with nf.FlowTable(max_entries=100, sketches=nf.SKETCH_HLL, hll_p=8, ext_sketch=[0, 0, base + 4, base + 1024]) as tab:
+        assert tab.sketch_snapshot(nf.HLL_SRC).sum() == 0
