@@ -125,6 +125,7 @@ struct nfagg_handle {
     // ~13 GB/s here, this at the PCIe rate
     void* h_bounce[2] = {nullptr, nullptr};
     hipStream_t d2h_stream = nullptr;
+    hipStream_t d2h_small = nullptr;     // small / one-off downloads (d2h_copy): not the stream the pipelined page-locked downloads use
     hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     hipGraphExec_t ep_graph = nullptr;   // kChainBatch windows of the epoch kernel chain, captured once (their arguments never change)
     bool ep_graph_off = false;           // the capture or the instantiation failed once: this handle launches its windows eagerly
@@ -867,6 +868,7 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->d_exp) hipFree(h->d_exp);
     for (int b = 0; b < 2; b++) { if (h->h_bounce[b]) hipHostFree(h->h_bounce[b]); if (h->bounce_ev[b]) hipEventDestroy(h->bounce_ev[b]); }
     if (h->d2h_stream) hipStreamDestroy(h->d2h_stream);
+    if (h->d2h_small) hipStreamDestroy(h->d2h_small);
     if (h->ep_graph) hipGraphExecDestroy(h->ep_graph);
     if (h->h_ep) hipHostFree(h->h_ep);
     if (h->d_ep_out) hipFree(h->d_ep_out);
@@ -916,15 +918,18 @@ static bool host_is_pinned(const void* p) {
 constexpr size_t kBounceBytes = 16u << 20;
 static int d2h_copy(nfagg_handle* h, void* dst, const void* d_src, size_t bytes) {
     if (bytes == 0) return NFAGG_OK;
-    if (!h->d2h_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking));
     if (bytes < (4u << 20) || host_is_pinned(dst)) {
         // NOT a blocking hipMemcpy: that one runs on the legacy stream, and nfagg_account calls this from a helper thread while the
         // calling thread may be CAPTURING the epoch chain's graph on the handle's stream — the capture was invalidated now and then
-        // ("operation failed due to a previous error during capture", once in ~240 soak streams: profiles/r05_soak_account.txt)
-        HIP_TRY(h, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->d2h_stream));
-        HIP_TRY(h, hipStreamSynchronize(h->d2h_stream));
+        // ("operation failed due to a previous error during capture", once in ~240 soak streams: profiles/r05_soak_account.txt).
+        // On a stream of ITS OWN: a copy into pageable memory on d2h_stream left that stream's later page-locked downloads at
+        // a third of the link (nfagg_account from page-locked buffers 22.0 -> 28.0 ms, same box: profiles/r05_account_host_pipeline.txt)
+        if (!h->d2h_small) HIP_TRY(h, hipStreamCreateWithFlags(&h->d2h_small, hipStreamNonBlocking));
+        HIP_TRY(h, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->d2h_small));
+        HIP_TRY(h, hipStreamSynchronize(h->d2h_small));
         return NFAGG_OK;
     }
+    if (!h->d2h_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking));
     for (int b = 0; b < 2; b++) {                                // created on first use; a failure part-way is picked up by the next call
         if (!h->h_bounce[b]) HIP_TRY(h, hipHostMalloc(&h->h_bounce[b], kBounceBytes, hipHostMallocDefault));
         if (!h->bounce_ev[b]) HIP_TRY(h, hipEventCreateWithFlags(&h->bounce_ev[b], hipEventDisableTiming));
