@@ -195,6 +195,7 @@ NF_DEV void cut_block(int32_t cur[kCutPer], uint32_t wave_base, CutState& st, ui
     constexpr int kWaves = kCutBlock / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t lane_base = wave_base + (uint32_t)lane * 4;        // first record of this lane's row 0
+    const int wv_u = __builtin_amdgcn_readfirstlane(wv);              // (wave-uniform: a scalar)
     while (st.k < st.max_cuts) {
         uint32_t c[kCutRows] = {0, 0, 0, 0};
         if (wave_base + 64u * kCutPer > st.s) {                       // (wave-uniform) some record of this wave is at or after s
@@ -219,9 +220,13 @@ NF_DEV void cut_block(int32_t cur[kCutPer], uint32_t wave_base, CutState& st, ui
         const uint32_t incl[kCutRows] = {i01 & 0xffffu, i01 >> 16, i23 & 0xffffu, i23 >> 16};
         if (lane == 0) wtot[st.par][wv] = row_tot[0] + row_tot[1] + row_tot[2] + row_tot[3];
         __syncthreads();
-        uint32_t woff = 0, total = 0;
-#pragma unroll
-        for (int q = 0; q < kWaves; q++) { const uint32_t x = wtot[st.par][q]; total += x; woff += q < wv ? x : 0u; }
+        // the 16 wave totals: one LDS read per lane and a scan inside the first row of 16 lanes (reading all 16 in every lane and
+        // adding them up was 48 of the 135 vector instructions a wave spends per step — and the walk is bound by exactly those:
+        // one CU, its four SIMDs ~65 % busy with them, profiles/r05_cut_walk_counters.txt)
+        uint32_t pre = lane < kWaves ? wtot[st.par][lane] : 0u;
+        pre = dpp_add_u32<0x111, 0xf>(pre); pre = dpp_add_u32<0x112, 0xf>(pre); pre = dpp_add_u32<0x114, 0xf>(pre); pre = dpp_add_u32<0x118, 0xf>(pre);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)pre, kWaves - 1);
+        const uint32_t woff = wv_u ? (uint32_t)__builtin_amdgcn_readlane((int)pre, wv_u - 1) : 0u;
         if (st.before + total <= st.budget) {                         // the epoch goes on beyond this block
             st.before += total;
             st.par ^= 1u;
