@@ -975,6 +975,47 @@ int nfagg_ingest(nfagg_handle* h, const void* records, size_t n, size_t* consume
     const char* src = static_cast<const char*>(records);
     const size_t cap = (size_t)h->cfg.staging_records;
     const bool pinned_src = host_is_pinned(records);            // page-locked caller buffer: sent up as it is, no host copy
+    // ---- the whole call folded optimistically (round 5). A call of several staging buffers into a table it MIGHT fill (live + n >
+    // max_entries) used to ask the device for the exact len(entries) before every chunk — a stream synchronisation that also stops
+    // the host from copying the next chunk: host copy and upload took turns instead of overlapping (20 M records from pageable
+    // memory: 88 ms, 227 M records/s, where the same call into a table that cannot fill ran at the link's 374 M). Here the chunks
+    // are folded without a look in between and the proof comes ONCE, after the last: n_live <= max_entries and no refused claim
+    // means no record of the call found the map full (account.go:85; DESIGN.md §2 "optimistic fold"). Otherwise everything is
+    // rolled back (raw copy of the live slots, sketches, counters: taken before the first chunk) and the loop below does it step by step.
+    if (n > cap && n <= kMaxFoldChunk && h->epoch_len_hint == 0 && !h->must_evict && !h->exported && !h->tv.subflow && !h->ext_sequenced) {
+        if (!h->mirror_fresh && (rc = refresh_counters(h)) != NFAGG_OK) return rc;
+        bool blocked = false;
+        if (h->live + n > h->cfg.max_entries && (rc = ensure_seq_window(h, n, &blocked)) == NFAGG_OK && !blocked) {
+            OptState st;
+            if ((rc = opt_begin(h, st)) != NFAGG_OK) return rc;
+            size_t off = 0;
+            while (off < n && rc == NFAGG_OK) {
+                const size_t m = (n - off) < cap ? (n - off) : cap;
+                const int b = h->stage_next;
+                HIP_TRY(h, hipEventSynchronize(h->stage_free[b]));
+                const void* up = src + off * kRecordBytes;
+                if (!pinned_src) { staged_copy(h->pinned[b], up, m * kRecordBytes, h->cfg.copy_threads); up = h->pinned[b]; }
+                HIP_TRY(h, hipMemcpyAsync(h->d_stage[b], up, m * kRecordBytes, hipMemcpyHostToDevice, h->copy_stream));
+                HIP_TRY(h, hipEventRecord(h->stage_up[b], h->copy_stream));
+                HIP_TRY(h, hipStreamWaitEvent(h->stream, h->stage_up[b], 0));
+                rc = launch_ingest_profiled(h, h->d_stage[b], m, st.seq0 + off);
+                HIP_TRY(h, hipEventRecord(h->stage_free[b], h->stream));
+                h->stage_next ^= 1;
+                off += m;
+            }
+            if (rc != NFAGG_OK) return rc;
+            if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;       // the one wait of the call
+            h->stats.optimistic_folds++;
+            st.n_after = h->h_ctr->n_live;
+            if (!h->h_ctr->aborted && st.n_after <= h->cfg.max_entries) {
+                opt_commit(h, st, n);
+                if (pinned_src) HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
+                if (consumed_out) *consumed_out = n;
+                return NFAGG_OK;
+            }
+            if ((rc = opt_rollback(h, st)) != NFAGG_OK) return rc;       // some record found the map full: step by step, below
+        } else if (rc != NFAGG_OK) return rc;
+    }
     // pinned ring, double buffered: the CPU fills buffer b+1 while the GPU
     // copies/folds buffer b (tracer_ringbuf.go:112-134 forwards one record at a time)
     while (consumed < n) {

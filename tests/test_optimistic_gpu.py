@@ -31,12 +31,14 @@ def test_large_batches_split_exactly(nf, O, max_entries, batch):
 
 
 def test_no_overflow_is_one_fold(nf, O):
-    """live + batch > max_entries but the distinct keys fit: one optimistic fold, no rollback, table as the oracle's."""
+    """live + batch > max_entries but the distinct keys fit: ONE optimistic fold for the whole host call (four staging buffers folded
+    without a look at the device in between, the proof — n_live <= max_entries — read once after the last: round 5), no rollback,
+    table as the oracle's; the same call from device memory is one launch and one fold."""
     recs = _zipf(O, 4_000_000, 50_000, seed=22)
     with nf.FlowTable(max_entries=60_000, profile=True) as tab:
         assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
         st = tab.stats()
-        assert (st.optimistic_folds, st.optimistic_rollbacks) == (st.ingest_launches, 0)
+        assert (st.optimistic_folds, st.optimistic_rollbacks, st.ingest_launches) == (1, 0, 4)
         got = nf.sort_by_key(tab.evict(nf.REASON_CLOSING))
     assert_records_equal(got, O.run_accounter(recs, 60_000)[0][1])
 
