@@ -310,6 +310,10 @@ typedef struct nfagg_stats {
     uint64_t optimistic_rollbacks; /* ... of which crossed max_entries (account.go:85) and were rolled back and split */
     uint64_t sequence_rebases;     /* times the 32-bit window of the slots' sequence tags was moved (once per ~2^32 records of an
                                       epoch; the epoch itself goes on: account.go:58-100 has no maximum length) */
+    uint64_t account_epochs_first; /* nfagg_account[_device]: launches that found their epochs first and folded them from the sorted call */
+    uint64_t account_chain;        /* ... launches of the kernel chain (short calls; calls the first path declined) */
+    uint64_t account_declined;     /* ... of which were calls the first path declined (too many other flows' records between a
+                                      record and its previous occurrence among equal hash bits) */
 } nfagg_stats;
 
 uint32_t nfagg_abi_version(void);

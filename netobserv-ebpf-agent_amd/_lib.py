@@ -92,6 +92,7 @@ class Stats(C.Structure):
         ("sketch_launches", C.c_uint64), ("sketch_kernel_ms", C.c_double), ("max_probe", C.c_uint64),
         ("records_bypassed", C.c_uint64),
         ("optimistic_folds", C.c_uint64), ("optimistic_rollbacks", C.c_uint64), ("sequence_rebases", C.c_uint64),
+        ("account_epochs_first", C.c_uint64), ("account_chain", C.c_uint64), ("account_declined", C.c_uint64),
     ]
 
 

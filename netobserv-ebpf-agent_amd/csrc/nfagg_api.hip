@@ -1541,13 +1541,15 @@ static int account_device_core(nfagg_handle* h, const void* d_records, size_t n,
                                     epoch_end + n_ep, max_epochs - n_ep, &c, &e, &o, &stop);
             for (size_t k = 0; k < e; k++) epoch_end[n_ep + k] += out_pos;
             consumed += c; n_ep += e; out_pos += o;
-            if (rc == kParDeclined) { rc = NFAGG_OK; par_declined = true; continue; }
+            if (rc == kParDeclined) { rc = NFAGG_OK; par_declined = true; h->stats.account_declined++; continue; }
+            if (rc == NFAGG_OK) h->stats.account_epochs_first++;
             if (rc != NFAGG_OK) break;
             if (stop == 2) { rc = NFAGG_TRUNCATED; break; }
             continue;
         }
         if (account_fast_ok(h, n - consumed, out_cap - out_pos) && n_ep < max_epochs) {
             size_t c = 0, e = 0, o = 0; uint32_t stop = 0;
+            h->stats.account_chain++;
             rc = account_chain_launch(
                 h, base + consumed * kRecordBytes, n - consumed, obase + out_pos * kRecordBytes, out_cap - out_pos,
                 epoch_end + n_ep, max_epochs - n_ep, &c, &e, &o, &stop);

@@ -11,12 +11,13 @@
 // already brings them together: the call's records sorted by (key hash, index) hold each flow's records of one epoch as a
 // contiguous SEGMENT in arrival order. So:
 //
-//   k_par_hash      sort key per record: (top 32 bits of the key hash) << 32 | index
-//   rocPRIM radix sort of the keys on their top 32 bits (stable: equal hashes stay in index order — the array is sorted as 64-bit
+//   k_par_hash      sort key per record: (top 40 bits of the key hash) << 24 | index (a launch takes at most 2^24 records)
+//   rocPRIM radix sort of the keys on their hash bits (stable: equal hash bits stay in index order — the array is sorted as 64-bit
 //                   numbers)
-//   k_par_links     prev(i) from the neighbours to the left in sorted order, FULL keys compared: flows that share their 32 hash
-//                   bits (a hundred pairs per million flows; any number when somebody crafts them) are told apart here and in the
-//                   fold — there is no collision fallback
+//   k_par_links     prev(i) from the neighbours to the left in sorted order, FULL keys compared: flows that share their 40 hash
+//                   bits (one pair in two calls at a million flows; any number when somebody crafts them) are told apart here and
+//                   in the fold. Only when more than 4096 records of OTHER flows lie between a record and its previous occurrence
+//                   (a cold flow sharing its hash bits with one of the hottest) does the call go to the kernel chain
 //   k_par_live      first occurrences whose flow is live in the table: prev = -2 (not new in the first epoch of the call)
 //   k_par_cuts      ONE workgroup streams prev[] once in blocks of 16 Ki records and walks the epochs over it: per step one
 //                   wave-level DPP scan, one 16-entry LDS exchange, one barrier (two when an epoch ends in the block)
@@ -36,7 +37,9 @@ namespace nfagg {
 
 constexpr int kParBlock = 256;
 constexpr uint32_t kParNone = 0xffffffffu;
-constexpr int kLinkSearch = 64;                                       // flows sharing 32 hash bits that k_par_links looks through before it gives up
+constexpr int kLinkSearch = 4096;                                     // records of OTHER flows with the same hash bits that k_par_links walks over before it gives up
+constexpr int kIdxBits = 24;                                          // a launch takes at most 2^24 records: the index's share of a sort key
+constexpr uint64_t kIdxMask = (1ull << kIdxBits) - 1ull, kHashMask = ~kIdxMask;   // ... and the key hash's: its top 40 bits
 constexpr uint32_t kSegShort = 16;                                    // records per segment the one-lane fold takes
 
 static inline int par_grid(uint64_t n, int per_block = kParBlock, int cap = 1 << 20) {
@@ -44,6 +47,16 @@ static inline int par_grid(uint64_t n, int per_block = kParBlock, int cap = 1 <<
     if (g < 1) g = 1;
     if (g > (uint64_t)cap) g = cap;
     return (int)g;
+}
+
+// The index a sort key carries. The empty asm is not decoration: hipcc (ROCm 7.2) sees `(key & 0xFFFFFF) * 144` as a 24-bit
+// multiply, drops the mask as "not demanded", and then forms v_mad_u64_u32 — which DOES read the upper eight bits: the record
+// address was computed from the key's low 32 bits, hash bits included (k_par_links faulted on its first launch; ISA and the
+// stand-alone reproduction: profiles/r05_mul24_miscompile.txt, tools/gpu/links_probe.hip). An opaque register keeps the mask.
+NF_DEV uint32_t key_index(uint64_t key) {
+    uint32_t i = (uint32_t)(key & kIdxMask);
+    asm volatile("" : "+v"(i));
+    return i;
 }
 
 NF_DEV void par_key(const void* recs, uint64_t i, uint64_t w[5]) {
@@ -62,11 +75,11 @@ __global__ __launch_bounds__(kParBlock) void k_par_hash(const void* __restrict__
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint64_t w[5];
         par_key(recs, i, w);
-        keys[i] = (key_hash(w) & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)i;
+        keys[i] = (key_hash(w) & kHashMask) | (uint64_t)i;
     }
 }
 
-// Sorted position p holds record i. Its previous occurrence is the nearest position to the left with the same 32 hash bits AND the
+// Sorted position p holds record i. Its previous occurrence is the nearest position to the left with the same hash bits AND the
 // same key (equal hash bits are in index order). Nearly always that is position p - 1 or nothing; flows that share their hash bits
 // interleave, and the search walks over the other flows' records (at most kLinkSearch of them: beyond that *overflow is raised and
 // the call takes the kernel chain).
@@ -75,19 +88,21 @@ __global__ __launch_bounds__(kParBlock) void k_par_links(const void* __restrict_
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         const uint64_t key = ks[p];
-        const uint32_t i = (uint32_t)key, hb = (uint32_t)(key >> 32);
+        const uint32_t i = key_index(key);
+        const uint64_t hb = key & kHashMask;
         int32_t pv = -1;
-        if (p > 0 && (uint32_t)(ks[p - 1] >> 32) == hb) {
+        if (p > 0 && (ks[p - 1] & kHashMask) == hb) {
             uint64_t a[5], b[5];
             par_key(recs, i, a);
             uint64_t q = p;
             int looked = 0;
             while (q > 0) {
                 const uint64_t k2 = ks[--q];
-                if ((uint32_t)(k2 >> 32) != hb) break;
+                if ((k2 & kHashMask) != hb) break;
                 if (++looked > kLinkSearch) { atomicExch(overflow, 1u); break; }
-                par_key(recs, (uint32_t)k2, b);
-                if (par_same_key(a, b)) { pv = (int32_t)(uint32_t)k2; break; }
+                const uint32_t j = key_index(k2);
+                par_key(recs, j, b);
+                if (par_same_key(a, b)) { pv = (int32_t)j; break; }
             }
         }
         prev[i] = pv;
@@ -373,10 +388,10 @@ __global__ __launch_bounds__(kParBlock) void k_par_segfold(const void* __restric
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const uint64_t key = ks[p];
-    const uint32_t i = (uint32_t)key;
+    const uint32_t i = key_index(key);
     const uint32_t ps = pos[i];
     if (ps == kParNone) return;
-    const uint64_t limit = (key & 0xFFFFFFFF00000000ull) | (uint64_t)cuts[ps / max_entries + 1];     // (hash bits, end of the epoch)
+    const uint64_t limit = (key & kHashMask) | (uint64_t)cuts[ps / max_entries + 1];     // (hash bits, end of the epoch)
     if (p + kSegShort < n && ks[p + kSegShort] < limit) {             // more than kSegShort positions: a wave takes it
         long_list[atomicAdd(n_long, 1u)] = (uint32_t)p;
         return;
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(kParBlock) void k_par_segfold(const void* __restric
         const uint64_t k2 = ks[q];
         if (k2 >= limit) break;
         Rec r;
-        load_record_head(recs, (uint32_t)k2, r);
+        load_record_head(recs, key_index(k2), r);
         r.d[9] &= 0x00ffffffu;
         uint64_t w2[5];
         r.key_words(w2);
@@ -467,9 +482,9 @@ __global__ __launch_bounds__(kParBlock) void k_par_segfold_long(const void* __re
     for (uint32_t e = blockIdx.x * (kParBlock / 64) + (threadIdx.x >> 6); e < count; e += waves) {
         const uint64_t p = long_list[e];
         const uint64_t key = ks[p];
-        const uint32_t i = (uint32_t)key;
+        const uint32_t i = key_index(key);
         const uint32_t ps = pos[i];
-        const uint64_t limit = (key & 0xFFFFFFFF00000000ull) | (uint64_t)cuts[ps / max_entries + 1];
+        const uint64_t limit = (key & kHashMask) | (uint64_t)cuts[ps / max_entries + 1];
         uint64_t lo = p + 1, hi = n;                                  // first position in (p, n] whose key is >= limit
         while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ks[mid] < limit) lo = mid + 1; else hi = mid; }
         const uint64_t end = lo;
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(kParBlock) void k_par_segfold_long(const void* __re
         SegAcc a;
         a.clear();
         for (uint64_t q = p + lane; q < end; q += 64) {
-            const uint32_t i2 = (uint32_t)ks[q];
+            const uint32_t i2 = key_index(ks[q]);
             Rec r;
             load_record_head(recs, i2, r);
             r.d[9] &= 0x00ffffffu;
@@ -517,12 +532,12 @@ hipError_t launch_par_hash(const void* d_records, uint64_t n, uint64_t* d_keys, 
 
 // temp == nullptr: only *temp_bytes is written. Sorted on the hash bits only: the indices below them are in order already, and the
 // radix passes are stable. ALWAYS the one-sweep radix passes (MergeSortLimit 0): up to 2^20 keys rocPRIM would take its block-sort +
-// merge path, and with a partial bit range that path handed k_par_links an array in which a flow's records met only inside 1024-key
-// tiles (profiles/r05_sort_merge_path.txt: previous occurrences found only within a tile, every call below 1 Mi records wrong;
-// the array read back after the call was sorted).
+// merge path, and with a partial bit range that path does not deliver the stable sort on those bits (tools/gpu/sort_probe.hip: at
+// 600 000 keys, bits [32, 64) or [24, 64), every position differs from std::stable_sort; the one-sweep passes are right for every
+// range and size tried: profiles/r05_sort_merge_path.txt).
 using ParSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
 hipError_t launch_par_sort(void* temp, size_t* temp_bytes, const uint64_t* k_in, uint64_t* k_out, uint64_t n, hipStream_t s) {
-    return rocprim::radix_sort_keys<ParSortConfig>(temp, *temp_bytes, k_in, k_out, (size_t)n, 32, 64, s);
+    return rocprim::radix_sort_keys<ParSortConfig>(temp, *temp_bytes, k_in, k_out, (size_t)n, kIdxBits, 64, s);
 }
 
 hipError_t launch_par_links(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, int32_t* d_prev, uint32_t* d_overflow, hipStream_t s) {

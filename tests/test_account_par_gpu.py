@@ -66,6 +66,7 @@ def test_epochs_found_first_equal_the_reference_loop(nf, O, max_entries, keys, n
             assert n_ev > 3
         st = tab.stats()
         assert st.records_ingested == n and st.evictions[nf.REASON_FULL] == n_ev - 1
+        assert st.account_epochs_first >= 1 if variant == 0 else (st.account_epochs_first == 0 and st.account_chain >= 1)   # (a short rest of a call is the chain's)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
@@ -84,24 +85,39 @@ def test_epochs_that_span_calls_a_hot_flow_and_the_sketches(nf, O, seed):
 
 
 @pytest.mark.parametrize("variant", [0, 30])
-@pytest.mark.parametrize("n_colliding,max_entries", [(2, 5000), (40, 300), (200, 5000)])
-def test_flows_that_share_their_key_hash(nf, O, n_colliding, max_entries, variant):
+@pytest.mark.parametrize("n_colliding,max_entries,hot", [(2, 5000, False), (40, 300, False), (200, 5000, False), (2, 5000, True), (40, 300, True), (600, 300, True)])
+def test_flows_that_share_their_key_hash(nf, O, n_colliding, max_entries, hot, variant):
     """Distinct keys with ONE 64-bit key hash (crafted: the hash is public and invertible step by step). The sort of the
-    epochs-found-first path groups by 32 hash bits only: previous-occurrence links and segment folds compare full keys and take such
-    flows apart; 200 of them are more than the link search looks through (64): that call is the chain's."""
+    epochs-found-first path groups by hash bits only: previous-occurrence links and segment folds compare full keys and take such
+    flows apart — on that path, no fallback (hot = False: the colliding flows are cold ones, their records a few positions apart among
+    equal hash bits). hot = True: half of them are the stream's hottest flows; with 600 of them the run of equal hash bits holds
+    70 000 records and 1 776 records have more than 4096 records of OTHER flows between themselves and their previous occurrence — more
+    than the link search walks over: that call is the kernel chain's, and says so in the stats. Same evictions either way."""
     rng = np.random.default_rng(n_colliding)
     recs = _stream(O, 400_000, 20_000, seed=31 + n_colliding)
     ids = np.ascontiguousarray(recs["id"]).view(np.uint64).reshape(len(recs), 5).copy()
     _, inv, counts = np.unique(ids, axis=0, return_inverse=True, return_counts=True)
     inv = inv.reshape(-1)
     order = np.argsort(-counts)
-    chosen = np.concatenate([order[:n_colliding // 2], order[2000:2000 + n_colliding - n_colliding // 2]])     # hot and cold flows alike
+    if hot:
+        chosen = np.concatenate([order[:n_colliding // 2], order[2000:2000 + n_colliding - n_colliding // 2]])
+    else:
+        chosen = order[3000:3000 + n_colliding]                        # a few records each
     crafted = _colliding_keys(rng, n_colliding)
     for k, f in enumerate(chosen):
         ids[inv == f] = crafted[k]
     recs.view(np.uint8).reshape(len(recs), 144)[:, :40] = ids.view(np.uint8).reshape(len(recs), 40)
     with nf.FlowTable(max_entries=max_entries, ingest_variant=variant) as tab:
         _check(nf, O, tab, recs, max_entries, [len(recs)])
+        st = tab.stats()
+        if variant == 30:
+            assert st.account_epochs_first == 0 and st.account_chain >= 1
+        elif hot:                                                         # (whether a walk really exceeds the bound depends on where the cold records fall)
+            assert st.account_epochs_first + st.account_chain >= 1 and (st.account_declined == 0 or st.account_chain >= 1)
+            if n_colliding >= 600:
+                assert st.account_declined >= 1
+        else:
+            assert st.account_epochs_first >= 1 and st.account_declined == 0 and st.account_chain == 0
 
 
 def test_device_resident_call_and_small_output_room(nf, O):

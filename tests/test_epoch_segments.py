@@ -1,7 +1,7 @@
 """CPU only. The evict-on-full path of nfagg_account with its epochs found first (csrc/nfagg_epoch_par.hip),
 restated step by step in numpy and checked against the oracle's Accounter — the design pinned where no GPU is needed:
 
-  sort keys    (top 32 bits of the key hash) << 32 | index, sorted as 64-bit numbers        k_par_hash + the radix sort
+  sort keys    (top 40 bits of the key hash) << 24 | index, sorted as 64-bit numbers        k_par_hash + the radix sort
   links        prev(i) = nearest position to the left with the same hash bits AND the same key   k_par_links
   cut walk     prev[] streamed in aligned blocks, the epochs walked over the resident block       k_par_cuts
   ranks        position of every new flow among its epoch's new flows, in arrival order           k_par_rank
@@ -16,7 +16,9 @@ import numpy as np
 import pytest
 
 NONE = 0xFFFFFFFF
-HI = 0xFFFFFFFF00000000
+IDX_BITS = 24                                                        # a launch takes at most 2^24 records
+IDX = (1 << IDX_BITS) - 1
+HI = 0xFFFFFFFFFFFFFFFF ^ IDX                                         # the key hash's share of a sort key: its top 40 bits
 
 
 def key_ids(recs):
@@ -41,17 +43,17 @@ def links(ks, kid, search=1 << 30):
     prev = np.full(n, -1, dtype=np.int64)
     overflow = False
     for p in range(n):
-        i, hb = int(ks[p]) & 0xFFFFFFFF, int(ks[p]) >> 32
+        i, hb = int(ks[p]) & IDX, int(ks[p]) >> IDX_BITS
         q, looked = p, 0
         while q > 0:
             q -= 1
-            if int(ks[q]) >> 32 != hb:
+            if int(ks[q]) >> IDX_BITS != hb:
                 break
             looked += 1
             if looked > search:
                 overflow = True
                 break
-            j = int(ks[q]) & 0xFFFFFFFF
+            j = int(ks[q]) & IDX
             if kid[j] == kid[i]:
                 prev[i] = j
                 break
@@ -109,7 +111,7 @@ def fold_segments(O, recs, ks, kid, pos, cuts, max_entries):
     written = np.zeros(n_mid * max_entries, dtype=bool)
     longest = 0
     for p in range(len(ks)):
-        i = int(ks[p]) & 0xFFFFFFFF
+        i = int(ks[p]) & IDX
         if pos[i] == NONE:
             continue
         limit = (int(ks[p]) & HI) | cuts[int(pos[i]) // max_entries + 1]
@@ -117,7 +119,7 @@ def fold_segments(O, recs, ks, kid, pos, cuts, max_entries):
         acc = canonical(raw[i])
         members = 1
         for q in range(p + 1, end):
-            j = int(ks[q]) & 0xFFFFFFFF
+            j = int(ks[q]) & IDX
             if kid[j] != kid[i]:
                 continue                                             # another flow with these hash bits
             assert pos[j] == NONE
@@ -159,7 +161,7 @@ def sort_records(a):
 
 @pytest.mark.parametrize("n,keys,max_entries,hot,lanes", [(6_000, 300, 50, 0, 8), (6_000, 1_500, 200, 0, 64), (8_000, 600, 7, 700, 4),
                                                            (3_000, 50, 2, 0, 2), (3_000, 10, 1, 0, 1), (6_000, 400, 400, 0, 8)])
-@pytest.mark.parametrize("hash_mask", [0xFFFFFFFFFFFFFFFF, 0x0000000F00000000])
+@pytest.mark.parametrize("hash_mask", [0xFFFFFFFFFFFFFFFF, 0x0000000F00000000])      # all 40 hash bits / four of them: sixteen buckets
 def test_segment_folds_of_the_sorted_call_equal_the_reference_loop(O, n, keys, max_entries, hot, lanes, hash_mask):
     recs = O.gen_stream(n, seed=n + keys + max_entries, n_keys=keys, thresholds=O.zipf_thresholds(keys, 1.1), hot_permille=hot, variant=1)
     want = O.run_accounter(recs, max_entries)

@@ -63,3 +63,29 @@ def test_the_cut_walk_scans_with_dpp_and_the_sketch_kernel_reduces_with_it(disas
             kernels[cur] += 1
     assert any("k_par_cuts" in k and v >= 2 for k, v in kernels.items()), "k_par_cuts: no DPP row broadcasts in its ISA"
     assert any("k_sketch_update" in k and v >= 2 for k, v in kernels.items()), "k_sketch_update: no DPP row broadcasts in its ISA"
+
+
+def test_no_record_address_is_formed_from_an_unmasked_sort_key(disassembly):
+    """Round 5: hipcc took `(key & 0xFFFFFF) * 144` for a 24-bit multiply, dropped the mask and emitted v_mad_u64_u32 on the unmasked
+    low dword of the key (profiles/r05_mul24_miscompile.txt, tools/gpu/mul24_miscompile.hip): k_par_links read records far outside
+    the batch. csrc/nfagg_epoch_par.hip key_index() keeps the mask behind an opaque register. The signature of the miscompile — a
+    register multiplied into an address and masked with 0xffffff only AFTERWARDS — must not be in the kernels that index by sort key."""
+    cur, window, hits = None, [], []
+    for line in disassembly.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line.strip())
+        if m:
+            cur, window = m.group(1), []
+            continue
+        if not cur or "k_par_" not in cur:
+            continue
+        ins = line.split("//")[0].strip()
+        if not ins:
+            continue
+        mm = re.match(r"v_and_b32_e32 (v\d+), 0xffffff, \1$", ins)
+        if mm:
+            reg = mm.group(1)
+            for prev in window[-8:]:
+                if prev.startswith("v_mad_u64_u32") and re.search(r", %s, s\d+" % reg, prev):
+                    hits.append((cur[:60], prev, ins))
+        window.append(ins)
+    assert not hits, hits[:3]

@@ -141,10 +141,17 @@ def test_drain_empty_full_and_truncated(nf, O):
     assert rc == nf._lib.EINVAL and len(got) == 2 and int(ring.cons[0]) == before + 2 * 152
 
 
-def test_bulk_drain_runs_of_plain_samples_split_over_threads(nf, O):
-    """Runs of >= 32768 plain 144-byte samples take the multi-threaded path of nfagg_ringbuf_drain (each thread verifies the headers
-    of its range; the run ends at the first header that is not "144 bytes, committed"): same result as the per-sample reader, with a
-    discarded sample, a wrong-length sample and a busy sample placed inside / between the runs, and the ring wrapping."""
+@pytest.mark.parametrize("pool", [None, 3, 16])
+def test_bulk_drain_runs_of_plain_samples_split_over_threads(nf, O, pool):
+    """Runs of >= 32768 plain 144-byte samples take the multi-part path of nfagg_ringbuf_drain (each part verifies the headers of its
+    range; the run ends at the first header that is not "144 bytes, committed"): same result as the per-sample reader, with a
+    discarded sample, a wrong-length sample and a busy sample placed inside / between the runs, and the ring wrapping. pool: the
+    process's copy workers (csrc/nfagg_hostpool.h) as they are (none before the first nfagg_create: the caller copies alone), or
+    re-shaped to 3 / 16 unbound workers (nfagg_host_threads)."""
+    if pool is not None:
+        assert nf.host_threads(pool, -1) == pool
+        info = nf.host_info()
+        assert info["workers"] == pool and 1 <= info["parts"] <= pool + 1 and not info["bound"]
     rng = np.random.default_rng(5)
     n = 150_000
     recs = O.gen_stream(n, seed=21, n_keys=5000, variant=1)
