@@ -475,6 +475,9 @@ def rank_main(args):
             dst_t.copy_(src_t); torch.cuda.synchronize()
             ev0.record(); dst_t.copy_(src_t); ev1.record(); torch.cuda.synchronize()
             out["roofline"]["hbm_copy_measured_GBs"] = round(2 * nb / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
+            if out["roofline"].get("traffic"):
+                # the counter traffic of the call against what this chip moves when it copies (mixed reads and writes), same run
+                out["roofline"]["traffic_over_measured_copy"] = round(out["roofline"]["traffic"] / out["roofline"]["hbm_copy_measured_GBs"], 4)
         except Exception as exc:                      # a diagnostic, never a reason to lose the bench line
             out["roofline"]["hbm_copy_measured_GBs"] = None
             out["roofline"]["hbm_copy_error"] = str(exc)[:100]

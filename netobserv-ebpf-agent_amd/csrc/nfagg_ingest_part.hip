@@ -234,7 +234,7 @@ NF_DEV uint32_t sub_shift_of(const SpillView& q) { return q.part_shift >= (uint3
 // staged four at a time in LDS so that a spill costs one 16-byte store and a quarter of an atomic.
 // ABL (libnfagg_diag.so only, ingest_variant 20..27: timing experiments, results are WRONG): bit 0 = spills are counted but not
 // queued, bit 1 = no fold into the cache entry, bit 2 = no cache claim (every record counts as a miss).
-template <bool SKETCH, bool TIMING, bool DOOR, int ABL = 0>
+template <bool SKETCH, bool TIMING, bool DOOR, int ABL = 0, bool DEEP = false>
 __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
                                                   uint64_t n, uint64_t seq_base) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -271,19 +271,10 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
     uint32_t carry = 0xffffffffu, carry_p = 0;                         // a spill that found its group full: retried next tile
     // Software pipeline: the records of tile k+1 are requested before tile k is folded, so no HBM latency is exposed inside
     // a tile. Loads are unconditional on a clamped index; `valid` only gates the fold.
-    bool valid; uint64_t i; Rec r;
-    {
-        const uint64_t pos = tile_first * kBlock + tid;
-        valid = pos < n; i = valid ? pos : 0;
-        load_record_head(recs, i, r);
-    }
-    for (uint64_t tile = tile_first; tile < tile_end; tile += tile_step) {
-        bool valid_n; uint64_t i_n; Rec r_n;
-        {
-            const uint64_t pos = (tile + tile_step) * kBlock + tid;
-            valid_n = pos < n; i_n = valid_n ? pos : 0;
-            load_record_head(recs, i_n, r_n);
-        }
+    // DEEP (experiment, round 5: libnfagg_diag.so ingest_variant 28): the records of tile k+2 are requested before tile k is folded —
+    // three record buffers in fixed roles, the loop unrolled by three so that no register copy waits for the youngest load; the
+    // seventh 16-byte unit shrinks to the one dword of it the fold reads (dscp) to stay inside 128 registers.
+    auto fold_tile = [&](Rec& r, bool valid, const uint64_t i) __attribute__((always_inline)) {
         uint64_t w[5];
         uint64_t h = 0;
         if (valid) {
@@ -334,11 +325,49 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
             }
         }
         if (TIMING) NF_TICK(5);
-        valid = valid_n; i = i_n;
-#pragma unroll
-        for (int k = 0; k < 28; k++) r.d[k] = r_n.d[k];
         // next tile: phase A touches only h64/key of NEW entries, the barrier after it orders phase B/C as before;
         // staging appends of this tile are drained after the next tile's first barrier
+    };
+    if (!DEEP) {
+        bool valid; uint64_t i; Rec r;
+        {
+            const uint64_t pos = tile_first * kBlock + tid;
+            valid = pos < n; i = valid ? pos : 0;
+            load_record_head(recs, i, r);
+        }
+        for (uint64_t tile = tile_first; tile < tile_end; tile += tile_step) {
+            bool valid_n; uint64_t i_n; Rec r_n;
+            {
+                const uint64_t pos = (tile + tile_step) * kBlock + tid;
+                valid_n = pos < n; i_n = valid_n ? pos : 0;
+                load_record_head(recs, i_n, r_n);
+            }
+            fold_tile(r, valid, i);
+            valid = valid_n; i = i_n;
+#pragma unroll
+            for (int k = 0; k < 28; k++) r.d[k] = r_n.d[k];
+        }
+    } else {
+        Rec ra, rb, rc; bool va, vb, vc; uint64_t ia, ib, ic;
+        auto request = [&](uint64_t tile_idx, Rec& rr, bool& vv, uint64_t& ii) __attribute__((always_inline)) {
+            const uint64_t pos = tile_idx * kBlock + tid;
+            vv = pos < n; ii = vv ? pos : 0;
+            const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + ii * kRecordBytes);
+#pragma unroll
+            for (int k = 0; k < 6; k++) { const uint4 v = p[k]; rr.d[4 * k] = v.x; rr.d[4 * k + 1] = v.y; rr.d[4 * k + 2] = v.z; rr.d[4 * k + 3] = v.w; }
+            rr.d[24] = reinterpret_cast<const uint32_t*>(p)[24];      // dscp; dwords 25..27 are not read by the fold
+        };
+        request(tile_first, ra, va, ia);
+        request(tile_first + tile_step, rb, vb, ib);
+        uint64_t tile = tile_first;
+        for (;;) {
+            if (tile >= tile_end) break;
+            request(tile + 2 * tile_step, rc, vc, ic); fold_tile(ra, va, ia); tile += tile_step;
+            if (tile >= tile_end) break;
+            request(tile + 2 * tile_step, ra, va, ia); fold_tile(rb, vb, ib); tile += tile_step;
+            if (tile >= tile_end) break;
+            request(tile + 2 * tile_step, rb, vb, ib); fold_tile(rc, vc, ic); tile += tile_step;
+        }
     }
     __syncthreads();
     if (carry != 0xffffffffu) {
@@ -645,7 +674,7 @@ __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView 
     if (direct) aadd(&t.ctr->n_direct, direct);
 }
 
-template <bool SKETCH, bool T1 = false, bool T2 = false, bool DOOR = true, int ABL = 0>
+template <bool SKETCH, bool T1 = false, bool T2 = false, bool DOOR = true, int ABL = 0, bool DEEP = false>
 static hipError_t run(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                       uint64_t seq_base, hipStream_t s) {
     const size_t lds1 = sizeof(Cache) + sizeof(Stage) + (DOOR ? sizeof(Door) : 0), lds2 = sizeof(Cache) + sizeof(Pass2Lds);
@@ -655,7 +684,7 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     (void)hipGetDevice(&dev_);
     std::atomic<bool>& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<SKETCH, T1, DOOR, ABL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<SKETCH, T1, DOOR, ABL, DEEP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<SKETCH, T2>),
@@ -671,7 +700,7 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     if (grid > 256) grid = 256;
     if (grid > tiles) grid = tiles;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_pass1<SKETCH, T1, DOOR, ABL>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
+    hipLaunchKernelGGL((k_pass1<SKETCH, T1, DOOR, ABL, DEEP>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_pass2<SKETCH, T2>), dim3(q.n_parts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
@@ -711,6 +740,7 @@ hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const Sp
         case 23: return part::run<false, false, false, true, 3>(tq, sk, q, d_records, n, seq_base, s);
         case 25: return part::run<false, false, false, true, 5>(tq, sk, q, d_records, n, seq_base, s);
         case 27: return part::run<false, false, false, true, 7>(tq, sk, q, d_records, n, seq_base, s);
+        case 28: return part::run<false, false, false, true, 0, true>(tq, sk, q, d_records, n, seq_base, s);   // experiment: records requested two tiles ahead (results RIGHT)
         default: break;
     }
 #endif
