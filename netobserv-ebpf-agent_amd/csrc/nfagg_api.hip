@@ -170,6 +170,16 @@ int fail(nfagg_handle* h, int code, const char* fmt, ...) {
             return fail((h), NFAGG_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// ... with something to do before the error is reported (a second stream to join)
+#define HIP_TRY_DO(h, expr, cleanup)                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            cleanup;                                                                          \
+            return fail((h), NFAGG_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        }                                                                                     \
+    } while (0)
+
 uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 
 // --- profiling: HIP events on the handle's stream around the dominant kernels
@@ -1654,15 +1664,17 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
         int rc_helper = NFAGG_OK, rc_helper2 = NFAGG_OK;
         std::thread helper, helper2;                            // one brings chunk k-1's evictions down (pageable output), one sends chunk k+1 up
         const bool down = !pinned_out && prev.has && prev.got != 0;
-        if (down) helper = std::thread([&] { (void)hipSetDevice(h->device); rc_helper = bring_down(); });
+        // (a thread that cannot be created must not throw through the C boundary: its job is done here and now instead)
+        auto spawn = [](std::thread& t, auto fn) { try { t = std::thread(fn); } catch (...) { fn(); } };
+        if (down) spawn(helper, [&] { (void)hipSetDevice(h->device); rc_helper = bring_down(); });
         else prev.has = false;
-        if (more) helper2 = std::thread([&] { (void)hipSetDevice(h->device); rc_helper2 = stage(b ^ 1, lo + m); });
+        if (more) spawn(helper2, [&] { (void)hipSetDevice(h->device); rc_helper2 = stage(b ^ 1, lo + m); });
         NF_DIAG_T(t_a);
         rc = account_device_core(h, h->d_stage[b], m, *dbuf, room, epoch_end + n_ep, max_epochs - n_ep, &e, &c);
         NF_DIAG_T(t_b);
-        if (down) helper.join();
+        if (helper.joinable()) helper.join();
         NF_DIAG_T(t_c);
-        if (more) helper2.join();
+        if (helper2.joinable()) helper2.join();
         NF_DIAG_T(t_d);
         NF_DIAG_PRINT("[account] chunk at %zu: %zu records, core %.2f ms (%zu evictions), wait down %.2f, wait up %.2f\n", lo, m, t_b - t_a, e, t_c - t_b, t_d - t_c);
         if (rc_helper == NFAGG_OK) rc_helper = rc_helper2;

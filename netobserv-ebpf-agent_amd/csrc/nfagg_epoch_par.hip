@@ -163,11 +163,11 @@ NF_DEV uint32_t wave_scan_u32(uint32_t v) {
 // block: from the epoch's first record s on, the records that start a new flow in it — prev < s; in the first epoch of the call:
 // prev == -1 (a flow the table holds, prev == -2, is no new entry) — are counted; the one that sees exactly `budget` new flows
 // before it (max_entries; less what is live, for the first epoch) finds the map full (account.go:85): it ends the epoch and opens
-// the next, which is walked over the SAME registers. A step is a block that is counted through or an epoch that ends: two
-// instructions per record (compare, add with carry), one DPP scan per wave, the 16 wave totals through LDS, one barrier — and a
+// the next, which is walked over the SAME registers. A step is a block that is counted through or an epoch that ends: one
+// vector compare per register and scalar counting of the lane masks (cut_block), the 16 wave totals through LDS, one barrier — and a
 // second one only when the epoch ends in the block (the lane that holds the cut tells the others). Records before s are dead for
 // good (s only grows): waves wholly before it skip their counting, the lane that holds s overwrites its dead records with "never new".
-// One CU evaluates 16 Ki records per step: the walk is bound by that arithmetic (~0.2 us per step), not by the 4 bytes per record.
+// One CU evaluates 16 Ki records per step: the walk is bound by the instructions of a step, not by the 4 bytes per record.
 // (Round 4's walk re-read every epoch from its first record on, 16 Ki records per step with a 256-entry scan by one lane: 5.8 us
 // per epoch, 3.2 ms per 8 M-record call with 557 epochs; this kernel's first form — six instructions per record, the blocks rotated
 // by register copies — 2.67 ms: profiles/r05_account_par_kernel_stats_first.csv.)
@@ -183,144 +183,253 @@ constexpr int32_t kCutNever = 0x7fffffff;
 // 16-byte load per row: an instruction covers 1 KiB of consecutive addresses — with 16 consecutive records per lane an instruction
 // touched 32 lines for 16 bytes each and every line four times: 1.48 ms per 8 M-record call against this layout's figure in §4.11b).
 constexpr int kCutRows = kCutPer / 4;
-NF_DEV void cut_load(const int32_t* __restrict__ prev, uint64_t n, uint64_t wave_base, int lane, int32_t v[kCutPer]) {
+// The loads are UNCONDITIONAL: prev[] is padded with kCutNever up to four blocks beyond the block that holds the call's last
+// record (par_prev_entries(); the host fills the pad). With a bounds branch around them the compiler closed every load with
+// s_waitcnt vmcnt(0) — nothing was in flight while a block was walked, and the walk was bound by four memory round trips per
+// block (1.32 ms per 8 M-record call, whatever its arithmetic: profiles/r05_cut_walk_latency.txt).
+NF_DEV void cut_load(const int32_t* __restrict__ prev, uint64_t wave_base, int lane, int32_t v[kCutPer]) {
 #pragma unroll
     for (int r = 0; r < kCutRows; r++) {
-        const uint64_t at = wave_base + (uint64_t)r * 256 + (uint64_t)lane * 4;
-        if (at + 4 <= n) {
-            const int4 x = *reinterpret_cast<const int4*>(prev + at);
-            v[4 * r] = x.x; v[4 * r + 1] = x.y; v[4 * r + 2] = x.z; v[4 * r + 3] = x.w;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; c++) v[4 * r + c] = at + c < n ? prev[at + c] : kCutNever;     // beyond the call: never new
-        }
+        const int4 x = *reinterpret_cast<const int4*>(prev + wave_base + (uint64_t)r * 256 + (uint64_t)lane * 4);
+        v[4 * r] = x.x; v[4 * r + 1] = x.y; v[4 * r + 2] = x.z; v[4 * r + 3] = x.w;
     }
+}
+
+NF_DEV void cut_arrived(const int32_t v[kCutPer]) {
+    asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+                       "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
 }
 
 struct CutState {
     uint32_t s, k, before, par, budget, max_entries, max_cuts;
     bool first;
+#ifdef NFAGG_DIAG
+    unsigned long long ph[8], tp;     // libnfagg_diag.so: cycles of wave 0 per phase (ctl[16..21], in Ki cycles): waiting for a block's loads,
+                                      // counting, barrier + totals, finding the cut + second barrier, bookkeeping of a cut, issuing loads
+#endif
 };
+#ifdef NFAGG_DIAG
+#define NF_CUT_TICK(k) do { const unsigned long long tn_ = __builtin_readcyclecounter(); st.ph[k] += tn_ - st.tp; st.tp = tn_; } while (0)
+#else
+#define NF_CUT_TICK(k)
+#endif
 
 // The epochs over one resident block (cur[]: this lane's records wave_base + 256 r + 4 lane + c). Returns when the block is
-// counted through or max_cuts are found. Record order inside the wave is row-major: the counts of a lane's four rows are scanned
-// as two packed words (16-bit fields: a row holds at most 256 new records).
-NF_DEV void cut_block(int32_t cur[kCutPer], uint32_t wave_base, CutState& st, uint32_t (*wtot)[kCutBlock / 64], uint32_t* fnd,
+// counted through or max_cuts are found. Record order inside the wave is row-major (row, lane, component).
+// The counting is SCALAR arithmetic on lane masks: one vector compare per register (16 per wave and step), its 64-bit result ANDed
+// with the row's live lanes (the groups of four wholly before s are dead) and counted by the scalar unit — the wave's total never
+// enters a vector register. (The first forms of this walk counted per lane — compare, add — and scanned the counts with DPP in every
+// step, ~135 vector instructions per wave and step on one compute unit: 1.32 ms per 8 M-record call, profiles/r05_cut_walk_counters.txt.)
+// Only the step that finds the epoch's end looks for a position, and only in the one wave and row that hold it.
+template <bool FIRST>
+NF_DEV bool cut_is_new(int32_t v, int32_t s32) { return FIRST ? v == -1 : v < s32; }
+
+// the new records of the wave's four rows, counted by the scalar unit from the compare masks (s: a scalar)
+template <bool FIRST>
+NF_DEV void cut_count(const int32_t cur[kCutPer], uint32_t wave_base, uint32_t s, uint32_t row_tot[kCutRows], uint64_t row_live[kCutRows]) {
+    const int32_t s32 = (int32_t)s;
+    if (s <= wave_base) {                                             // the usual case: the epoch began before this wave's records, all of them count
+        // (all sixteen compares first, each into scalar registers of its own: with one compare -> count pair after the other
+        // every pair waits for the vector pipeline to hand over VCC)
+        uint64_t m[kCutPer];
+#pragma unroll
+        for (int k = 0; k < kCutPer; k++) m[k] = __ballot(cut_is_new<FIRST>(cur[k], s32));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < kCutRows; r++) {
+            row_tot[r] = (uint32_t)(__popcll(m[4 * r]) + __popcll(m[4 * r + 1]) + __popcll(m[4 * r + 2]) + __popcll(m[4 * r + 3]));
+            row_live[r] = ~0ull;
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < kCutRows; r++) {
+        // lane l's four records of row r lie wholly before s when 4 l + 4 <= s - row_base (the four that hold s have their dead
+        // records overwritten when the cut is made)
+        const uint32_t row_base = wave_base + (uint32_t)r * 256;
+        const uint32_t dead = s > row_base ? (s - row_base) >> 2 : 0u;
+        const uint64_t livem = dead >= 64u ? 0ull : ~0ull << dead;
+        row_live[r] = livem;
+        uint32_t rc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) rc += (uint32_t)__popcll(__ballot(cut_is_new<FIRST>(cur[4 * r + q], s32)) & livem);
+        row_tot[r] = rc;
+    }
+}
+
+// the wave and row that hold new record number `target` (from 0, in record order) of the row: its index in the call
+template <bool FIRST>
+NF_DEV void cut_find(const int32_t cur[kCutPer], int r, uint32_t row_first, uint32_t s, uint64_t livem, uint32_t target, int lane, uint32_t* out) {
+    const int32_t s32 = (int32_t)s;
+    uint32_t cr = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) cr += cut_is_new<FIRST>(cur[4 * r + q], s32) ? 1u : 0u;
+    if (!((livem >> lane) & 1ull)) cr = 0;
+    const uint32_t incl = wave_scan_u32(cr);
+    const uint32_t need = target - (incl - cr);                       // which of this lane's new records of the row it is (wraps when it is elsewhere)
+    if (need < cr) {
+        uint32_t seen = 0, at = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (cut_is_new<FIRST>(cur[4 * r + q], s32)) { if (seen == need) at = (uint32_t)q; seen++; }
+        }
+        *out = row_first + (uint32_t)lane * 4 + at;
+    }
+}
+
+NF_DEV void cut_block(int32_t cur[kCutPer], uint32_t wave_base_v, CutState& st, uint32_t (*wtot)[kCutBlock / 64], uint32_t* fnd,
                       uint32_t* __restrict__ cuts) {
     constexpr int kWaves = kCutBlock / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // everything the steps decide on is the same in every lane of a wave: kept in scalar registers, so that the masks are counted
+    // and the branches taken by the scalar unit
+    const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_base_v);
     const uint32_t lane_base = wave_base + (uint32_t)lane * 4;        // first record of this lane's row 0
-    const int wv_u = __builtin_amdgcn_readfirstlane(wv);              // (wave-uniform: a scalar)
+    const int wv_u = __builtin_amdgcn_readfirstlane(wv);
     while (st.k < st.max_cuts) {
-        uint32_t c[kCutRows] = {0, 0, 0, 0};
-        if (wave_base + 64u * kCutPer > st.s) {                       // (wave-uniform) some record of this wave is at or after s
-            const int32_t s32 = (int32_t)st.s;
-#pragma unroll
-            for (int r = 0; r < kCutRows; r++) {
-                uint32_t cr = 0;
-                if (st.first) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) cr += cur[4 * r + q] == -1 ? 1u : 0u;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) cr += cur[4 * r + q] < s32 ? 1u : 0u;
-                }
-                // four records wholly before s (the four that hold s have their dead records overwritten)
-                c[r] = lane_base + (uint32_t)r * 256 + 4 <= st.s ? 0u : cr;
-            }
+        uint32_t row_tot[kCutRows] = {0, 0, 0, 0};
+        uint64_t row_live[kCutRows] = {0, 0, 0, 0};
+        const uint32_t s_u = st.s;
+        const bool first_u = st.first;
+        if (wave_base + 64u * kCutPer > s_u) {                        // some record of this wave is at or after s
+            if (first_u) cut_count<true>(cur, wave_base, s_u, row_tot, row_live);
+            else cut_count<false>(cur, wave_base, s_u, row_tot, row_live);
         }
-        const uint32_t i01 = wave_scan_u32(c[0] | (c[1] << 16)), i23 = wave_scan_u32(c[2] | (c[3] << 16));
-        const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane((int)i01, 63), t23 = (uint32_t)__builtin_amdgcn_readlane((int)i23, 63);
-        const uint32_t row_tot[kCutRows] = {t01 & 0xffffu, t01 >> 16, t23 & 0xffffu, t23 >> 16};
-        const uint32_t incl[kCutRows] = {i01 & 0xffffu, i01 >> 16, i23 & 0xffffu, i23 >> 16};
-        if (lane == 0) wtot[st.par][wv] = row_tot[0] + row_tot[1] + row_tot[2] + row_tot[3];
+        const uint32_t wave_total = row_tot[0] + row_tot[1] + row_tot[2] + row_tot[3];
+        NF_CUT_TICK(1);
+        if (lane == 0) wtot[st.par][wv] = wave_total;
         __syncthreads();
-        // the 16 wave totals: one LDS read per lane and a scan inside the first row of 16 lanes (reading all 16 in every lane and
-        // adding them up was 48 of the 135 vector instructions a wave spends per step — and the walk is bound by exactly those:
-        // one CU, its four SIMDs ~65 % busy with them, profiles/r05_cut_walk_counters.txt)
+        NF_CUT_TICK(6);
+        // the 16 wave totals: one LDS read per lane and a scan inside the first row of 16 lanes
         uint32_t pre = lane < kWaves ? wtot[st.par][lane] : 0u;
         pre = dpp_add_u32<0x111, 0xf>(pre); pre = dpp_add_u32<0x112, 0xf>(pre); pre = dpp_add_u32<0x114, 0xf>(pre); pre = dpp_add_u32<0x118, 0xf>(pre);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)pre, kWaves - 1);
         const uint32_t woff = wv_u ? (uint32_t)__builtin_amdgcn_readlane((int)pre, wv_u - 1) : 0u;
+        NF_CUT_TICK(2);
         if (st.before + total <= st.budget) {                         // the epoch goes on beyond this block
             st.before += total;
             st.par ^= 1u;
             return;
         }
-        // entry number budget + 1 is in this block: exactly one (lane, row) holds it
-        uint32_t row_off = st.before + woff;                          // new flows of the epoch before this wave's row r
+        // entry number budget + 1 is in this block: new record number `target` (from 0) of exactly one wave — the others see a
+        // number beyond their total (before it: not reached; after it: the subtraction wraps)
+        uint32_t target = st.budget - st.before - woff;
+        if (target < wave_total) {
 #pragma unroll
-        for (int r = 0; r < kCutRows; r++) {
-            const uint32_t need = st.budget - (row_off + incl[r] - c[r]);   // which of this lane's new records of the row it is (wraps when it is elsewhere)
-            if (need < c[r]) {
-                uint32_t seen = 0, at = 0;
-                const int32_t s32 = (int32_t)st.s;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const bool is_new = st.first ? cur[4 * r + q] == -1 : cur[4 * r + q] < s32;
-                    if (is_new) { if (seen == need) at = (uint32_t)q; seen++; }
+            for (int r = 0; r < kCutRows; r++) {
+                if (target < row_tot[r]) {                            // ... of exactly one row of it
+                    if (first_u) cut_find<true>(cur, r, wave_base + (uint32_t)r * 256, s_u, row_live[r], target, lane, &fnd[st.par]);
+                    else cut_find<false>(cur, r, wave_base + (uint32_t)r * 256, s_u, row_live[r], target, lane, &fnd[st.par]);
+                    target = 0xffffffffu;                             // found: no later row
+                } else {
+                    target -= row_tot[r];
                 }
-                fnd[st.par] = lane_base + (uint32_t)r * 256 + at;
             }
-            row_off += row_tot[r];
         }
         __syncthreads();
-        const uint32_t f = fnd[st.par];
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)fnd[st.par]);   // (the same in every lane: kept scalar, like all of st)
+        NF_CUT_TICK(3);
         if (tid == 0) cuts[st.k] = f;
         st.k++; st.s = f; st.before = 0; st.first = false; st.budget = st.max_entries;   // the next epoch is walked over the same block
         st.par ^= 1u;
+        if (f - wave_base < 64u * kCutPer) {                          // (scalar) this wave holds the new s ...
 #pragma unroll
-        for (int r = 0; r < kCutRows; r++) {                          // the four records that hold the new s: those before it never count again
-            const uint32_t b4 = lane_base + (uint32_t)r * 256;
-            if (f >= b4 && f < b4 + 4) {
+            for (int r = 0; r < kCutRows; r++) {
+                if ((f - wave_base) >> 8 == (uint32_t)r) {            // (scalar) ... in this row: of the four records around it, those before it never count again
+                    const uint32_t b4 = lane_base + (uint32_t)r * 256;
+                    if (f >= b4 && f < b4 + 4) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) if (b4 + (uint32_t)q < f) cur[4 * r + q] = kCutNever;
+                        for (int q = 0; q < 4; q++) if (b4 + (uint32_t)q < f) cur[4 * r + q] = kCutNever;
+                    }
+                }
             }
         }
+        NF_CUT_TICK(4);
     }
 }
 
+// The walk is RESUMABLE: a launch covers the blocks [b_begin, b_end) and leaves its state (the epoch in progress: where it began,
+// how many new flows it has seen, which cut comes next) in ctl[8..12]; a launch with b_begin > 0 picks it up. The host runs the walk
+// in a few such parts and hands the epochs each part has completed to the segment folds while the next part walks on: the walk
+// keeps ONE compute unit busy, the folds the other 255 (nfagg_account_par.inc). Nothing else changes: a block boundary is an
+// ordinary place for an epoch to go on across (the records of a block before the epoch's start were dead anyway).
 __global__ __launch_bounds__(kCutBlock) void k_par_cuts(const int32_t* __restrict__ prev, uint64_t n, uint32_t max_entries, uint32_t live0,
-                                                        uint32_t* __restrict__ cuts, uint32_t max_cuts, uint32_t* __restrict__ ctl) {
+                                                        uint32_t* __restrict__ cuts, uint32_t max_cuts, uint32_t* __restrict__ ctl,
+                                                        uint64_t b_begin, uint64_t b_end) {
     __shared__ uint32_t wtot[2][kCutBlock / 64];                      // double-buffered by step parity: one barrier per step
     __shared__ uint32_t fnd[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint64_t n_blocks = (n + kCutSpan - 1) / kCutSpan;
+    // the walk is what the rest of the launch waits for, and waves of the segment folds may share this compute unit: its
+    // instructions go first
+    __builtin_amdgcn_s_setprio(3);
     CutState st;
-    st.s = 0; st.k = 0; st.before = 0; st.par = 0; st.first = true;   // the first epoch: the one the table's live flows belong to (it may end at record 0)
-    st.budget = live0 >= max_entries ? 0u : max_entries - live0;
+    st.par = 0;
+    if (b_begin == 0) {
+        st.s = 0; st.k = 0; st.before = 0; st.first = true;           // the first epoch: the one the table's live flows belong to (it may end at record 0)
+        st.budget = live0 >= max_entries ? 0u : max_entries - live0;
+    } else {                                                          // (read by every lane before lane 0 rewrites them behind the walk's barriers)
+        st.s = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[8]); st.k = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[9]);
+        st.before = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[10]); st.first = __builtin_amdgcn_readfirstlane((int)ctl[11]) != 0;
+        st.budget = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[12]);
+    }
     st.max_entries = max_entries; st.max_cuts = max_cuts;
+#ifdef NFAGG_DIAG
+    for (int k = 0; k < 8; k++) st.ph[k] = 0;
+    st.tp = __builtin_readcyclecounter();
+#endif
+    __syncthreads();
     const uint64_t wave_off = (uint64_t)wv * 64u * kCutPer;          // this wave's first record, relative to the block
     int32_t A[kCutPer], B[kCutPer], C[kCutPer], D[kCutPer];
-    cut_load(prev, n, wave_off, lane, A);
-    cut_load(prev, n, kCutSpan + wave_off, lane, B);
-    cut_load(prev, n, 2 * kCutSpan + wave_off, lane, C);
-    cut_load(prev, n, 3 * kCutSpan + wave_off, lane, D);
+    // b_end - b_begin is a multiple of four (the host cuts the parts so; prev[] is padded with "never new" to a multiple of four
+    // blocks and four more): the loop body has no branch around a load, and the loads are issued in the order their registers are
+    // used in — what the compiler needs to let twelve of them fly while the oldest four are worked on.
+    cut_load(prev, b_begin * kCutSpan + wave_off, lane, A);
+    __builtin_amdgcn_sched_barrier(0);
+    cut_load(prev, (b_begin + 1) * kCutSpan + wave_off, lane, B);
+    __builtin_amdgcn_sched_barrier(0);
+    cut_load(prev, (b_begin + 2) * kCutSpan + wave_off, lane, C);
+    __builtin_amdgcn_sched_barrier(0);
+    cut_load(prev, (b_begin + 3) * kCutSpan + wave_off, lane, D);
+    __builtin_amdgcn_sched_barrier(0);
+    // cut_arrived: an empty statement that READS the block's registers, outside any loop: the compiler waits there for exactly
+    // these sixteen (vmcnt(12): the twelve younger loads stay in flight). Without it the first use is inside cut_block's loop,
+    // and the compiler drains every load before a loop that reads loaded registers (vmcnt(0) in the loop's preheader).
 #define NF_CUT_BLOCK(BUF, BIDX)                                                                                                      \
-    if ((BIDX) < n_blocks && st.k < st.max_cuts) {                                                                                   \
-        cut_block(BUF, (uint32_t)((BIDX) * kCutSpan + wave_off), st, wtot, fnd, cuts);                                               \
-        cut_load(prev, n, ((BIDX) + 4) * kCutSpan + wave_off, lane, BUF);                                                            \
-    }
-    for (uint64_t b0 = 0; b0 < n_blocks && st.k < st.max_cuts; b0 += 4) {
+    cut_arrived(BUF);                                                                                                                \
+    NF_CUT_TICK(0);                                                                                                                  \
+    cut_block(BUF, (uint32_t)((BIDX) * kCutSpan + wave_off), st, wtot, fnd, cuts);                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                               \
+    cut_load(prev, ((BIDX) + 4) * kCutSpan + wave_off, lane, BUF);                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                               \
+    NF_CUT_TICK(5);
+    for (uint64_t b0 = b_begin; b0 < b_end && st.k < st.max_cuts; b0 += 4) {
         NF_CUT_BLOCK(A, b0)
         NF_CUT_BLOCK(B, b0 + 1)
         NF_CUT_BLOCK(C, b0 + 2)
         NF_CUT_BLOCK(D, b0 + 3)
     }
 #undef NF_CUT_BLOCK
-    if (tid == 0) { ctl[0] = st.k; ctl[3] = st.before; }
+#ifdef NFAGG_DIAG
+    if (tid == 0) for (int k = 0; k < 8; k++) atomicAdd(&ctl[16 + k], (uint32_t)(st.ph[k] >> 10));
+    if (tid == kCutBlock - 64) for (int k = 0; k < 8; k++) atomicAdd(&ctl[24 + k], (uint32_t)(st.ph[k] >> 10));
+#endif
+    if (tid == 0) {
+        ctl[0] = st.k; ctl[3] = st.before;
+        ctl[8] = st.s; ctl[9] = st.k; ctl[10] = st.before; ctl[11] = st.first ? 1u : 0u; ctl[12] = st.budget;
+    }
 }
 
 // One workgroup per complete epoch t of the middle: records [cuts[t], cuts[t + 1]). pos[i] = t * max_entries + the number of new
 // flows of the epoch before record i, for the records that start one (prev < the epoch's first record); kParNone for the others.
+// A launch ranks the epochs [t_lo, t_hi): the ones a part of the walk has just completed.
 // The eviction of the epoch is what the records with a position fold to, in that order (Go's map order is random: any order is
 // the reference's). Every such epoch holds exactly max_entries new flows — that is how its end was found: *bad otherwise.
-__global__ __launch_bounds__(kParBlock) void k_par_rank(const int32_t* __restrict__ prev, const uint32_t* __restrict__ cuts, uint32_t n_mid,
+__global__ __launch_bounds__(kParBlock) void k_par_rank(const int32_t* __restrict__ prev, const uint32_t* __restrict__ cuts, uint32_t t_lo, uint32_t t_hi,
                                                         uint32_t max_entries, uint32_t* __restrict__ pos, uint32_t* __restrict__ bad) {
     constexpr int kWaves = kParBlock / 64;
     __shared__ uint32_t wcnt[2][kWaves];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (uint32_t t = blockIdx.x; t < n_mid; t += gridDim.x) {
+    for (uint32_t t = t_lo + blockIdx.x; t < t_hi; t += gridDim.x) {
         const uint32_t s = cuts[t], e = cuts[t + 1];
         uint32_t running = 0, par = 0;
         for (uint32_t base = s; base < e; base += kParBlock) {
@@ -378,17 +487,20 @@ NF_DEV void store_record(void* base, uint64_t i, const Rec& r) {
 // from p up to (not including) the first whose sort key reaches (hash bits, first record of the next epoch) — the array is sorted
 // by (hash bits, index), so that is where the flow's records of this epoch end — less the records of other flows with the same
 // hash bits (full keys compared). Up to kSegShort positions: folded here, in arrival order, exactly as account.go:82-95 does;
-// longer ones are listed for k_par_segfold_long.
-// mid_base: pos[] counts from the first middle epoch, whose cut is cuts[0].
+// longer ones are listed for k_par_segfold_long. A launch folds the epochs whose records are [i_lo, i_hi) (cut to cut): the ones
+// k_par_rank has just given positions.
+// pos[] counts from the first middle epoch, whose cut is cuts[0].
 template <bool SKETCH>
 __global__ __launch_bounds__(kParBlock) void k_par_segfold(const void* __restrict__ recs, const uint64_t* __restrict__ ks, uint64_t n,
                                                            const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cuts,
                                                            uint32_t max_entries, SketchView sk, void* __restrict__ out,
-                                                           uint32_t* __restrict__ long_list, uint32_t* __restrict__ n_long) {
+                                                           uint32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
+                                                           uint32_t i_lo, uint32_t i_hi) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const uint64_t key = ks[p];
     const uint32_t i = key_index(key);
+    if (i < i_lo || i >= i_hi) return;                                // not a record of the epochs this launch folds (pos[] holds nothing for it, or an earlier launch's)
     const uint32_t ps = pos[i];
     if (ps == kParNone) return;
     const uint64_t limit = (key & kHashMask) | (uint64_t)cuts[ps / max_entries + 1];     // (hash bits, end of the epoch)
@@ -554,27 +666,38 @@ hipError_t launch_par_live(const TableView& t, const void* d_records, int32_t* d
     return hipGetLastError();
 }
 
+// The walk over the blocks [b_begin, b_end) of par_cut_span() records each (k_par_cuts: b_begin > 0 resumes from the state in d_ctl);
+// b_end - b_begin: a multiple of four, b_end <= par_walk_blocks(n).
 hipError_t launch_par_cuts(const int32_t* d_prev, uint64_t n, uint32_t max_entries, uint32_t live0, uint32_t* d_cuts, uint32_t max_cuts,
-                           uint32_t* d_ctl, hipStream_t s) {
+                           uint32_t* d_ctl, uint64_t b_begin, uint64_t b_end, hipStream_t s) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_par_cuts, dim3(1), dim3(kCutBlock), 0, s, d_prev, n, max_entries, live0, d_cuts, max_cuts, d_ctl);
+    hipLaunchKernelGGL(k_par_cuts, dim3(1), dim3(kCutBlock), 0, s, d_prev, n, max_entries, live0, d_cuts, max_cuts, d_ctl, b_begin, b_end);
     return hipGetLastError();
 }
+uint64_t par_cut_span() { return kCutSpan; }
+// entries of prev[] for a launch of n records: its blocks (a multiple of four) and the four the walk requests ahead (cut_load);
+// [n, this) = kCutNever
+uint64_t par_walk_blocks(uint64_t n) { return (((n + kCutSpan - 1) / kCutSpan + 3) / 4) * 4; }     // the walk takes its blocks four at a time
+uint64_t par_prev_entries(uint64_t n) { return (par_walk_blocks(n) + 4) * kCutSpan; }
+int32_t par_prev_pad_value() { return kCutNever; }
 
-// The middle epochs of a walk that found n_cuts cuts: positions, then both folds. d_out: where the first middle epoch's eviction
-// begins. d_long: room for n / kSegShort + 1 positions; d_n_long / d_bad: zero on entry.
+// The complete epochs [t_lo, t_hi) of the middle (epoch t = records [cuts[t], cuts[t + 1]); i_lo = cuts[t_lo], i_hi = cuts[t_hi]):
+// positions, then both folds. d_out: where the FIRST middle epoch's eviction begins (epoch t goes to d_out + t * max_entries records).
+// d_long: room for n / kSegShort + 1 positions; *d_n_long is zeroed here (in stream order); *d_bad accumulates.
 hipError_t launch_par_middle(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, const int32_t* d_prev, const uint32_t* d_cuts,
-                             uint32_t n_cuts, uint32_t max_entries, const SketchView& sk, uint32_t* d_pos, void* d_out, uint32_t* d_long,
-                             uint32_t* d_n_long, uint32_t* d_bad, hipStream_t s) {
-    if (n_cuts < 2) return hipSuccess;
-    const uint32_t n_mid = n_cuts - 1;
+                             uint32_t t_lo, uint32_t t_hi, uint32_t i_lo, uint32_t i_hi, uint32_t max_entries, const SketchView& sk, uint32_t* d_pos,
+                             void* d_out, uint32_t* d_long, uint32_t* d_n_long, uint32_t* d_bad, hipStream_t s) {
+    if (t_hi <= t_lo) return hipSuccess;
+    const uint32_t n_mid = t_hi - t_lo;
+    hipError_t e = hipMemsetAsync(d_n_long, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_par_rank, dim3(n_mid < 65535u ? n_mid : 65535u), dim3(kParBlock), 0, s, d_prev, d_cuts, n_mid, max_entries, d_pos, d_bad);
+    hipLaunchKernelGGL(k_par_rank, dim3(n_mid < 65535u ? n_mid : 65535u), dim3(kParBlock), 0, s, d_prev, d_cuts, t_lo, t_hi, max_entries, d_pos, d_bad);
     if (sk.flags) {
-        hipLaunchKernelGGL(k_par_segfold<true>, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, d_long, d_n_long);
+        hipLaunchKernelGGL(k_par_segfold<true>, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, d_long, d_n_long, i_lo, i_hi);
         hipLaunchKernelGGL(k_par_segfold_long<true>, dim3(2048), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_long, (const uint32_t*)d_n_long);
     } else {
-        hipLaunchKernelGGL(k_par_segfold<false>, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, d_long, d_n_long);
+        hipLaunchKernelGGL(k_par_segfold<false>, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, d_long, d_n_long, i_lo, i_hi);
         hipLaunchKernelGGL(k_par_segfold_long<false>, dim3(2048), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_long, (const uint32_t*)d_n_long);
     }
     return hipGetLastError();

@@ -165,10 +165,14 @@ hipError_t launch_par_sort(void* temp, size_t* temp_bytes, const uint64_t* k_in,
 hipError_t launch_par_links(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, int32_t* d_prev, uint32_t* d_overflow, hipStream_t s);
 hipError_t launch_par_live(const TableView& t, const void* d_records, int32_t* d_prev, uint64_t n, hipStream_t s);
 hipError_t launch_par_cuts(const int32_t* d_prev, uint64_t n, uint32_t max_entries, uint32_t live0, uint32_t* d_cuts, uint32_t max_cuts,
-                           uint32_t* d_ctl, hipStream_t s);
+                           uint32_t* d_ctl, uint64_t b_begin, uint64_t b_end, hipStream_t s);
+uint64_t par_cut_span();
+uint64_t par_walk_blocks(uint64_t n);
+uint64_t par_prev_entries(uint64_t n);
+int32_t par_prev_pad_value();
 hipError_t launch_par_middle(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, const int32_t* d_prev, const uint32_t* d_cuts,
-                             uint32_t n_cuts, uint32_t max_entries, const SketchView& sk, uint32_t* d_pos, void* d_out, uint32_t* d_long,
-                             uint32_t* d_n_long, uint32_t* d_bad, hipStream_t s);
+                             uint32_t t_lo, uint32_t t_hi, uint32_t i_lo, uint32_t i_hi, uint32_t max_entries, const SketchView& sk, uint32_t* d_pos,
+                             void* d_out, uint32_t* d_long, uint32_t* d_n_long, uint32_t* d_bad, hipStream_t s);
 uint32_t par_seg_short();
 // Kernel-dedup mode: nfagg_dedup.hip (direct: a claim pass, then a fold pass) / nfagg_dedup_cached.hip (one streaming pass + partitions).
 hipError_t launch_ingest_dedup(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);

@@ -53,10 +53,11 @@ def _colliding_keys(rng, k):
 
 @pytest.mark.parametrize("variant", [0, 30])
 @pytest.mark.parametrize("max_entries,keys,n", [(5000, 100_000, 600_000), (100, 3_000, 150_000), (2, 50, 80_000), (20_000, 400_000, 900_000),
-                                                 (5000, 4_000, 300_000), (1, 40, 70_000), (3, 200, 300_000)])
+                                                 (5000, 4_000, 300_000), (1, 40, 70_000), (3, 200, 300_000), (5000, 1_000_000, 3_000_000)])
 def test_epochs_found_first_equal_the_reference_loop(nf, O, max_entries, keys, n, variant):
     """Epochs of 2 records to epochs longer than a 16 Ki-record block of the cut walk; more cuts than one launch lists (65 535);
-    a map that never fills."""
+    a map that never fills; walks in one part (below 512 Ki records) and in two to four (the epochs a part completes are folded
+    while the next part walks on)."""
     if variant == 30 and n > 200_000 and max_entries < 100:
         pytest.skip("the chain takes 30 us per epoch: covered at smaller sizes by test_account_gpu.py")
     recs = _stream(O, n, keys, seed=7 + max_entries)

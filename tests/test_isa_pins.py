@@ -89,3 +89,22 @@ def test_no_record_address_is_formed_from_an_unmasked_sort_key(disassembly):
                     hits.append((cur[:60], prev, ins))
         window.append(ins)
     assert not hits, hits[:3]
+
+
+def test_the_cut_walk_keeps_twelve_loads_in_flight(disassembly):
+    """Round 5: the walk was bound by memory round trips, not by its arithmetic — a bounds branch around its loads made the compiler
+    close every one of them with s_waitcnt vmcnt(0), and once that was gone it drained all loads before the loop that first reads
+    them (profiles/r05_cut_walk_latency.txt). The kernel now waits for the sixteen registers of the block it walks and for nothing
+    younger: vmcnt(12), four times (once per register set), and no vmcnt(0) anywhere in it."""
+    cur, waits = None, {}
+    for line in disassembly.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line.strip())
+        if m:
+            cur = m.group(1)
+            continue
+        if cur and "k_par_cuts" in cur:
+            m = re.search(r"s_waitcnt\s+(.*?)\s*//", line)
+            if m and "vmcnt" in m.group(1):
+                n = int(re.search(r"vmcnt\((\d+)\)", m.group(1)).group(1))
+                waits[n] = waits.get(n, 0) + 1
+    assert waits.get(12, 0) == 4 and 0 not in waits, "k_par_cuts waits on its loads as %r (wanted: vmcnt(12) x 4, no vmcnt(0))" % waits
