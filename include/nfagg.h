@@ -419,7 +419,7 @@ int nfagg_evict_device(nfagg_handle* h, int reason, void* d_out, size_t cap, siz
  * drain `out`, then call again with the rest (a pending eviction is delivered first).
  * With a small CACHE_MAX_FLOWS (the reference ships 5000, pkg/config/config.go:146) the stream stops on "full" every few
  * thousand records; here that whole loop runs on the device (max_entries <= 32768, NFAGG_MODE_ACCOUNTER). A call of more than a few
- * epochs (n >= 4 * max_entries + 65536) has its epochs FOUND FIRST (csrc/nfagg_epoch_par.hip, DESIGN.md §4.11): previous-occurrence
+ * epochs (n >= 4 * max_entries + 65536) has its epochs FOUND FIRST (csrc/nfagg_epoch_par.hip, DESIGN.md §4.11b): previous-occurrence
  * links from one sort of (key hash, index) keys, one prefix count per epoch — WHERE the loop of account.go:81-96 evicts does not
  * need the map — and every complete epoch is then folded on its own, all of them at once, each flow's records gathered in arrival
  * order and folded as flow_content.go:28-61 folds them, straight into `out`; only the call's first epoch (it continues what the
