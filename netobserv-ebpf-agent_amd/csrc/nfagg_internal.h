@@ -158,7 +158,8 @@ bool ingest_needs_spill(int mode, int variant, uint64_t n);
 hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                               uint64_t seq_base, int variant, hipStream_t s);
 // nfagg_epoch_par.hip / nfagg_account_par.inc: the evict-on-full loop of nfagg_account with its epochs found first — sort keys
-// ((hash bits) << 32 | index), their sort, previous-occurrence links, live flags, the cut walk; then the complete epochs of the
+// ((top 40 hash bits) << 24 | index), their sort, previous-occurrence links, live flags, the cut walk (resumable: run in parts);
+// then the complete epochs of the
 // middle: positions and segment folds (no table)
 hipError_t launch_par_hash(const void* d_records, uint64_t n, uint64_t* d_keys, hipStream_t s);
 hipError_t launch_par_sort(void* temp, size_t* temp_bytes, const uint64_t* k_in, uint64_t* k_out, uint64_t n, hipStream_t s);
