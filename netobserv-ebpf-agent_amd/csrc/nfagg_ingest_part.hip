@@ -132,6 +132,99 @@ NF_DEV int cache_fold(Cache& L, int ent, const Rec& r, const uint64_t w[5], uint
     return ent;
 }
 
+#ifdef NFAGG_DIAG
+// ---- experiment (libnfagg_diag.so, ingest_variant 24; results RIGHT): a wave's duplicates combined BEFORE the LDS atomics ----------
+// The round-2/3/4 reviews asked for this to be built and measured instead of estimated (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+// is 56 % in pass 1: 64 lanes hit a hash-indexed cache, and ~5 lanes of every wave fold into the hottest flow). One group per
+// wave and tile: the entries of lanes 0, 16, 32 and 48 are candidates, the one most lanes share wins; its lanes' contributions
+// are reduced across the wave with DPP (row shifts + row broadcasts, identities elsewhere), ONE lane performs the entry's
+// atomics with the totals, the others of the group skip theirs. Everything else takes cache_fold as before.
+// Result: profiles/r05x_wave_combining.txt.
+template <int CTRL, int ROW_MASK>
+NF_DEV uint32_t comb_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true); }
+template <int CTRL, int ROW_MASK>
+NF_DEV uint64_t comb_dpp64(uint64_t v) { return (uint64_t)comb_dpp<CTRL, ROW_MASK>((uint32_t)v) | ((uint64_t)comb_dpp<CTRL, ROW_MASK>((uint32_t)(v >> 32)) << 32); }
+#define NF_COMB_STEPS(OP, T, F)                                                                              \
+    v = OP(v, F<0x111, 0xf>(v)); v = OP(v, F<0x112, 0xf>(v)); v = OP(v, F<0x114, 0xf>(v)); v = OP(v, F<0x118, 0xf>(v)); \
+    v = OP(v, F<0x142, 0xa>(v)); v = OP(v, F<0x143, 0xc>(v));
+NF_DEV uint32_t comb_add32(uint32_t a, uint32_t b) { return a + b; }
+NF_DEV uint32_t comb_or32(uint32_t a, uint32_t b) { return a | b; }
+NF_DEV uint32_t comb_max32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+NF_DEV uint64_t comb_add64(uint64_t a, uint64_t b) { return a + b; }
+NF_DEV uint64_t comb_max64(uint64_t a, uint64_t b) { return a > b ? a : b; }
+// the wave's total (lane 63 holds it after the steps; every lane must be active)
+NF_DEV uint32_t wave_add32(uint32_t v) { NF_COMB_STEPS(comb_add32, uint32_t, comb_dpp) return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+NF_DEV uint32_t wave_or32(uint32_t v) { NF_COMB_STEPS(comb_or32, uint32_t, comb_dpp) return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+NF_DEV uint32_t wave_max32(uint32_t v) { NF_COMB_STEPS(comb_max32, uint32_t, comb_dpp) return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+NF_DEV uint64_t wave_add64(uint64_t v) {
+    NF_COMB_STEPS(comb_add64, uint64_t, comb_dpp64)
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63) << 32);
+}
+NF_DEV uint64_t wave_max64(uint64_t v) {
+    NF_COMB_STEPS(comb_max64, uint64_t, comb_dpp64)
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63) << 32);
+}
+#undef NF_COMB_STEPS
+
+// phase B for a whole wave (every lane calls it: `valid` lanes with ent >= 0 take part). Returns the lane's entry, -1 for a
+// key mismatch (as cache_fold).
+NF_DEV int cache_fold_combined(Cache& L, bool valid, int ent, const Rec& r, const uint64_t w[5], uint32_t seq32) {
+    const int lane = threadIdx.x & 63;
+    bool active = valid && ent >= 0;
+    if (active) {
+        const uint4 a = L.k0[ent], b = L.k1[ent], c = L.k2[ent];
+        active = ((u64hi(a) ^ w[0]) | (u64lo(b) ^ w[1]) | (u64hi(b) ^ w[2]) | (u64lo(c) ^ w[3]) | (u64hi(c) ^ w[4])) == 0;
+        if (!active) ent = -1;
+    }
+    const int mine = active ? ent : -1;
+    // the group: of the entries of four sample lanes the one most lanes share
+    int best_e = -1;
+    unsigned long long best_g = 0;
+#pragma unroll
+    for (int s = 0; s < 64; s += 16) {
+        const int e = __builtin_amdgcn_readlane(mine, s);
+        if (e >= 0) {
+            const unsigned long long g = __ballot(mine == e);
+            if (__popcll(g) > __popcll(best_g)) { best_g = g; best_e = e; }
+        }
+    }
+    const bool grouped = __popcll(best_g) >= 2;                       // (wave-uniform)
+    const bool member = grouped && mine == best_e;
+    if (grouped) {
+        const uint64_t s1 = (uint64_t)seq32 + 1;
+        const uint64_t bytes = wave_add64(member ? r.bytes() : 0ull);
+        const uint32_t packets = wave_add32(member ? r.packets() : 0u);
+        const uint32_t flags = wave_or32(member ? r.flags() : 0u);
+        const uint64_t end = wave_max64(member ? r.end() : 0ull);
+        const uint64_t start_inv = wave_max64(member && r.start() ? ~r.start() : 0ull);
+        const uint64_t eth_tag = wave_max64(member && r.eth() ? (s1 << 16) | r.eth() : 0ull);
+        const uint64_t dscp_tag = wave_max64(member && r.dscp() ? (s1 << 8) | r.dscp() : 0ull);
+        const uint64_t samp_tag = wave_max64(member && r.sampling() ? (s1 << 32) | r.sampling() : 0ull);
+        const uint32_t first_inv = wave_max32(member ? ~seq32 : 0u);      // (~seq32 > 0: sequence numbers stop short of 2^32 - 16)
+        const uint32_t smac_inv = wave_max32(member && r.smac() ? ~seq32 : 0u);
+        const uint32_t dmac_inv = wave_max32(member && r.dmac() ? ~seq32 : 0u);
+        if (lane == (int)__builtin_ctzll(best_g)) {                   // the group's first lane: the entry's atomics, once
+            const int e = best_e;
+            const uint4 tt = L.t[e], qq = L.q[e];
+            if (bytes) atomicAdd(lo64(&L.v[e]), (unsigned long long)bytes);
+            if (packets) atomicAdd(&L.packets[e], packets);
+            if (flags & ~qq.x) atomicOr(reinterpret_cast<uint32_t*>(&L.q[e]), flags);
+            if (end > u64lo(tt)) atomicMax(lo64(&L.t[e]), (unsigned long long)end);
+            if (start_inv > u64hi(tt)) atomicMax(hi64(&L.t[e]), (unsigned long long)start_inv);
+            if (eth_tag) atomicMax(lo64(&L.w[e]), (unsigned long long)eth_tag);
+            if (dscp_tag) atomicMax(hi64(&L.w[e]), (unsigned long long)dscp_tag);
+            if (samp_tag) atomicMax(hi64(&L.v[e]), (unsigned long long)samp_tag);
+            uint32_t* qw = reinterpret_cast<uint32_t*>(&L.q[e]);
+            if (qq.y > ~first_inv) atomicMin(qw + 1, ~first_inv);
+            if (smac_inv && qq.z > ~smac_inv) atomicMin(qw + 2, ~smac_inv);
+            if (dmac_inv && qq.w > ~dmac_inv) atomicMin(qw + 3, ~dmac_inv);
+        }
+    }
+    if (active && !member) ent = cache_fold(L, ent, r, w, seq32);      // everybody else: as before (the key was checked twice: harmless)
+    return ent;
+}
+#endif
+
 // Overflow list: spills that found their partition queue (or staging group) full.
 // Sized by the API for the worst case; pass 3 merges its records one by one.
 NF_DEV void overflow_push(const SpillView& q, uint4 v) {
@@ -233,7 +326,8 @@ NF_DEV uint32_t sub_shift_of(const SpillView& q) { return q.part_shift >= (uint3
 // persistent LDS cache; a record whose flow has no entry is spilled: its index goes to the queue of its flow's partition,
 // staged four at a time in LDS so that a spill costs one 16-byte store and a quarter of an atomic.
 // ABL (libnfagg_diag.so only, ingest_variant 20..27: timing experiments, results are WRONG): bit 0 = spills are counted but not
-// queued, bit 1 = no fold into the cache entry, bit 2 = no cache claim (every record counts as a miss).
+// queued, bit 1 = no fold into the cache entry, bit 2 = no cache claim (every record counts as a miss). Bit 3 (variant 24, results
+// RIGHT): a wave's duplicates are combined before the LDS atomics (cache_fold_combined).
 template <bool SKETCH, bool TIMING, bool DOOR, int ABL = 0, bool DEEP = false>
 __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
                                                   uint64_t n, uint64_t seq_base) {
@@ -289,6 +383,10 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
         NF_TICK(1);
         __syncthreads();
         NF_TICK(2);
+#ifdef NFAGG_DIAG
+        if (ABL & 8) ent = cache_fold_combined(L, valid, ent, r, w, seq32);   // experiment: a wave's duplicates combined first (variant 24)
+        else
+#endif
         if (valid && ent >= 0 && !(ABL & 2)) ent = cache_fold(L, ent, r, w, seq32);
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -740,6 +838,7 @@ hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const Sp
         case 23: return part::run<false, false, false, true, 3>(tq, sk, q, d_records, n, seq_base, s);
         case 25: return part::run<false, false, false, true, 5>(tq, sk, q, d_records, n, seq_base, s);
         case 27: return part::run<false, false, false, true, 7>(tq, sk, q, d_records, n, seq_base, s);
+        case 24: return part::run<false, false, false, true, 8>(tq, sk, q, d_records, n, seq_base, s);         // experiment: wave-level duplicate combining before the LDS atomics (results RIGHT)
         case 28: return part::run<false, false, false, true, 0, true>(tq, sk, q, d_records, n, seq_base, s);   // experiment: records requested two tiles ahead (results RIGHT)
         default: break;
     }
