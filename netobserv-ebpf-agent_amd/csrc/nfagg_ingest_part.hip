@@ -363,6 +363,15 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
 #pragma unroll
     for (int k = 0; k < 2; k++) { pend[k] = false; pend_at[k] = 0; pend_p[k] = 0; fill_p[k] = kNoPart; pend_v[k] = make_uint4(0, 0, 0, 0); }
     uint32_t carry = 0xffffffffu, carry_p = 0;                         // a spill that found its group full: retried next tile
+#ifdef NFAGG_DIAG
+    // ABL bit 4 (variant 26; results WRONG — pass 2 does not know about it — a timing experiment for PASS 1 only): a quarter of the
+    // partitions, staging groups of SIXTEEN entries, every queue write one whole 64-byte sector (four 16-byte stores to
+    // consecutive addresses) instead of a 16-byte piece of one. What the round-4 review's item 2(a) could give pass 1 at best.
+    uint4 pw_v[2][4];
+    uint32_t pw_at[2] = {0, 0}, pw_p[2] = {0, 0}, fw_p[2] = {kNoPart, kNoPart};
+    bool pw[2] = {false, false};
+    uint32_t* const SW = &S.buf[0][0];                                 // [512][16]
+#endif
     // Software pipeline: the records of tile k+1 are requested before tile k is folded, so no HBM latency is exposed inside
     // a tile. Loads are unconditional on a clamped index; `valid` only gates the fold.
     // DEEP (experiment, round 5: libnfagg_diag.so ingest_variant 28): the records of tile k+2 are requested before tile k is folded —
@@ -388,6 +397,45 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
         else
 #endif
         if (valid && ent >= 0 && !(ABL & 2)) ent = cache_fold(L, ent, r, w, seq32);
+#ifdef NFAGG_DIAG
+        if (ABL & 16) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (pw[k]) {
+                    if (pw_at[k] + 16u <= 4u * q.qcap) {
+                        uint4* dst = reinterpret_cast<uint4*>(q.queue + (uint64_t)pw_p[k] * 4u * q.qcap + pw_at[k]);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) dst[j] = pw_v[k][j];
+                    }
+                    pw[k] = false;
+                }
+                if (fw_p[k] != kNoPart) {
+                    const uint32_t p = fw_p[k];
+                    const uint4* src = reinterpret_cast<const uint4*>(SW + p * 16u);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) pw_v[k][j] = src[j];
+                    S.cnt[p] = 0;
+                    pw_at[k] = aadd(&q.qtail[p * 4u], 16u);
+                    pw_p[k] = p; pw[k] = true; fw_p[k] = kNoPart;
+                }
+            }
+            __syncthreads();
+            if (carry != 0xffffffffu) {
+                const uint32_t at = atomicAdd(&S.cnt[carry_p], 1u);
+                if (at < 16u) { SW[carry_p * 16u + at] = carry; if (at == 15u) fw_p[0] = carry_p; }
+                carry = 0xffffffffu;
+            }
+            if (valid && ent < 0) {
+                spilled++;
+                const uint32_t p = part_of(h, q) >> 2;
+                const uint32_t at = atomicAdd(&S.cnt[p], 1u);
+                const uint32_t qi = (uint32_t)i | (tag_on ? ((uint32_t)(h >> sub_shift) & (uint32_t)(kSubs - 1)) << kIdxBits : 0u);
+                if (at < 16u) { SW[p * 16u + at] = qi; if (at == 15u) fw_p[1] = p; }
+                else { carry = qi; carry_p = p; }
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             if (pend[k]) {
@@ -838,6 +886,7 @@ hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const Sp
         case 23: return part::run<false, false, false, true, 3>(tq, sk, q, d_records, n, seq_base, s);
         case 25: return part::run<false, false, false, true, 5>(tq, sk, q, d_records, n, seq_base, s);
         case 27: return part::run<false, false, false, true, 7>(tq, sk, q, d_records, n, seq_base, s);
+        case 26: return part::run<false, false, false, true, 16>(tq, sk, q, d_records, n, seq_base, s);        // experiment, pass 1's time only (results WRONG): 64-byte queue stores, a quarter of the partitions
         case 24: return part::run<false, false, false, true, 8>(tq, sk, q, d_records, n, seq_base, s);         // experiment: wave-level duplicate combining before the LDS atomics (results RIGHT)
         case 28: return part::run<false, false, false, true, 0, true>(tq, sk, q, d_records, n, seq_base, s);   // experiment: records requested two tiles ahead (results RIGHT)
         default: break;
