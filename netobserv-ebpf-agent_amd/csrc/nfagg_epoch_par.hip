@@ -19,8 +19,8 @@
 //                   in the fold. Only when more than 4096 records of OTHER flows lie between a record and its previous occurrence
 //                   (a cold flow sharing its hash bits with one of the hottest) does the call go to the kernel chain
 //   k_par_live      first occurrences whose flow is live in the table: prev = -2 (not new in the first epoch of the call)
-//   k_par_cuts      ONE workgroup streams prev[] once in blocks of 16 Ki records and walks the epochs over it: per step one
-//                   wave-level DPP scan, one 16-entry LDS exchange, one barrier (two when an epoch ends in the block)
+//   k_par_cuts      ONE workgroup streams prev[] once in blocks of 16 Ki records and walks the epochs over it (per step: 16 compares per wave,
+//                   scalar mask counts, one 16-entry LDS exchange, one barrier); resumable: run in parts, the folds of a part's epochs beside the next part
 //   k_par_rank      one workgroup per complete epoch: the rank of every new flow among the epoch's new flows in arrival order =
 //                   its position in the epoch's eviction (exactly max_entries of them per epoch: checked)
 //   k_par_segfold   one lane per segment of at most kSegShort records: the records gathered in arrival order and folded
