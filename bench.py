@@ -59,7 +59,8 @@ def parse_args(argv=None):
     ap.add_argument("--variant", type=int, default=0, help="ingest kernel variant (DESIGN.md)")
     ap.add_argument("--dedup", action="store_true", help="configs[4]: NFAGG_MODE_KERNEL_DEDUP, every flow seen on two interfaces (stream variant 2)")
     ap.add_argument("--chunk", type=int, default=0, help="records per nfagg_ingest_device call (0 = whole stream)")
-    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="records of the stream the CPU oracle is timed on (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="records of the stream the CPU oracle is timed on (0 = skip; default: the whole "
+                    "100 M-record stream of configs[1] — ~10 s on one core, ~4 s more for the multi-core variants)")
     ap.add_argument("--max-entries", type=int, default=0)
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the bounded extra legs (e2e host path, configs[2], configs[4] shape, CACHE_MAX_FLOWS 5000)")
     ap.add_argument("--presharded", action="store_true", help="N > 1: round 2's line — every rank folds a private stream over its own shard's "
