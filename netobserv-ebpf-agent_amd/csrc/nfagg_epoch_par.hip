@@ -83,26 +83,52 @@ __global__ __launch_bounds__(kParBlock) void k_par_hash(const void* __restrict__
 // same key (equal hash bits are in index order). Nearly always that is position p - 1 or nothing; flows that share their hash bits
 // interleave, and the search walks over the other flows' records (at most kLinkSearch of them: beyond that *overflow is raised and
 // the call takes the kernel chain).
+// Every lane gathers ITS record's key once; the key of position p - 1 comes from the lane to the left (lane 0 of a wave loads
+// it): one gather per record instead of two — the second one was not served from the cache (299 B fetched per record for two
+// 48-byte keys, profiles/r05_cache_max_flows_5000_pmc_summary.md of the round's first evidence pass).
+NF_DEV uint64_t shfl_up1_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
 __global__ __launch_bounds__(kParBlock) void k_par_links(const void* __restrict__ recs, const uint64_t* __restrict__ ks, uint64_t n,
                                                          int32_t* __restrict__ prev, uint32_t* __restrict__ overflow) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
-        const uint64_t key = ks[p];
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += stride) {      // (every lane of a wave goes round together: shuffles)
+        const uint64_t p = base + threadIdx.x;
+        const bool valid = p < n;
+        const uint64_t key = valid ? ks[p] : 0ull;
         const uint32_t i = key_index(key);
         const uint64_t hb = key & kHashMask;
+        uint64_t a[5] = {0, 0, 0, 0, 0};
+        if (valid) par_key(recs, i, a);
+        // position p - 1: hash bits, index and key from the lane to the left
+        uint64_t hb_l = shfl_up1_u64(hb);
+        uint32_t j_l = (uint32_t)__shfl_up((int)i, 1);
+        uint64_t b[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) b[k] = shfl_up1_u64(a[k]);
+        if (lane == 0 && valid && p > 0) {                            // the wave's first position: its left neighbour belongs to another wave
+            const uint64_t k2 = ks[p - 1];
+            hb_l = k2 & kHashMask; j_l = key_index(k2);
+            if (hb_l == hb) par_key(recs, j_l, b);
+        }
+        if (!valid) continue;
         int32_t pv = -1;
-        if (p > 0 && (ks[p - 1] & kHashMask) == hb) {
-            uint64_t a[5], b[5];
-            par_key(recs, i, a);
-            uint64_t q = p;
-            int looked = 0;
-            while (q > 0) {
-                const uint64_t k2 = ks[--q];
-                if ((k2 & kHashMask) != hb) break;
-                if (++looked > kLinkSearch) { atomicExch(overflow, 1u); break; }
-                const uint32_t j = key_index(k2);
-                par_key(recs, j, b);
-                if (par_same_key(a, b)) { pv = (int32_t)j; break; }
+        if (p > 0 && hb_l == hb) {
+            if (par_same_key(a, b)) {
+                pv = (int32_t)j_l;
+            } else {                                                  // another flow with these hash bits: walk on to the left
+                uint64_t q = p - 1;
+                int looked = 1;
+                while (q > 0) {
+                    const uint64_t k2 = ks[--q];
+                    if ((k2 & kHashMask) != hb) break;
+                    if (++looked > kLinkSearch) { atomicExch(overflow, 1u); break; }
+                    const uint32_t j = key_index(k2);
+                    par_key(recs, j, b);
+                    if (par_same_key(a, b)) { pv = (int32_t)j; break; }
+                }
             }
         }
         prev[i] = pv;
