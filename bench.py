@@ -400,6 +400,9 @@ def rank_main(args):
                            "ingest variant %d" % args.variant),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac_note": "achieved / peak as the bench contract defines it: SURVEY 8(d)'s algorithmic bytes (a slot read + write per record, which "
+                             "a fold in LDS never moves) over the launch time. It is a model rate, not HBM traffic, and passes 1.0 on the "
+                             "fastest boxes; the fractions of real bounds are frac_traffic (counter bytes) and frac_stream_floor (the records read once)",
                 # honest yardsticks next to SURVEY §8(d)'s algorithmic figure (which charges a slot read + write per record that
                 # the LDS flow cache never performs): frac_stream_floor = the 144-byte records alone, read once, against the
                 # peak; frac_traffic = HBM bytes the counters saw (roofline.traffic), against the peak
