@@ -127,7 +127,7 @@ struct nfagg_handle {
     hipStream_t d2h_stream = nullptr;
     hipStream_t d2h_small = nullptr;     // small / one-off downloads (d2h_copy): not the stream the pipelined page-locked downloads use
     hipEvent_t bounce_ev[2] = {nullptr, nullptr};
-    hipGraphExec_t ep_graph = nullptr;   // kChainBatch windows of the epoch kernel chain, captured once (their arguments never change)
+    hipGraphExec_t ep_graph[3] = {nullptr, nullptr, nullptr};   // kChainWindows[k] windows of the epoch kernel chain, captured once (their arguments never change)
     bool ep_graph_off = false;           // the capture or the instantiation failed once: this handle launches its windows eagerly
     void* ep_graph_key[3] = {};          // the buffers the captured launches point at: re-capture when one was re-allocated
     // sub-flow table (kernel-dedup mode of a local-fold rank, nfagg_dedup.h): the flow-keyed table its epochs are joined into
@@ -140,8 +140,8 @@ struct nfagg_handle {
     // the evict-on-full loop with its epochs found first (nfagg_account_par.inc): analysis arrays, pinned mirror, the stream the
     // middle epochs are folded on while the table takes the first and the last
     uint32_t* h_par = nullptr;      // pinned: control words, then the cuts
-    void* d_par[7] = {};            // sort keys, sorted keys, prev, pos, long segments, sort scratch, control + cuts
-    size_t d_par_cap[7] = {};
+    void* d_par[8] = {};            // sort keys, sorted keys, prev, pos, long segments, sort scratch, control + cuts, rank tile counts
+    size_t d_par_cap[8] = {};
     hipStream_t par_stream = nullptr;
     hipEvent_t par_done = nullptr;
     nfagg_stats stats{};
@@ -261,10 +261,13 @@ int launch_ingest_profiled(nfagg_handle* h, const void* d, uint64_t n, uint64_t 
     return NFAGG_OK;
 }
 
-// Bring the device counters to the host (synchronises the stream).
-int refresh_counters(nfagg_handle* h) {
+// Bring the device counters to the host (synchronises the stream). In two halves for callers that wait for something else on the
+// same stream anyway: enqueue the copy, wait once, take the counters in.
+int refresh_counters_enqueue(nfagg_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->h_ctr, h->tv.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NFAGG_OK;
+}
+int refresh_counters_taken(nfagg_handle* h) {
     if (h->h_ctr->error)
         return fail(h, NFAGG_EDEVICE, "flow table kernel bailed out (code %u: 1 = probe overflow / table too small, 2 = claim spin limit, 5 = spill overflow list full, 6 = claimed slot without a record, 7 = partial of another shard merged)", h->h_ctr->error);
     h->live_ub = h->h_ctr->n_live;
@@ -274,6 +277,12 @@ int refresh_counters(nfagg_handle* h) {
     h->stats.records_bypassed = h->h_ctr->n_bypassed;
     if (h->h_ctr->max_probe > h->stats.max_probe) h->stats.max_probe = h->h_ctr->max_probe;
     return NFAGG_OK;
+}
+int refresh_counters(nfagg_handle* h) {
+    int rc = refresh_counters_enqueue(h);
+    if (rc != NFAGG_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return refresh_counters_taken(h);
 }
 
 // ---- optimistic fold -------------------------------------------------------------------------------------------
@@ -862,7 +871,7 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->tv.live_list) hipFree(h->tv.live_list);
     if (h->tv.ctr) hipFree(h->tv.ctr);
     if (h->h_par) hipHostFree(h->h_par);
-    for (int k = 0; k < 7; k++) if (h->d_par[k]) hipFree(h->d_par[k]);
+    for (int k = 0; k < 8; k++) if (h->d_par[k]) hipFree(h->d_par[k]);
     if (h->par_done) hipEventDestroy(h->par_done);
     if (h->par_stream) hipStreamDestroy(h->par_stream);
     if (h->jv.hot) hipFree(h->jv.hot);
@@ -879,7 +888,7 @@ void nfagg_destroy(nfagg_handle* h) {
     for (int b = 0; b < 2; b++) { if (h->h_bounce[b]) hipHostFree(h->h_bounce[b]); if (h->bounce_ev[b]) hipEventDestroy(h->bounce_ev[b]); }
     if (h->d2h_stream) hipStreamDestroy(h->d2h_stream);
     if (h->d2h_small) hipStreamDestroy(h->d2h_small);
-    if (h->ep_graph) hipGraphExecDestroy(h->ep_graph);
+    for (int k = 0; k < 3; k++) if (h->ep_graph[k]) hipGraphExecDestroy(h->ep_graph[k]);
     if (h->h_ep) hipHostFree(h->h_ep);
     if (h->d_ep_out) hipFree(h->d_ep_out);
     for (int k = 0; k < 3; k++) if (h->d_ep[k]) hipFree(h->d_ep[k]);
@@ -1428,13 +1437,26 @@ static bool account_fast_ok(const nfagg_handle* h, size_t n, size_t out_cap) {
 
 // One pass of the kernel chain (nfagg_epoch_chain.hip) over d[0..n). *consumed / *n_ep / *n_out: records consumed, evictions
 // performed, records written to d_out (epoch e ends at epoch_end[e] records); *stop as the control block reports it.
-// Windows are enqueued kChainBatch at a time, the control block is read back after each batch of launches.
+// Windows are enqueued kChainWindows[k] at a time, the control block is read back after each batch of launches.
+// Windows per launch of the chain. A window takes up to chain_window() records and ends early where an epoch ends, so a call of n
+// records needs about n / chain_window() + its evictions + 1 of them; the kernels of windows beyond the call's end find `stop` set
+// and return at once — but a launch of nothing still costs ~2 us, and a shim that drains a 50-slot channel
+// (pkg/agent/agent.go:408, pkg/config/config.go:134) calls with 1 ... a few thousand records: round 5 replayed 24 windows = 96
+// launches for every call, 230 us for ONE record (profiles/r06_account_small_calls.txt). Three graphs, the shortest that covers
+// what is left is replayed.
+constexpr int kChainWindows[3] = {2, 6, 24};
+constexpr size_t kChainEndsInline = 32;                 // epoch ends that come back with the control block (more: a second copy)
+
 static int account_chain_launch(nfagg_handle* h, const void* d, size_t n, void* d_out, size_t out_cap, uint64_t* epoch_end, size_t max_epochs,
                                 size_t* consumed, size_t* n_ep, size_t* n_out, uint32_t* stop) {
-    constexpr int kChainBatch = 24;
     int rc;
-    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;                       // exact len(entries), n_live, n_finalized
-    if (h->h_ctr->n_finalized != h->h_ctr->n_live) return fail(h, NFAGG_ESTATE, "account: unfinalized slots at the start of a batch");
+    // len(entries), n_live: the host knows them after an eviction and after the last chain launch (counters_exact) — one round
+    // trip less per call; otherwise asked for
+    if (!h->counters_exact) {
+        if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;
+        if (h->h_ctr->n_finalized != h->h_ctr->n_live) return fail(h, NFAGG_ESTATE, "account: unfinalized slots at the start of a batch");
+    }
+    const uint64_t n_live0 = h->live_ub;
     const uint32_t me = max_epochs > 0xFFFFu ? 0xFFFFu : (uint32_t)max_epochs;
     const size_t ctlb = (chain_ctl_bytes() + 63) & ~(size_t)63;
     if ((rc = ensure_bytes(h, &h->d_ep[0], &h->d_ep_cap[0], ctlb)) != NFAGG_OK) return rc;
@@ -1447,27 +1469,32 @@ static int account_chain_launch(nfagg_handle* h, const void* d, size_t n, void* 
         h->h_ep_cap = hb + 4096;
     }
     const uint64_t seq_start = h->epoch_seq - h->seq_origin;                      // window-relative, as the slots carry it
-    chain_ctl_fill(h->h_ep, d, d_out, n, seq_start, h->live, h->h_ctr->n_live, out_cap, h->tv.epoch_bits, h->cfg.max_entries, me);
+    chain_ctl_fill(h->h_ep, d, d_out, n, seq_start, h->live, n_live0, out_cap, h->tv.epoch_bits, h->cfg.max_entries, me);
     HIP_TRY(h, hipMemcpyAsync(h->d_ep[0], h->h_ep, chain_ctl_bytes(), hipMemcpyHostToDevice, h->stream));
-    // kChainBatch windows = 4 x kChainBatch launches whose arguments are the same in every call: captured into a graph once, one
+    // kChainWindows[k] windows = 4 x that many launches whose arguments are the same in every call: captured into graphs once, one
     // hipGraphLaunch per batch afterwards (eager launches cost the host ~8 us each here: the chain was host-bound)
-    if (!h->ep_graph_off && (!h->ep_graph || h->ep_graph_key[0] != h->d_ep[0] || h->ep_graph_key[1] != h->d_ep[1] || h->ep_graph_key[2] != h->d_ep[2])) {
-        if (h->ep_graph) { hipGraphExecDestroy(h->ep_graph); h->ep_graph = nullptr; }
-        hipGraph_t g = nullptr;
-        hipError_t ec = h->ep_graph_off ? hipErrorNotSupported : hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
-        if (ec == hipSuccess) {
-            for (int k = 0; k < kChainBatch && ec == hipSuccess; k++)
-                ec = launch_epoch_chain_window(h->tv, h->sk, h->d_ep[0], (uint32_t*)h->d_ep[2], (uint64_t*)h->d_ep[1], h->stream);
-            const hipError_t ee = hipStreamEndCapture(h->stream, &g);
-            if (ec == hipSuccess) ec = ee;
-            if (ec == hipSuccess) ec = hipGraphInstantiate(&h->ep_graph, g, nullptr, nullptr, 0);
-            if (g) hipGraphDestroy(g);
+    if (!h->ep_graph_off && (!h->ep_graph[0] || h->ep_graph_key[0] != h->d_ep[0] || h->ep_graph_key[1] != h->d_ep[1] || h->ep_graph_key[2] != h->d_ep[2])) {
+        hipError_t ec = hipSuccess;
+        for (int k = 0; k < 3; k++) {
+            if (h->ep_graph[k]) { hipGraphExecDestroy(h->ep_graph[k]); h->ep_graph[k] = nullptr; }
+            hipGraph_t g = nullptr;
+            if (ec == hipSuccess) ec = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+            else continue;
+            if (ec == hipSuccess) {
+                for (int w = 0; w < kChainWindows[k] && ec == hipSuccess; w++)
+                    ec = launch_epoch_chain_window(h->tv, h->sk, h->d_ep[0], (uint32_t*)h->d_ep[2], (uint64_t*)h->d_ep[1], h->stream);
+                const hipError_t ee = hipStreamEndCapture(h->stream, &g);
+                if (ec == hipSuccess) ec = ee;
+                if (ec == hipSuccess) ec = hipGraphInstantiate(&h->ep_graph[k], g, nullptr, nullptr, 0);
+                if (g) hipGraphDestroy(g);
+            }
         }
         if (ec != hipSuccess) {
             // no graph (a capture that something in the process invalidated, an instantiation that failed): this handle launches
             // its windows eagerly from now on — slower (~8 us of host time per launch), never wrong
             (void)hipGetLastError();
-            h->ep_graph = nullptr; h->ep_graph_off = true;
+            for (int k = 0; k < 3; k++) if (h->ep_graph[k]) { hipGraphExecDestroy(h->ep_graph[k]); h->ep_graph[k] = nullptr; }
+            h->ep_graph_off = true;
         } else {
             h->ep_graph_key[0] = h->d_ep[0]; h->ep_graph_key[1] = h->d_ep[1]; h->ep_graph_key[2] = h->d_ep[2];
         }
@@ -1475,24 +1502,39 @@ static int account_chain_launch(nfagg_handle* h, const void* d, size_t n, void* 
     EventPair ep{};
     if (h->cfg.profile) prof_begin(h, ep, 0);
     uint64_t v[9];
+    uint64_t left = n, ends_inline = 0;
+    h->counters_exact = false; h->mirror_fresh = false;
     for (;;) {
-        if (h->ep_graph) HIP_TRY(h, hipGraphLaunch(h->ep_graph, h->stream));
+        // windows this launch should hold: what is left in whole windows, one for every eviction an epoch of max_entries flows can
+        // end in (each ends its window early), one to spare
+        const uint64_t want = (left + chain_window() - 1) / chain_window() + left / (h->cfg.max_entries ? h->cfg.max_entries : 1) + 1;
+        int k = 0;
+        while (k < 2 && (uint64_t)kChainWindows[k] < want) k++;
+        if (h->ep_graph[k]) HIP_TRY(h, hipGraphLaunch(h->ep_graph[k], h->stream));
         else {
-            for (int k = 0; k < kChainBatch; k++) {
+            for (int w = 0; w < kChainWindows[k]; w++) {
                 const hipError_t el = launch_epoch_chain_window(h->tv, h->sk, h->d_ep[0], (uint32_t*)h->d_ep[2], (uint64_t*)h->d_ep[1], h->stream);
                 if (el != hipSuccess) return fail(h, NFAGG_EDEVICE, "epoch chain launch failed: %s", hipGetErrorString(el));
             }
         }
+        // the control block, the first epoch ends and the counters behind ONE wait (round 5: three)
+        ends_inline = me < kChainEndsInline ? me : kChainEndsInline;
         HIP_TRY(h, hipMemcpyAsync(h->h_ep, h->d_ep[0], chain_ctl_bytes(), hipMemcpyDeviceToHost, h->stream));
+        if (ends_inline) HIP_TRY(h, hipMemcpyAsync((char*)h->h_ep + ctlb, h->d_ep[1], ends_inline * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        if ((rc = refresh_counters_enqueue(h)) != NFAGG_OK) return rc;
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         chain_ctl_read(h->h_ep, v);
         if (v[6] != 0) break;
+        left = n - v[0];
     }
     if (h->cfg.profile) prof_end(h, ep);
     const uint64_t pos = v[0], seq = v[1], live = v[2], out_pos = v[3], n_epochs = v[5];
-    if (n_epochs) HIP_TRY(h, hipMemcpyAsync((char*)h->h_ep + ctlb, h->d_ep[1], (size_t)n_epochs * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
-    h->counters_exact = false; h->mirror_fresh = false;
-    if ((rc = refresh_counters(h)) != NFAGG_OK) return rc;                       // synchronises: epoch ends, counters
+    if (n_epochs > ends_inline) {
+        HIP_TRY(h, hipMemcpyAsync((char*)h->h_ep + ctlb + ends_inline * sizeof(uint64_t), (const uint64_t*)h->d_ep[1] + ends_inline,
+                                  (size_t)(n_epochs - ends_inline) * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    if ((rc = refresh_counters_taken(h)) != NFAGG_OK) return rc;
     if (h->h_ctr->n_live != live)
         return fail(h, NFAGG_EDEVICE, "epoch chain: %llu claimed slots, len(entries) %llu", (unsigned long long)h->h_ctr->n_live, (unsigned long long)live);
     for (uint64_t k = 0; k < n_epochs && k < max_epochs; k++) epoch_end[k] = ((const uint64_t*)((const char*)h->h_ep + ctlb))[k];
@@ -1505,6 +1547,7 @@ static int account_chain_launch(nfagg_handle* h, const void* d, size_t n, void* 
     if (n_epochs) h->seq_origin = 0;                            // an eviction inside the call restarted the epoch: a fresh window
     h->epoch_seq = h->seq_origin + seq; h->live = h->live_ub = live;
     h->counters_exact = true;
+    h->mirror_fresh = false;                                    // (k_finalize moves n_finalized behind the mirror's back)
     h->epoch_unclustered = true;
     h->stats.records_ingested += pos;
     h->stats.evictions[NFAGG_REASON_FULL] += n_epochs;
@@ -1612,7 +1655,7 @@ int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, siz
     auto stage = [&](int b, size_t lo) -> int {
         size_t want = cap;
         if (n_staged < 2 && n > cap + cap / 2) want = cap >> (2 - n_staged);        // ramp: cap / 4, cap / 2, cap, cap, ...
-        if (want < (size_t)(4 * h->cfg.max_entries + 65536)) want = cap;            // (never so short that the chunk leaves the epochs-found-first path)
+        if (want < (size_t)account_par_min_records(h->cfg.max_entries)) want = cap; // (never so short that the chunk leaves the epochs-found-first path)
         n_staged++;
         const size_t m = (n - lo) < want ? (n - lo) : want;
         HIP_TRY(h, hipEventSynchronize(h->stage_free[b]));

@@ -281,7 +281,8 @@ NF_DEV void merge_at(const TableView& t, uint32_t idx, const DedupPartial& p, ui
     dedup_merge<true>(t, idx, hx, p);
 }
 
-NF_DEV void fold_item(const TableView& t, const Item& x, const void* recs, uint32_t seq_base32) {
+NF_DEV void fold_item(const TableView& t, const SketchView& sk, const Item& x, const void* recs, uint32_t seq_base32) {
+    if (sk.flags) sketch_add(sk, x.w, x.p.bytes);                // the item's records reach the sketches here, once (see parts_flush)
     Hints hx;
     const uint64_t kx = sub_kx(t, x.ifx), hs = sub_hash(t, x.h, x.ifx);
     uint32_t idx = probe_home(t, x.w, hs, hx, kx);
@@ -453,7 +454,12 @@ NF_DEV void parts_round(const TableView& t, const SpillView& q, FoldCache<kPartE
 // Phase A: slot + first record + earliest interfaces for every entry. Barrier. Phase B: the merges (F is final: every sub-flow
 // of every flow of this partition has been claimed — by this flush, by parts_round<FIRST>, by the overflow kernel before this
 // launch, or in an earlier call).
-NF_DEV void parts_flush(const TableView& t, FoldCache<kPartEntries>& L, const void* recs, uint32_t seq_base32) {
+// The sketches (every record's bytes, whatever the dedup merge does with them) are fed HERE, one contribution per
+// cache entry: an entry's `bytes` is the plain sum over all the records it stands for — the counted / side decision is taken at
+// the merge (dedup_merge), not in the partial — and every record of the batch ends in exactly one flush of one entry (through the
+// streaming pass's exported entry or as a queued record) or in fold_item. Count-Min is linear, HyperLogLog idempotent. Round 5 ran
+// k_sketch_update over the batch as a second pass: 8.1 ms of the 14.3 ms configs[4] step (profiles/r05_bench_world1_nccl_configs4_100m.json).
+NF_DEV void parts_flush(const TableView& t, const SketchView& sk, FoldCache<kPartEntries>& L, const void* recs, uint32_t seq_base32) {
     const int e = threadIdx.x;
     const bool used = L.h64[e] != 0 && L.min_seq[e] != 0xffffffffu;
     uint32_t idx = kNoSlot;
@@ -480,6 +486,12 @@ NF_DEV void parts_flush(const TableView& t, FoldCache<kPartEntries>& L, const vo
         DedupPartial p;
         partial_of_entry(L, e, p);
         merge_at(t, idx, p, L.min_seq[e], recs, seq_base32);
+    }
+    if (used && sk.flags) {
+        uint64_t w[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) w[k] = L.key[k][e];
+        sketch_add(sk, w, L.bytes[e]);
     }
     __syncthreads();
 }
@@ -573,7 +585,7 @@ NF_DEV void flush_fresh_flow(const TableView& t, const FoldCache<kPartEntries>& 
     for (int k = 0; k < 5; k++) ast(&H->key[k], w[k]);
 }
 
-NF_DEV void parts_flush_grouped(const TableView& t, FoldCache<kPartEntries>& L, PartsLds& P, const void* recs, uint32_t seq_base32) {
+NF_DEV void parts_flush_grouped(const TableView& t, const SketchView& sk, FoldCache<kPartEntries>& L, PartsLds& P, const void* recs, uint32_t seq_base32) {
     static_assert(offsetof(SlotAux, endl_lo) == 56 && offsetof(SlotAux, ssl_first) == 72 && offsetof(SlotAux, cs_tag) == 88 &&
                   offsetof(SlotAux, dir) == 104, "flush_fresh_flow writes the aux lines as 16-byte units");
     const int e = threadIdx.x;
@@ -664,6 +676,7 @@ NF_DEV void parts_flush_grouped(const TableView& t, FoldCache<kPartEntries>& L, 
         if (base + my_k < t.claim_limit) t.live_list[base + my_k] = idx;
         else ast(&t.hot[idx].tag, (uint64_t)0);
     }
+    if (used && sk.flags) sketch_add(sk, w, L.bytes[e]);                     // one contribution per entry (parts_flush)
     __syncthreads();
 }
 
@@ -671,7 +684,7 @@ constexpr int kMaxRounds = 16;
 
 // Rounds over the items at list[0..m) (written by this workgroup) until none is left: every round takes what fits a fresh cache
 // and writes the rest back to the front of the list. Every item's sub-flow has been claimed on the table (first round).
-NF_DEV void parts_drain(const TableView& t, const SpillView& q, FoldCache<kPartEntries>& L, PartsLds& P, uint32_t* list, uint32_t m,
+NF_DEV void parts_drain(const TableView& t, const SketchView& sk, const SpillView& q, FoldCache<kPartEntries>& L, PartsLds& P, uint32_t* list, uint32_t m,
                         const void* recs, uint32_t seq_base32, uint32_t idx_mask, int max_rounds) {
     const int tid = threadIdx.x;
     for (int round = 1; m != 0; round++) {
@@ -683,7 +696,7 @@ NF_DEV void parts_drain(const TableView& t, const SpillView& q, FoldCache<kPartE
                 load_item(q, recs, it, idx_mask, raw);
                 Item x;
                 decode_item(it, idx_mask, raw, seq_base32, x);
-                fold_item(t, x, recs, seq_base32);
+                fold_item(t, sk, x, recs, seq_base32);
             }
             break;
         }
@@ -691,7 +704,7 @@ NF_DEV void parts_drain(const TableView& t, const SpillView& q, FoldCache<kPartE
         if (tid == 0) P.retry_cnt = 0;
         __syncthreads();
         parts_round<false, true>(t, q, L, P, list, m, recs, seq_base32, idx_mask);
-        parts_flush(t, L, recs, seq_base32);
+        parts_flush(t, sk, L, recs, seq_base32);
         m = P.retry_cnt;
         drain_stores();
         __syncthreads();                                          // everybody has read retry_cnt; the retry list is written
@@ -700,7 +713,7 @@ NF_DEV void parts_drain(const TableView& t, const SpillView& q, FoldCache<kPartE
 
 
 template <int ABL = 0>
-__global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q, const void* __restrict__ recs, uint64_t n, uint64_t seq_base,
+__global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs, uint64_t n, uint64_t seq_base,
                                                         int max_rounds) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     FoldCache<kPartEntries>& L = *reinterpret_cast<FoldCache<kPartEntries>*>(lds_raw);
@@ -766,7 +779,7 @@ __global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q
                 take = (int)(room / (per_run + per_run / 4u));
                 if (take == 0) {                                           // no room for another run: flush, fresh cache
                     __syncthreads();
-                    if (grouped) parts_flush_grouped(t, L, P, recs, seq_base32); else parts_flush(t, L, recs, seq_base32);
+                    if (grouped) parts_flush_grouped(t, sk, L, P, recs, seq_base32); else parts_flush(t, sk, L, recs, seq_base32);
                     cache_init(L, tid);
                     if (tid == 0) {
                         P.fill = 0;
@@ -785,21 +798,21 @@ __global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q
             runs_in_cache += s1 - s0;
             s0 = s1;
         }
-        if (grouped) parts_flush_grouped(t, L, P, recs, seq_base32); else parts_flush(t, L, recs, seq_base32);
+        if (grouped) parts_flush_grouped(t, sk, L, P, recs, seq_base32); else parts_flush(t, sk, L, recs, seq_base32);
         const uint32_t m2 = P.retry_cnt;                                   // sub-flows of a run that overflowed a whole cache: claimed already
         if (m2 == 0) return;
         drain_stores();
         __syncthreads();
-        parts_drain(t, q, L, P, my_queue, m2, recs, seq_base32, idx_mask, max_rounds);
+        parts_drain(t, sk, q, L, P, my_queue, m2, recs, seq_base32, idx_mask, max_rounds);
         return;
     }
     parts_round<true, false, ABL>(t, q, L, P, my_queue, count, recs, seq_base32, idx_mask);
     if (ABL) {
-        if (!(ABL & 1)) parts_flush(t, L, recs, seq_base32);
+        if (!(ABL & 1)) parts_flush(t, sk, L, recs, seq_base32);
         return;
     }
-    if (t.defer_claims && !t.subflow) parts_flush_grouped(t, L, P, recs, seq_base32);     // sub-flow tables: every entry its own slot
-    else parts_flush(t, L, recs, seq_base32);
+    if (t.defer_claims && !t.subflow) parts_flush_grouped(t, sk, L, P, recs, seq_base32); // sub-flow tables: every entry its own slot
+    else parts_flush(t, sk, L, recs, seq_base32);
     const uint32_t m = P.retry_cnt;
     if (m == 0) return;
     drain_stores();
@@ -809,7 +822,7 @@ __global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q
     // surely fits a cache one round of its own; a run that does not fit after all is drained in further rounds.
     const uint32_t sorted_at = (count + 3u) & ~3u;
     if (!tag_on || (uint64_t)sorted_at + m > q.qcap) {
-        parts_drain(t, q, L, P, my_queue, m, recs, seq_base32, idx_mask, max_rounds);
+        parts_drain(t, sk, q, L, P, my_queue, m, recs, seq_base32, idx_mask, max_rounds);
         return;
     }
     if (tid == 0) { uint32_t o = 0; for (int s = 0; s < kSubs; s++) { P.sub_off[s] = o; o += P.sub_cnt[s]; } P.sub_off[kSubs] = o; }
@@ -826,14 +839,14 @@ __global__ __launch_bounds__(kBlock) void k_dedup_parts(TableView t, SpillView q
         uint32_t c = P.sub_cnt[s];
         int e = s + 1;
         while (e < kSubs && c + P.sub_cnt[e] <= kPackItems) { c += P.sub_cnt[e]; e++; }
-        if (c) parts_drain(t, q, L, P, sorted + P.sub_off[s], c, recs, seq_base32, idx_mask, max_rounds);
+        if (c) parts_drain(t, sk, q, L, P, sorted + P.sub_off[s], c, recs, seq_base32, idx_mask, max_rounds);
         s = e;
     }
 }
 
 // the (normally empty) overflow list of the streaming pass: one item per lane, straight on the table
 template <bool FOLD>
-__global__ __launch_bounds__(256) void k_dedup_overflow(TableView t, SpillView q, const void* __restrict__ recs, uint64_t n, uint64_t seq_base) {
+__global__ __launch_bounds__(256) void k_dedup_overflow(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs, uint64_t n, uint64_t seq_base) {
     const uint32_t idx_mask = n <= (uint64_t)kIdxMask ? kIdxMask : kIdxMaskUntagged;
     uint32_t count = *q.ovf_tail;
     if (count > q.ovf_cap) count = q.ovf_cap;
@@ -845,7 +858,7 @@ __global__ __launch_bounds__(256) void k_dedup_overflow(TableView t, SpillView q
         load_item(q, recs, it, idx_mask, raw);
         Item x;
         decode_item(it, idx_mask, raw, (uint32_t)seq_base, x);
-        if (FOLD) { fold_item(t, x, recs, (uint32_t)seq_base); direct++; }
+        if (FOLD) { fold_item(t, sk, x, recs, (uint32_t)seq_base); direct++; }
         else claim_item(t, x);
     }
     if (direct) aadd(&t.ctr->phase[7], direct);                 // diagnostics (nfagg_debug_phase_cycles[7] of libnfagg_diag.so): items through the overflow list
@@ -853,9 +866,10 @@ __global__ __launch_bounds__(256) void k_dedup_overflow(TableView t, SpillView q
 
 }  // namespace dcache
 
-// Four launches: stream, overflow claims, partitions, overflow folds (+ the reset of the overflow tail).
+// Four launches: stream, overflow claims, partitions, overflow folds (+ the reset of the overflow tail). The sketches of sk (flags = 0:
+// none) are fed by the partition pass's flushes and the overflow folds.
 // variant 12 (A/B, tests): no retry rounds in the partition pass.
-hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, int variant, hipStream_t s) {
+hipError_t launch_ingest_dedup_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base, int variant, hipStream_t s) {
     using namespace dcache;
     if (n == 0) return hipSuccess;
     const SpillView& q = t.spill;
@@ -884,15 +898,15 @@ hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records,
     hipError_t e;
 #define NF_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); e = hipGetLastError(); if (e != hipSuccess) return e; } while (0)
     NF_LAUNCH(k_dedup_stream, dim3(grid), dim3(kBlock), lds1, s, t, q, d_records, n, seq_base);
-    NF_LAUNCH((k_dedup_overflow<false>), dim3(32), dim3(256), 0, s, t, q, d_records, n, seq_base);
+    NF_LAUNCH((k_dedup_overflow<false>), dim3(32), dim3(256), 0, s, t, sk, q, d_records, n, seq_base);
 #ifdef NFAGG_DIAG
-    if (variant == 13) NF_LAUNCH(k_dedup_parts<1>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, 1);
-    else if (variant == 14) NF_LAUNCH(k_dedup_parts<3>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, 1);
-    else if (variant == 15) NF_LAUNCH(k_dedup_parts<7>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, 1);
+    if (variant == 13) NF_LAUNCH(k_dedup_parts<1>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base, 1);
+    else if (variant == 14) NF_LAUNCH(k_dedup_parts<3>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base, 1);
+    else if (variant == 15) NF_LAUNCH(k_dedup_parts<7>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base, 1);
     else
 #endif
-    NF_LAUNCH(k_dedup_parts<0>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, q, d_records, n, seq_base, variant == 12 ? 1 : kMaxRounds);
-    NF_LAUNCH((k_dedup_overflow<true>), dim3(32), dim3(256), 0, s, t, q, d_records, n, seq_base);
+    NF_LAUNCH(k_dedup_parts<0>, dim3(kSpillParts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base, variant == 12 ? 1 : kMaxRounds);
+    NF_LAUNCH((k_dedup_overflow<true>), dim3(32), dim3(256), 0, s, t, sk, q, d_records, n, seq_base);
 #undef NF_LAUNCH
     return hipMemsetAsync(q.ovf_tail, 0, sizeof(uint32_t), s);
 }

@@ -21,8 +21,8 @@
 //   k_par_live      first occurrences whose flow is live in the table: prev = -2 (not new in the first epoch of the call)
 //   k_par_cuts      ONE workgroup streams prev[] once in blocks of 16 Ki records and walks the epochs over it (per step: 16 compares per wave,
 //                   scalar mask counts, one 16-entry LDS exchange, one barrier); resumable: run in parts, the folds of a part's epochs beside the next part
-//   k_par_rank      one workgroup per complete epoch: the rank of every new flow among the epoch's new flows in arrival order =
-//                   its position in the epoch's eviction (exactly max_entries of them per epoch: checked)
+//   k_par_rank_*    the rank of every new flow among its epoch's new flows in arrival order = its position in the epoch's eviction:
+//                   one running count over tiles of the launch's records (exactly max_entries per epoch: checked)
 //   k_par_segfold   one lane per segment of at most kSegShort records: the records gathered in arrival order and folded
 //                   SEQUENTIALLY, literally as the reference does; the folded record goes straight to its place in the caller's buffer
 //   k_par_segfold_long   one wave per longer segment (the hot flows): an order-free partial per lane, combined across the wave
@@ -41,6 +41,9 @@ constexpr int kLinkSearch = 4096;                                     // records
 constexpr int kIdxBits = 24;                                          // a launch takes at most 2^24 records: the index's share of a sort key
 constexpr uint64_t kIdxMask = (1ull << kIdxBits) - 1ull, kHashMask = ~kIdxMask;   // ... and the key hash's: its top 40 bits
 constexpr uint32_t kSegShort = 16;                                    // records per segment the one-lane fold takes
+constexpr uint32_t kSegHuge = 4096;                                   // positions per segment beyond which a whole workgroup folds it (one wave up to here)
+constexpr uint32_t kHugeCap = 8192;                                   // entries of the list of such segments (disjoint runs of > kSegHuge positions: <= 2^24 / 4097 per launch)
+constexpr int kHugeBlock = 1024;
 
 static inline int par_grid(uint64_t n, int per_block = kParBlock, int cap = 1 << 20) {
     uint64_t g = (n + per_block - 1) / per_block;
@@ -445,34 +448,124 @@ __global__ __launch_bounds__(kCutBlock) void k_par_cuts(const int32_t* __restric
     }
 }
 
-// One workgroup per complete epoch t of the middle: records [cuts[t], cuts[t + 1]). pos[i] = t * max_entries + the number of new
-// flows of the epoch before record i, for the records that start one (prev < the epoch's first record); kParNone for the others.
-// A launch ranks the epochs [t_lo, t_hi): the ones a part of the walk has just completed.
-// The eviction of the epoch is what the records with a position fold to, in that order (Go's map order is random: any order is
-// the reference's). Every such epoch holds exactly max_entries new flows — that is how its end was found: *bad otherwise.
-__global__ __launch_bounds__(kParBlock) void k_par_rank(const int32_t* __restrict__ prev, const uint32_t* __restrict__ cuts, uint32_t t_lo, uint32_t t_hi,
-                                                        uint32_t max_entries, uint32_t* __restrict__ pos, uint32_t* __restrict__ bad) {
-    constexpr int kWaves = kParBlock / 64;
-    __shared__ uint32_t wcnt[2][kWaves];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (uint32_t t = t_lo + blockIdx.x; t < t_hi; t += gridDim.x) {
-        const uint32_t s = cuts[t], e = cuts[t + 1];
-        uint32_t running = 0, par = 0;
-        for (uint32_t base = s; base < e; base += kParBlock) {
-            const uint32_t i = base + tid;
-            const bool head = i < e && (int64_t)prev[i] < (int64_t)s;
-            const unsigned long long m = __ballot(head);
-            if (lane == 0) wcnt[par][wv] = (uint32_t)__popcll(m);
-            __syncthreads();
-            uint32_t woff = 0, total = 0;
+// The positions of the middle epochs' new flows. Epoch t of the middle = records [cuts[t], cuts[t + 1]); a record i of it starts a new
+// flow in it when prev[i] < cuts[t] (a HEAD). pos[i] = t * max_entries + the number of heads of the epoch before record i, for the
+// heads; kParNone for the other records. The eviction of the epoch is what the heads' segments fold to, in that order (Go's map
+// order is random: any order is the reference's). Every complete epoch holds exactly max_entries heads — that is how its end was
+// found — so the position is ONE running count over all the records of the launch: t_lo * max_entries + the heads in
+// [cuts[t_lo], i). Three launches over tiles of kRankTile records, whatever the epochs' lengths (round 5 ranked every epoch with one
+// workgroup of its own: right for the 14 k-record epochs of CACHE_MAX_FLOWS = 5000, a serial walk of 2400 steps per epoch at
+// 100 000 — pkg/flow/tracer_map_bench_test.go:64-111 brackets 1 k / 10 k / 100 k):
+//   k_par_rank_count   heads per tile
+//   k_par_rank_scan    one workgroup: exclusive prefix of the tile counts; the total must be (t_hi - t_lo) * max_entries
+//   k_par_rank_write   pos[]; and the check that makes "exactly max_entries per epoch" a fact and not an assumption: the first
+//                      record of every epoch t is a head (prev[i] < i always) and its position must be exactly t * max_entries — by
+//                      induction every epoch before it holds max_entries heads; the total covers the last one. *bad otherwise.
+constexpr int kRankPer = 8;
+constexpr uint32_t kRankTile = kParBlock * kRankPer;
+
+// the middle epoch that holds record i: the largest t in [t_lo, t_hi) with cuts[t] <= i (cuts[t_lo] <= i < cuts[t_hi])
+NF_DEV uint32_t par_epoch_of(const uint32_t* __restrict__ cuts, uint32_t t_lo, uint32_t t_hi, uint32_t i) {
+    uint32_t lo = t_lo, hi = t_hi;
+    while (hi - lo > 1u) { const uint32_t mid = lo + ((hi - lo) >> 1); if (cuts[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// Is record i a head, and of which epoch? The tile's first and last epochs bracket the search (most tiles lie inside one epoch).
+struct RankTile { uint32_t t_first, t_last; };
+NF_DEV RankTile rank_tile_epochs(const uint32_t* __restrict__ cuts, uint32_t t_lo, uint32_t t_hi, uint32_t base, uint32_t i_hi, uint32_t* sh) {
+    if (threadIdx.x == 0) {
+        const uint32_t last = base + kRankTile - 1u < i_hi ? base + kRankTile - 1u : i_hi - 1u;
+        sh[0] = par_epoch_of(cuts, t_lo, t_hi, base);
+        sh[1] = par_epoch_of(cuts, sh[0], t_hi, last);
+    }
+    __syncthreads();
+    RankTile r; r.t_first = sh[0]; r.t_last = sh[1];
+    return r;
+}
+NF_DEV bool rank_is_head(const int32_t* __restrict__ prev, const uint32_t* __restrict__ cuts, const RankTile& rt, uint32_t s_first, uint32_t i, uint32_t* t_out) {
+    uint32_t t = rt.t_first, s = s_first;
+    if (rt.t_last != rt.t_first) { t = par_epoch_of(cuts, rt.t_first, rt.t_last + 1u, i); s = cuts[t]; }
+    *t_out = t;
+    return (int64_t)prev[i] < (int64_t)s;
+}
+
+__global__ __launch_bounds__(kParBlock) void k_par_rank_count(const int32_t* __restrict__ prev, const uint32_t* __restrict__ cuts, uint32_t t_lo, uint32_t t_hi,
+                                                              uint32_t i_lo, uint32_t i_hi, uint32_t* __restrict__ tile_cnt) {
+    __shared__ uint32_t sh[2], wsum[kParBlock / 64];
+    const uint32_t base = i_lo + blockIdx.x * kRankTile;
+    const RankTile rt = rank_tile_epochs(cuts, t_lo, t_hi, base, i_hi, sh);
+    const uint32_t s_first = cuts[rt.t_first];
+    uint32_t mine = 0;
 #pragma unroll
-            for (int q = 0; q < kWaves; q++) { const uint32_t x = wcnt[par][q]; total += x; woff += q < wv ? x : 0u; }
-            if (i < e) pos[i] = head ? t * max_entries + running + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) : kParNone;
-            running += total;
-            par ^= 1u;
+    for (int k = 0; k < kRankPer; k++) {
+        const uint32_t i = base + (uint32_t)k * kParBlock + threadIdx.x;
+        uint32_t t;
+        if (i < i_hi && rank_is_head(prev, cuts, rt, s_first, i, &t)) mine++;
+    }
+    mine = wave_scan_u32(mine);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t tot = 0; for (int q = 0; q < kParBlock / 64; q++) tot += wsum[q]; tile_cnt[blockIdx.x] = tot; }
+}
+
+// One workgroup of 1024 lanes: tile_cnt[0 .. n_tiles) -> its exclusive prefix, in place; n_tiles <= 2^24 / kRankTile = 8192.
+__global__ __launch_bounds__(1024) void k_par_rank_scan(uint32_t* __restrict__ tile_cnt, uint32_t n_tiles, uint32_t expect_total, uint32_t* __restrict__ bad) {
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += 1024u) {
+        const uint32_t j = base + (uint32_t)tid;
+        const uint32_t v = j < n_tiles ? tile_cnt[j] : 0u;
+        const uint32_t incl = wave_scan_u32(v);
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const uint32_t x = wsum[q]; total += x; woff += q < wv ? x : 0u; }
+        if (j < n_tiles) tile_cnt[j] = carry + woff + incl - v;
+        carry += total;
+        __syncthreads();
+    }
+    if (tid == 0 && carry != expect_total) atomicExch(bad, 2u);
+}
+
+__global__ __launch_bounds__(kParBlock) void k_par_rank_write(const int32_t* __restrict__ prev, const uint32_t* __restrict__ cuts, uint32_t t_lo, uint32_t t_hi,
+                                                              uint32_t i_lo, uint32_t i_hi, uint32_t max_entries, const uint32_t* __restrict__ tile_off,
+                                                              uint32_t* __restrict__ pos, uint32_t* __restrict__ bad) {
+    constexpr int kWaves = kParBlock / 64;
+    __shared__ uint32_t sh[2], wcnt[kRankPer][kWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t base = i_lo + blockIdx.x * kRankTile;
+    const RankTile rt = rank_tile_epochs(cuts, t_lo, t_hi, base, i_hi, sh);
+    const uint32_t s_first = cuts[rt.t_first];
+    unsigned long long m[kRankPer];
+    uint32_t ep[kRankPer];
+#pragma unroll
+    for (int k = 0; k < kRankPer; k++) {
+        const uint32_t i = base + (uint32_t)k * kParBlock + (uint32_t)tid;
+        uint32_t t = 0;
+        const bool head = i < i_hi && rank_is_head(prev, cuts, rt, s_first, i, &t);
+        ep[k] = t;
+        m[k] = __ballot(head);
+        if (lane == 0) wcnt[k][wv] = (uint32_t)__popcll(m[k]);
+    }
+    __syncthreads();
+    uint32_t running = t_lo * max_entries + tile_off[blockIdx.x];          // heads before this tile, counted from the first middle epoch
+#pragma unroll
+    for (int k = 0; k < kRankPer; k++) {
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < kWaves; q++) { const uint32_t x = wcnt[k][q]; total += x; woff += q < wv ? x : 0u; }
+        const uint32_t i = base + (uint32_t)k * kParBlock + (uint32_t)tid;
+        if (i < i_hi) {
+            const bool head = (m[k] >> lane) & 1ull;
+            const uint32_t p = running + woff + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull));
+            pos[i] = head ? p : kParNone;
+            // the epoch's first record: a head whose position is the epoch's first — or an earlier epoch does not hold max_entries
+            if (i == (rt.t_last != rt.t_first ? cuts[ep[k]] : s_first) && (!head || p != ep[k] * max_entries)) atomicExch(bad, 1u);
         }
-        if (tid == 0 && running != max_entries) atomicExch(bad, 1u);
-        __syncthreads();                                              // wcnt[] of the last tile is read before the next epoch rewrites it
+        running += total;
     }
 }
 
@@ -520,7 +613,8 @@ template <bool SKETCH>
 __global__ __launch_bounds__(kParBlock) void k_par_segfold(const void* __restrict__ recs, const uint64_t* __restrict__ ks, uint64_t n,
                                                            const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cuts,
                                                            uint32_t max_entries, SketchView sk, void* __restrict__ out,
-                                                           uint32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
+                                                           uint32_t* __restrict__ long_list, uint32_t* __restrict__ n_long, uint32_t long_cap,
+                                                           uint32_t* __restrict__ huge_list, uint32_t* __restrict__ n_huge,
                                                            uint32_t i_lo, uint32_t i_hi) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -531,8 +625,20 @@ __global__ __launch_bounds__(kParBlock) void k_par_segfold(const void* __restric
     if (ps == kParNone) return;
     const uint64_t limit = (key & kHashMask) | (uint64_t)cuts[ps / max_entries + 1];     // (hash bits, end of the epoch)
     if (p + kSegShort < n && ks[p + kSegShort] < limit) {             // more than kSegShort positions: a wave takes it
-        long_list[atomicAdd(n_long, 1u)] = (uint32_t)p;
-        return;
+        // The list is bounded. Segments of flows that do not share their 40 hash bits are disjoint runs of more than kSegShort
+        // positions: at most n / (kSegShort + 1) of them. Flows that DO share them (crafted: key_hash has a fixed seed) interleave
+        // in one run, and every head with kSegShort positions of the run behind it lands here — G such flows list ~G segments
+        // from G records. Beyond the list's room this lane folds its segment itself, however long the run is: slower, never out
+        // of bounds (tests/test_account_par_gpu.py::test_many_runs_of_flows_that_share_their_key_hash).
+        // ... and a whole workgroup a segment of more than kSegHuge positions: the hot flows of a LONG epoch (CACHE_MAX_FLOWS =
+        // 100 000: ~600 k records per epoch, 42 k of them the hottest flow's — 656 dependent gathers for one wave, 1.3 ms on the
+        // critical path of every launch: profiles/r06_account_regimes.txt)
+        if (p + kSegHuge < n && ks[p + kSegHuge] < limit) {
+            const uint32_t ah = atomicAdd(n_huge, 1u);
+            if (ah < kHugeCap) { huge_list[ah] = (uint32_t)p; return; }
+        }
+        const uint32_t at = atomicAdd(n_long, 1u);
+        if (at < long_cap) { long_list[at] = (uint32_t)p; return; }
     }
     Rec acc;
     load_record(recs, i, acc);
@@ -606,57 +712,105 @@ NF_DEV uint64_t shfl_xor_u64(uint64_t v, int m) {
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-// One wave per listed segment. Its end: the first position whose sort key reaches (hash bits, end of the epoch) — a binary search,
-// the array is sorted. The lanes take the positions 64 at a time; what they hold is combined with xor-shuffles; lane 0 applies it
-// to the first record and stores.
+// What the lanes of one wave hold after they have taken the positions [first + lane, end) `step` apart, combined over the wave
+// (xor-shuffles: every lane ends up with the wave's partial).
+NF_DEV void seg_gather(const void* __restrict__ recs, const uint64_t* __restrict__ ks, uint64_t first, uint64_t end, uint64_t step,
+                       const uint64_t w[5], SegAcc& a) {
+    a.clear();
+    for (uint64_t q = first; q < end; q += step) {
+        const uint32_t i2 = key_index(ks[q]);
+        Rec r;
+        load_record_head(recs, i2, r);
+        r.d[9] &= 0x00ffffffu;
+        uint64_t w2[5];
+        r.key_words(w2);
+        if (par_same_key(w, w2)) a.add(r, i2);
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        SegAcc o;
+        o.bytes = shfl_xor_u64(a.bytes, m); o.end = shfl_xor_u64(a.end, m); o.start_inv = shfl_xor_u64(a.start_inv, m);
+        o.eth_tag = shfl_xor_u64(a.eth_tag, m); o.dscp_tag = shfl_xor_u64(a.dscp_tag, m); o.samp_tag = shfl_xor_u64(a.samp_tag, m);
+        o.smac = shfl_xor_u64(a.smac, m); o.dmac = shfl_xor_u64(a.dmac, m);
+        o.packets = (uint32_t)__shfl_xor((int)a.packets, m); o.flags = (uint32_t)__shfl_xor((int)a.flags, m);
+        o.smac_at = (uint32_t)__shfl_xor((int)a.smac_at, m); o.dmac_at = (uint32_t)__shfl_xor((int)a.dmac_at, m);
+        a.combine(o);
+    }
+}
+
+// the end of the segment that begins at sorted position p: the first position in (p, n] whose sort key reaches `limit` = (hash
+// bits, end of the epoch) — a binary search, the array is sorted
+NF_DEV uint64_t seg_end(const uint64_t* __restrict__ ks, uint64_t n, uint64_t p, uint64_t limit) {
+    uint64_t lo = p + 1, hi = n;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ks[mid] < limit) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// One wave per listed segment. The lanes take the positions 64 at a time; what they hold is combined with xor-shuffles; lane 0
+// applies it to the first record and stores.
 template <bool SKETCH>
 __global__ __launch_bounds__(kParBlock) void k_par_segfold_long(const void* __restrict__ recs, const uint64_t* __restrict__ ks, uint64_t n,
                                                                 const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cuts,
                                                                 uint32_t max_entries, SketchView sk, void* __restrict__ out,
-                                                                const uint32_t* __restrict__ long_list, const uint32_t* __restrict__ n_long) {
+                                                                const uint32_t* __restrict__ long_list, const uint32_t* __restrict__ n_long, uint32_t long_cap) {
     const int lane = threadIdx.x & 63;
     const uint32_t waves = gridDim.x * (kParBlock / 64);
-    const uint32_t count = *n_long;
+    const uint32_t count = *n_long < long_cap ? *n_long : long_cap;  // (what did not fit was folded by k_par_segfold's own lanes)
     for (uint32_t e = blockIdx.x * (kParBlock / 64) + (threadIdx.x >> 6); e < count; e += waves) {
         const uint64_t p = long_list[e];
         const uint64_t key = ks[p];
         const uint32_t i = key_index(key);
         const uint32_t ps = pos[i];
         const uint64_t limit = (key & kHashMask) | (uint64_t)cuts[ps / max_entries + 1];
-        uint64_t lo = p + 1, hi = n;                                  // first position in (p, n] whose key is >= limit
-        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ks[mid] < limit) lo = mid + 1; else hi = mid; }
-        const uint64_t end = lo;
+        const uint64_t end = seg_end(ks, n, p, limit);
         Rec head;
         load_record(recs, i, head);
         head.canonicalize();
         uint64_t w[5];
         head.key_words(w);
         SegAcc a;
-        a.clear();
-        for (uint64_t q = p + lane; q < end; q += 64) {
-            const uint32_t i2 = key_index(ks[q]);
-            Rec r;
-            load_record_head(recs, i2, r);
-            r.d[9] &= 0x00ffffffu;
-            uint64_t w2[5];
-            r.key_words(w2);
-            if (par_same_key(w, w2)) a.add(r, i2);
-        }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            SegAcc o;
-            o.bytes = shfl_xor_u64(a.bytes, m); o.end = shfl_xor_u64(a.end, m); o.start_inv = shfl_xor_u64(a.start_inv, m);
-            o.eth_tag = shfl_xor_u64(a.eth_tag, m); o.dscp_tag = shfl_xor_u64(a.dscp_tag, m); o.samp_tag = shfl_xor_u64(a.samp_tag, m);
-            o.smac = shfl_xor_u64(a.smac, m); o.dmac = shfl_xor_u64(a.dmac, m);
-            o.packets = (uint32_t)__shfl_xor((int)a.packets, m); o.flags = (uint32_t)__shfl_xor((int)a.flags, m);
-            o.smac_at = (uint32_t)__shfl_xor((int)a.smac_at, m); o.dmac_at = (uint32_t)__shfl_xor((int)a.dmac_at, m);
-            a.combine(o);
-        }
+        seg_gather(recs, ks, p + lane, end, 64, w, a);
         if (lane == 0) {
             a.apply(head);
             if (SKETCH) sketch_add(sk, w, a.bytes);
             store_record(out, ps, head);
         }
+    }
+}
+
+// One workgroup of kHugeBlock lanes per segment of more than kSegHuge positions: its sixteen waves take the positions 1024 at a
+// time, their partials meet in LDS, lane 0 combines them (SegAcc is order-free: the records' indices decide "first" and "last").
+template <bool SKETCH>
+__global__ __launch_bounds__(kHugeBlock) void k_par_segfold_huge(const void* __restrict__ recs, const uint64_t* __restrict__ ks, uint64_t n,
+                                                                 const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cuts,
+                                                                 uint32_t max_entries, SketchView sk, void* __restrict__ out,
+                                                                 const uint32_t* __restrict__ huge_list, const uint32_t* __restrict__ n_huge) {
+    __shared__ SegAcc part[kHugeBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t count = *n_huge < kHugeCap ? *n_huge : kHugeCap;
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const uint64_t p = huge_list[e];
+        const uint64_t key = ks[p];
+        const uint32_t i = key_index(key);
+        const uint32_t ps = pos[i];
+        const uint64_t limit = (key & kHashMask) | (uint64_t)cuts[ps / max_entries + 1];
+        const uint64_t end = seg_end(ks, n, p, limit);
+        Rec head;
+        load_record(recs, i, head);
+        head.canonicalize();
+        uint64_t w[5];
+        head.key_words(w);
+        SegAcc a;
+        seg_gather(recs, ks, p + (uint64_t)tid, end, kHugeBlock, w, a);
+        if (lane == 0) part[wv] = a;
+        __syncthreads();
+        if (tid == 0) {
+            for (int q = 1; q < kHugeBlock / 64; q++) a.combine(part[q]);
+            a.apply(head);
+            if (SKETCH) sketch_add(sk, w, a.bytes);
+            store_record(out, ps, head);
+        }
+        __syncthreads();                                              // part[] is read before the next segment rewrites it
     }
 }
 
@@ -707,27 +861,37 @@ uint64_t par_walk_blocks(uint64_t n) { return (((n + kCutSpan - 1) / kCutSpan + 
 uint64_t par_prev_entries(uint64_t n) { return (par_walk_blocks(n) + 4) * kCutSpan; }
 int32_t par_prev_pad_value() { return kCutNever; }
 
+uint64_t par_rank_tiles(uint64_t records) { return (records + kRankTile - 1) / kRankTile; }
+
 // The complete epochs [t_lo, t_hi) of the middle (epoch t = records [cuts[t], cuts[t + 1]); i_lo = cuts[t_lo], i_hi = cuts[t_hi]):
 // positions, then both folds. d_out: where the FIRST middle epoch's eviction begins (epoch t goes to d_out + t * max_entries records).
-// d_long: room for n / kSegShort + 1 positions; *d_n_long is zeroed here (in stream order); *d_bad accumulates.
+// d_long: room for long_cap positions, d_huge: for par_huge_cap(); d_n_long: two counters; d_tiles: par_rank_tiles(i_hi - i_lo) counters; *d_n_long is zeroed here (in stream order);
+// *d_bad accumulates.
 hipError_t launch_par_middle(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, const int32_t* d_prev, const uint32_t* d_cuts,
                              uint32_t t_lo, uint32_t t_hi, uint32_t i_lo, uint32_t i_hi, uint32_t max_entries, const SketchView& sk, uint32_t* d_pos,
-                             void* d_out, uint32_t* d_long, uint32_t* d_n_long, uint32_t* d_bad, hipStream_t s) {
-    if (t_hi <= t_lo) return hipSuccess;
+                             void* d_out, uint32_t* d_long, uint32_t long_cap, uint32_t* d_huge, uint32_t* d_tiles, uint32_t* d_n_long, uint32_t* d_bad, hipStream_t s) {
+    if (t_hi <= t_lo || i_hi <= i_lo) return hipSuccess;
     const uint32_t n_mid = t_hi - t_lo;
-    hipError_t e = hipMemsetAsync(d_n_long, 0, sizeof(uint32_t), s);
+    hipError_t e = hipMemsetAsync(d_n_long, 0, 2 * sizeof(uint32_t), s);    // [0] long segments listed, [1] huge ones
+    uint32_t* d_n_huge = d_n_long + 1;
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_par_rank, dim3(n_mid < 65535u ? n_mid : 65535u), dim3(kParBlock), 0, s, d_prev, d_cuts, t_lo, t_hi, max_entries, d_pos, d_bad);
+    const uint32_t n_tiles = (uint32_t)par_rank_tiles(i_hi - i_lo);
+    hipLaunchKernelGGL(k_par_rank_count, dim3(n_tiles), dim3(kParBlock), 0, s, d_prev, d_cuts, t_lo, t_hi, i_lo, i_hi, d_tiles);
+    hipLaunchKernelGGL(k_par_rank_scan, dim3(1), dim3(1024), 0, s, d_tiles, n_tiles, n_mid * max_entries, d_bad);
+    hipLaunchKernelGGL(k_par_rank_write, dim3(n_tiles), dim3(kParBlock), 0, s, d_prev, d_cuts, t_lo, t_hi, i_lo, i_hi, max_entries, (const uint32_t*)d_tiles, d_pos, d_bad);
     if (sk.flags) {
-        hipLaunchKernelGGL(k_par_segfold<true>, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, d_long, d_n_long, i_lo, i_hi);
-        hipLaunchKernelGGL(k_par_segfold_long<true>, dim3(2048), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_long, (const uint32_t*)d_n_long);
+        hipLaunchKernelGGL(k_par_segfold<true>, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, d_long, d_n_long, long_cap, d_huge, d_n_huge, i_lo, i_hi);
+        hipLaunchKernelGGL(k_par_segfold_huge<true>, dim3(256), dim3(kHugeBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_huge, (const uint32_t*)d_n_huge);
+        hipLaunchKernelGGL(k_par_segfold_long<true>, dim3(2048), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_long, (const uint32_t*)d_n_long, long_cap);
     } else {
-        hipLaunchKernelGGL(k_par_segfold<false>, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, d_long, d_n_long, i_lo, i_hi);
-        hipLaunchKernelGGL(k_par_segfold_long<false>, dim3(2048), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_long, (const uint32_t*)d_n_long);
+        hipLaunchKernelGGL(k_par_segfold<false>, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, d_long, d_n_long, long_cap, d_huge, d_n_huge, i_lo, i_hi);
+        hipLaunchKernelGGL(k_par_segfold_huge<false>, dim3(256), dim3(kHugeBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_huge, (const uint32_t*)d_n_huge);
+        hipLaunchKernelGGL(k_par_segfold_long<false>, dim3(2048), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_long, (const uint32_t*)d_n_long, long_cap);
     }
     return hipGetLastError();
 }
 uint32_t par_seg_short() { return kSegShort; }
+uint32_t par_huge_cap() { return kHugeCap; }
 
 }  // namespace nfagg

@@ -173,11 +173,13 @@ uint64_t par_prev_entries(uint64_t n);
 int32_t par_prev_pad_value();
 hipError_t launch_par_middle(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, const int32_t* d_prev, const uint32_t* d_cuts,
                              uint32_t t_lo, uint32_t t_hi, uint32_t i_lo, uint32_t i_hi, uint32_t max_entries, const SketchView& sk, uint32_t* d_pos,
-                             void* d_out, uint32_t* d_long, uint32_t* d_n_long, uint32_t* d_bad, hipStream_t s);
+                             void* d_out, uint32_t* d_long, uint32_t long_cap, uint32_t* d_huge, uint32_t* d_tiles, uint32_t* d_n_long, uint32_t* d_bad, hipStream_t s);
 uint32_t par_seg_short();
+uint32_t par_huge_cap();
+uint64_t par_rank_tiles(uint64_t records);
 // Kernel-dedup mode: nfagg_dedup.hip (direct: a claim pass, then a fold pass) / nfagg_dedup_cached.hip (one streaming pass + partitions).
 hipError_t launch_ingest_dedup(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, hipStream_t s);
-hipError_t launch_ingest_dedup_cached(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base, int variant, hipStream_t s);
+hipError_t launch_ingest_dedup_cached(const TableView& t, const SketchView& sk, const void* d_records, uint64_t n, uint64_t seq_base, int variant, hipStream_t s);
 hipError_t launch_evict_dedup(const TableView& t, uint64_t n_live, uint64_t seq_limit, void* d_out, hipStream_t s);
 // Careful path, phase A: claim slots only; writes the slot index of every record.
 hipError_t launch_claim(const TableView& t, const void* d_records, uint64_t n, uint64_t seq_base,

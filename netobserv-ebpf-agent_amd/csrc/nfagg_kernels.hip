@@ -317,6 +317,7 @@ static bool takes_direct(int variant, uint64_t n, uint32_t sketch_flags) {
 static bool dedup_takes_cached(int variant, uint64_t n) { return !(variant == 1 || (variant != 10 && (variant < 12 || variant > 16) && n < kDedupCachedMinBatch)); }
 bool ingest_needs_spill(int mode, int variant, uint64_t n) { return mode == 0 ? takes_two_pass(variant, n) : dedup_takes_cached(variant, n); }
 bool ingest_fuses_sketches(int mode, int variant, uint64_t n, uint32_t sketch_flags) {
+    if (mode == 1) return dedup_takes_cached(variant, n) && !(variant >= 13 && variant <= 15);   // the partition pass's flushes feed them (nfagg_dedup_cached.hip); 13-15: its timing ablations
     return mode == 0 && !takes_direct(variant, n, sketch_flags) && variant != 6 && variant != 8 && variant != 9 && (variant < 20 || variant == 30);
 }
 
@@ -325,7 +326,7 @@ hipError_t launch_ingest(const TableView& t, const SketchView& sk, const void* d
     if (n == 0) return hipSuccess;
     if (mode == 1) {   // NFAGG_MODE_KERNEL_DEDUP: LDS-cached passes; direct per-record passes for small batches (variant 1: always, 10: never)
         if (!dedup_takes_cached(variant, n)) return launch_ingest_dedup(t, d_records, n, seq_base, s);
-        return launch_ingest_dedup_cached(t, d_records, n, seq_base, variant, s);
+        return launch_ingest_dedup_cached(t, sk, d_records, n, seq_base, variant, s);
     }
     // 0 (default): by batch size (see kDirectMaxBatch / kPartMinBatch above) — direct kernel, single-pass cached kernel
     // (what variant 7 always runs), two-pass partitioned fold (nfagg_ingest_part.hip; 8/9 = its phase-timing builds).

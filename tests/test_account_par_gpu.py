@@ -121,6 +121,60 @@ def test_flows_that_share_their_key_hash(nf, O, n_colliding, max_entries, hot, v
             assert st.account_epochs_first >= 1 and st.account_declined == 0 and st.account_chain == 0
 
 
+@pytest.mark.parametrize("max_entries,keys,n,batches", [
+    (10_000, 1_000_000, 3_000_000, None),                  # scripts/agent.yml:35-36 deploys CACHE_MAX_FLOWS = 10 000
+    (40_000, 1_000_000, 3_000_000, None),                  # the first size beyond the kernel chain's (32 768)
+    (100_000, 1_000_000, 4_000_000, None),                 # pkg/flow/tracer_map_bench_test.go:64-111 brackets 1 k / 10 k / 100 k
+    (100_000, 1_000_000, 4_000_000, [1_048_576] * 4),      # ... in calls of the shim's batch size: an epoch spans two calls
+    (100_000, 300_000, 2_500_000, [131_072, 50_000, 400_000, 7, 900_000, 2_000_000]),   # calls on both sides of the path's entry bar
+    (250_000, 1_000_000, 4_000_000, None),
+    (100_000, 1_000_000, 6_000_000, [6_000_000, 1]),       # hot=700 below: segments of more than 4096 records (a workgroup per segment)
+    (100_000, 60_000, 1_000_000, None),                    # a map that never fills
+])
+def test_table_sizes_the_reference_benchmarks_and_deploys(nf, O, max_entries, keys, n, batches):
+    """CACHE_MAX_FLOWS beyond the kernel chain's 32 768: the epochs are found first for every call of at least 128 Ki records that
+    may fill the map (round 5 sent these sizes through the optimistic fold of nfagg_ingest: fold, find the split, roll back, fold
+    again). Epochs of ~600 k records: the ranking runs over tiles of the call, not one workgroup per epoch."""
+    recs = _stream(O, n, keys, seed=11 + max_entries, hot=700 if n == 6_000_000 else 0)
+    with nf.FlowTable(max_entries=max_entries) as tab:
+        n_ev = _check(nf, O, tab, recs, max_entries, batches or [n])
+        st = tab.stats()
+        assert st.records_ingested == n and st.evictions[nf.REASON_FULL] == n_ev - 1
+        if keys > 2 * max_entries:
+            assert n_ev >= 2 and st.account_epochs_first >= 1 and st.account_chain == 0
+
+
+def _collision_runs_stream(O, runs=12, per_run=2_000, max_entries=9_000):
+    """lead (so that epochs END before the crafted part: only complete epochs are segment-folded) + `runs` runs of `per_run` crafted
+    flows with one key hash per run, every flow twice: [first occurrences][second occurrences] — no record has more than
+    2 x per_run < 4096 records of other flows between itself and its previous occurrence (the link search's bound) — + filler."""
+    rng = np.random.default_rng(77)
+    lead = _stream(O, 40_000, 40_000, seed=124)
+    body = _stream(O, runs * per_run * 2, 50_000, seed=123)
+    ids = np.ascontiguousarray(body["id"]).view(np.uint64).reshape(len(body), 5).copy()
+    at = 0
+    for r in range(runs):
+        crafted = _colliding_keys(rng, per_run)
+        for rep in range(2):
+            ids[at:at + per_run] = crafted[rng.permutation(per_run)]
+            at += per_run
+    body.view(np.uint8).reshape(len(body), 144)[:, :40] = ids.view(np.uint8).reshape(len(body), 40)
+    tail = _stream(O, 40_000, 40_000, seed=125)
+    return np.concatenate([lead, body, tail]), max_entries
+
+
+def test_many_runs_of_flows_that_share_their_key_hash(nf, O):
+    """Several runs of crafted flows with one key hash each, one record per flow and epoch on average: every head with 16 positions
+    of its run behind it is listed as a long segment — about G entries from G records per run, more than the list of long segments
+    was sized for (call / 16) when the runs together exceed 1/16 of the call. The list is bounded now: what does not fit is folded
+    by the listing lane itself (round-5 advisor finding: an out-of-bounds device write by construction)."""
+    recs, max_entries = _collision_runs_stream(O)
+    with nf.FlowTable(max_entries=max_entries) as tab:
+        _check(nf, O, tab, recs, max_entries, [len(recs)])
+        st = tab.stats()
+        assert st.account_epochs_first >= 1 and st.account_declined == 0
+
+
 def test_device_resident_call_and_small_output_room(nf, O):
     import torch
     max_entries = 2000

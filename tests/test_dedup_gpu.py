@@ -113,7 +113,7 @@ def test_dedup_sharded(nf, O, n_shards, ingest_variant):
 
 
 def test_dedup_with_sketches(nf, O):
-    """Sketches run as their own kernel in dedup mode and see every record."""
+    """Small batch (the direct kernels): the sketches run as their own kernel and see every record."""
     recs = dedup_stream(O, 20000, seed=9, n_keys=300, style=1)
     with nf.FlowTable(max_entries=4096, mode=nf.MODE_KERNEL_DEDUP, sketches=nf.SKETCH_CM | nf.SKETCH_HLL) as tab:
         assert tab.ingest(recs.view(nf.FLOW_RECORD)) == (nf.OK, len(recs))
@@ -123,6 +123,40 @@ def test_dedup_with_sketches(nf, O):
     cs, _, _, hd = O.sketches(recs)
     assert np.array_equal(cm, cs) and np.array_equal(hll, hd)
     assert_records_equal(got, O.run_accounter(recs, 4096, mode=1)[0][1])
+
+
+@pytest.mark.parametrize("style,hot,keys,log2_slots,variant,batch,n_shards", [
+    (1, 0, 60_000, 0, 0, 1 << 30, 1), (2, 900, 60_000, 0, 0, 1 << 30, 1), (0, 0, 3_000, 0, 10, 70_001, 1), (3, 0, 60_000, 21, 0, 200_000, 1),
+    (2, 0, 600_000, 22, 0, 1 << 30, 1),      # more sub-flows than the partitions' caches hold: retry rounds, each flushing its own entries
+    (2, 0, 600_000, 22, 16, 1 << 30, 1),     # ... sorted first
+    (1, 500, 60_000, 0, 12, 1 << 30, 1),     # no retry rounds: what the first cache cannot take is folded item by item
+    (2, 0, 60_000, 0, 0, 1 << 30, 4),        # a shard filter: the sketches see the shard's records only
+])
+def test_dedup_sketches_fused_into_the_partition_flushes(nf, O, style, hot, keys, log2_slots, variant, batch, n_shards):
+    """The streaming + partition passes feed the sketches themselves — one contribution per cache entry at its flush (round 5: a
+    second pass over the batch, k_sketch_update: 8.1 of the 14.3 ms of a configs[4] step). The sketches count EVERY record's bytes
+    (oracle/nfagg_oracle.c orc_sketch_ingest has no mode), also the ones the dedup merge does not count
+    (bpf/flows.c:104-125: a record on another interface than the flow's first only moves end and flags): a cache entry's byte sum
+    is the plain sum of its records — the counted / side decision falls at the merge. Count-Min counters, HLL registers and the
+    records themselves, bit for bit; in one call and in several; grouped and two-phase flushes (tables with deferred claims)."""
+    n = 900_000
+    th = O.zipf_thresholds(keys, 1.1)
+    recs = dedup_stream(O, n, seed=40 + style, n_keys=keys, thresholds=th, hot_permille=hot, style=style)
+    view = recs.view(nf.FLOW_RECORD)
+    kw = dict(table_log2_slots=log2_slots) if log2_slots else {}
+    got, cms, hls = [], [], []
+    for shard in range(n_shards):
+        with nf.FlowTable(max_entries=1 << 20, mode=nf.MODE_KERNEL_DEDUP, sketches=nf.SKETCH_CM | nf.SKETCH_HLL, cm_log2_width=14, hll_p=10,
+                          ingest_variant=variant, n_shards=n_shards, shard_id=shard, **kw) as tab:
+            for lo in range(0, n, batch):
+                assert tab.ingest(view[lo:lo + batch]) == (nf.OK, len(view[lo:lo + batch]))
+            cms.append([tab.sketch_snapshot(nf.CM_SRC), tab.sketch_snapshot(nf.CM_DST)])
+            hls.append([tab.sketch_snapshot(nf.HLL_SRC), tab.sketch_snapshot(nf.HLL_DST)])
+            got.append(tab.evict())
+    cs, cd, hs, hd = O.sketches(recs, 4, 14, 10)
+    assert np.array_equal(sum(c[0] for c in cms), cs) and np.array_equal(sum(c[1] for c in cms), cd)
+    assert np.array_equal(np.maximum.reduce([h[0] for h in hls]), hs) and np.array_equal(np.maximum.reduce([h[1] for h in hls]), hd)
+    assert_records_equal(nf.sort_by_key(np.concatenate(got)), O.run_accounter(recs, 1 << 21, mode=1)[0][1])
 
 
 @pytest.mark.parametrize("style", [0, 1, 2, 3])

@@ -4,7 +4,7 @@ restated step by step in numpy and checked against the oracle's Accounter — th
   sort keys    (top 40 bits of the key hash) << 24 | index, sorted as 64-bit numbers        k_par_hash + the radix sort
   links        prev(i) = nearest position to the left with the same hash bits AND the same key   k_par_links
   cut walk     prev[] streamed in aligned blocks, the epochs walked over the resident block       k_par_cuts
-  ranks        position of every new flow among its epoch's new flows, in arrival order           k_par_rank
+  ranks        position of every new flow among its epoch's new flows, in arrival order           k_par_rank_count / _scan / _write
   segments     [p, first position whose key reaches (hash bits, end of the epoch)) less the other flows with these hash bits,
                folded in arrival order by AccumulateBase (pkg/model/flow_content.go:28-61)         k_par_segfold[_long]
 
@@ -88,13 +88,27 @@ def cut_walk(prev, max_entries, live0, max_cuts, lanes, per=16):
     return cuts, before
 
 
-def ranks(prev, cuts, max_entries):
+def ranks(prev, cuts, max_entries, tile=64):
+    """k_par_rank_count / _scan / _write: ONE running count of the heads over tiles of the records [cuts[0], cuts[-1]) — every
+    complete epoch holds exactly max_entries heads, so t * max_entries + (heads of epoch t before i) = heads in [cuts[0], i).
+    The check that makes that a fact: the first record of every epoch is a head at position t * max_entries, and the total."""
     pos = np.full(len(prev), NONE, dtype=np.int64)
-    for t in range(len(cuts) - 1):
-        s, e = cuts[t], cuts[t + 1]
-        head = prev[s:e] < s
-        assert int(head.sum()) == max_entries                       # how the epoch's end was found
-        pos[s:e][head] = t * max_entries + np.arange(int(head.sum()))
+    i_lo, i_hi = cuts[0], cuts[-1]
+    cuts_a = np.asarray(cuts, dtype=np.int64)
+    idx = np.arange(i_lo, i_hi)
+    t_of = np.searchsorted(cuts_a, idx, side="right") - 1          # par_epoch_of: the largest t with cuts[t] <= i
+    head = prev[idx] < cuts_a[t_of]
+    n_tiles = (len(idx) + tile - 1) // tile
+    tile_cnt = np.array([int(head[k * tile:(k + 1) * tile].sum()) for k in range(n_tiles)], dtype=np.int64)
+    tile_off = np.concatenate([[0], np.cumsum(tile_cnt)[:-1]]) if n_tiles else tile_cnt
+    assert int(tile_cnt.sum()) == (len(cuts) - 1) * max_entries      # k_par_rank_scan: *bad = 2
+    for k in range(n_tiles):
+        h = head[k * tile:(k + 1) * tile]
+        p = tile_off[k] + np.cumsum(h) - h
+        sl = idx[k * tile:(k + 1) * tile]
+        pos[sl[h]] = p[h]
+        first = sl == cuts_a[t_of[k * tile:(k + 1) * tile]]          # k_par_rank_write: *bad = 1
+        assert h[first].all() and (p[first] == t_of[k * tile:(k + 1) * tile][first] * max_entries).all()
     return pos
 
 

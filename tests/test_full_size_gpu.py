@@ -145,7 +145,8 @@ def test_configs4_at_size_eight_ranks_dedup_local_fold_rehearsed_on_one_gpu(nf, 
     """configs[4] as BASELINE.json writes it — "adversarial 90 % single-hot-flow stream, dedup on, 8 GPU" — at 100 M records,
     rehearsed on ONE GPU: 8 kernel-dedup handles created with local_fold (sub-flow tables) stand for the ranks of
     `bench.py --gpus 8 --dedup --hot-permille 900`; rank r folds the contiguous slice [12.5 M r, 12.5 M (r + 1)) of ONE stream whose
-    hot flow alternates over two interfaces (stream variant 2) with job-global sequence numbers, then the tick: sub-flow partials
+    hot flow alternates over two interfaces (stream variant 2) with job-global sequence numbers, CM + HLL on, then the tick: the
+    sketch arrays summed / maxed over the ranks (bit-exact vs the oracle's over all records, estimates within 1 ULP), sub-flow partials
     (256 bytes) grouped by the owner of their FLOW, device-to-device exchange, merge, join, evict owned. Every rank folds ~11 M
     records of the hot flow; which interface is counted is decided by the rank that holds the stream's first record. The union
     must be bit-identical to ONE kernel-dedup table (bpf/flows.c:76-143; the oracle in mode 1, pinned to oracle/_ref)."""
@@ -156,11 +157,30 @@ def test_configs4_at_size_eight_ranks_dedup_local_fold_rehearsed_on_one_gpu(nf, 
     host = d.cpu().numpy()
     want = O.run_accounter(host, 1 << 22, mode=1)[0][1]
     assert 400_000 < len(want) <= keys and (want["metrics"]["nb_observed_intf"] >= 1).any()
-    tabs = [nf.FlowTable(max_entries=1 << 21, mode=nf.MODE_KERNEL_DEDUP, local_fold=True) for _ in range(n_ranks)]
+    # sketches ON, as `bench.py --gpus N --dedup` runs it (bench.py: sketches default to on at N > 1): fed by the partition pass's
+    # flushes of the kernel-dedup fold (csrc/nfagg_dedup_cached.hip) — every record's bytes, counted by the merge or not
+    sk = nf.SKETCH_CM | nf.SKETCH_HLL
+    tabs = [nf.FlowTable(max_entries=1 << 21, mode=nf.MODE_KERNEL_DEDUP, local_fold=True, sketches=sk, profile=True) for _ in range(n_ranks)]
     try:
         for r, tab in enumerate(tabs):
             tab.set_sequence(r * per)
             assert tab.ingest_device(d.data_ptr() + r * per * 144, per) == (nf.OK, per)
+        assert all(t.stats().sketch_launches == 0 for t in tabs), "the sketches are fused into the fold: no second pass over the batch"
+        # the per-tick collective, rehearsed: CM sum / HLL max over the ranks' arrays = the oracle's over all records
+        cm_s, cm_d, hs, hd = O.sketches(host)
+        for which, ref in ((nf.CM_SRC, cm_s), (nf.CM_DST, cm_d)):
+            acc = np.zeros_like(ref)
+            for t in tabs:
+                acc += t.sketch_snapshot(which)
+            assert np.array_equal(acc, ref)
+        for which, ref in ((nf.HLL_SRC, hs), (nf.HLL_DST, hd)):
+            acc = np.zeros_like(ref)
+            for t in tabs:
+                acc = np.maximum(acc, t.sketch_snapshot(which))
+            assert np.array_equal(acc, ref)
+            hist = np.bincount(acc, minlength=65).astype(np.uint32)
+            est, want_est = nf.hll_estimate_from_histogram(hist, 14), O.hll_estimate(ref, 14)
+            assert abs(est - want_est) <= np.spacing(want_est)
         seen = [len(t) for t in tabs]                                     # (flow, interface) pairs per rank
         pb = tabs[0].partial_bytes
         assert pb == 256
@@ -202,10 +222,12 @@ def _key_hash64(torch, rec):
     return h
 
 
-def test_configs3_at_its_full_size_one_billion_records_by_properties(nf, torch):
+def test_configs3_at_its_full_size_one_billion_records(nf, O, torch):
     """configs[3] at BASELINE.json's OWN size — 1 B records (144 GB, generated on the device: SURVEY §8(d) config 4, seed 4),
-    10 M flows — on ONE GPU. The oracle cannot follow at this size in a test's time (90 s of one core, 144 GB through the host), so
-    parity rests on what the 100 M-record tests above pin bit by bit, and this test checks what does not depend on size:
+    10 M flows — on ONE GPU, compared with the ORACLE bit for bit: the device-generated records come down in 50 M-record chunks
+    into ONE incremental oracle Accounter (pkg/flow/account.go:58-124 restated; every chunk pre-folded on the host's cores by
+    orc_local_fold_mt, then merged in arrival order), and the union of the eight ranks' evictions must be that Accounter's closing
+    eviction. Beside it, what does not depend on size:
       * two independent routes through the library deliver the SAME evictions, bit for bit: (A) one handle, eight calls of
         125 M records; (B) eight unsharded handles standing for the ranks of `bench.py --gpus 8`, each folding its 125 M-record
         slice with job-global sequence numbers, then partials by owner, merge, evict owned (the route of the test above);
@@ -222,6 +244,41 @@ def test_configs3_at_its_full_size_one_billion_records_by_properties(nf, torch):
     th = nf.synth.zipf_thresholds(keys, 1.1)
     d = dev_stream(torch, nf.synth, n, seed=4, n_keys=keys, thresholds=th, variant=1)
     rec = d.view(torch.int64).view(n, 18)
+    # ---- the oracle: ONE Accounter over the whole stream (pkg/flow/account.go:58-124 restated), on a host thread of its own while
+    # the GPU routes run (ctypes releases the GIL). Chunk by chunk: the chunk's records come down, orc_local_fold_mt folds them on
+    # the host's cores (bit-exact against the one-core Accounter: tests/test_oracle_mt.py) into one record per flow, and those are
+    # folded into the Accounter in chunk order = arrival order — AccumulateBase is its own ordered merge of partials (sums, OR,
+    # min / max, last-non-zero, first-non-zero, the first record's fields: pkg/model/flow_content.go:28-61). The one-core oracle
+    # alone would take ~3 min for 1 B records; with a single host core this does too, and is still right.
+    import os
+    import threading
+    oracle = {}
+    CH = 50_000_000
+    T = max(1, min(64, (os.cpu_count() or 2) // 2))
+
+    def _oracle_worker():
+        try:
+            acc = O.Accounter(1 << 25, 0)
+            took = 0
+            for a in range(0, n, CH):
+                b = min(n, a + CH)
+                host = d[a * 144:b * 144].cpu().numpy()
+                if T >= 2:
+                    folded, n_fl, _, _, _, flows = O.local_fold_mt(host, T, 1 << 25, want_flows=True)
+                    assert folded == b - a and n_fl == len(flows)
+                    assert acc.ingest(flows) == len(flows), "the oracle's map filled up"
+                else:
+                    assert acc.ingest(host) == b - a
+                took += b - a
+                del host
+            oracle["records"] = took
+            oracle["flows"] = acc.evict()                               # sorted by key
+            acc.close()
+        except BaseException as exc:                                    # reported by the main thread
+            oracle["error"] = exc
+
+    worker = threading.Thread(target=_oracle_worker, daemon=True)
+    worker.start()
     # ---- what the stream says
     h = _key_hash64(torch, rec)
     n_distinct = int(torch.unique(h).numel())
@@ -300,3 +357,10 @@ def test_configs3_at_its_full_size_one_billion_records_by_properties(nf, torch):
     assert torch.equal(a, b), "1 B records: one handle and eight ranks + merge disagree in %d of %d flows" % (int((a != b).any(dim=1).sum()), n_distinct)
     got = properties(ev_a)
     assert got == (want_bytes, want_packets, want_flags, want_end, want_start), (got, (want_bytes, want_packets, want_flags, want_end, want_start))
+    # ---- ... and the oracle's Accounter over the same 1 B records: every evicted flow, bit for bit
+    worker.join()
+    if "error" in oracle:
+        raise oracle["error"]
+    assert oracle["records"] == n and len(oracle["flows"]) == n_distinct
+    got_b = nf.sort_by_key(ev_b.cpu().numpy().view(np.uint8).reshape(-1).view(nf.FLOW_RECORD))
+    assert_records_equal(got_b, oracle["flows"], "configs[3] at 1 B records: union of 8 ranks vs ONE oracle Accounter")
