@@ -190,4 +190,6 @@ def load_synth():
     s.nfagg_synth_shard_population.argtypes = [u64, C.c_uint32, C.c_uint32, _vp]
     s.nfagg_synth_stream_host.restype = None
     s.nfagg_synth_stream_host.argtypes = [_vp, u64, u64, u64, u64, _vp, C.c_uint32, C.c_uint32, _vp]
+    s.nfagg_synth_yardstick.restype = C.c_double
+    s.nfagg_synth_yardstick.argtypes = [C.c_int, _vp, _vp, u64, _vp, C.c_int]
     return s

@@ -26,6 +26,7 @@
 //   k_par_segfold   one lane per segment of at most kSegShort records: the records gathered in arrival order and folded
 //                   SEQUENTIALLY, literally as the reference does; the folded record goes straight to its place in the caller's buffer
 //   k_par_segfold_long   one wave per longer segment (the hot flows): an order-free partial per lane, combined across the wave
+//   k_par_huge_chunks / k_par_huge_combine   segments of more than 4096 records (long epochs): a wave per chunk of 2048, then the chunks' partials
 //
 // The first epoch of the call (it continues what the table holds) and the last, incomplete one (it stays live) go through the
 // ordinary table fold; everything in between never touches a hash table.
@@ -41,9 +42,10 @@ constexpr int kLinkSearch = 4096;                                     // records
 constexpr int kIdxBits = 24;                                          // a launch takes at most 2^24 records: the index's share of a sort key
 constexpr uint64_t kIdxMask = (1ull << kIdxBits) - 1ull, kHashMask = ~kIdxMask;   // ... and the key hash's: its top 40 bits
 constexpr uint32_t kSegShort = 16;                                    // records per segment the one-lane fold takes
-constexpr uint32_t kSegHuge = 4096;                                   // positions per segment beyond which a whole workgroup folds it (one wave up to here)
+constexpr uint32_t kSegHuge = 4096;                                   // positions per segment beyond which it is folded in CHUNKS, a wave per chunk (one wave for the whole segment up to here)
+constexpr uint32_t kHugeChunk = 2048;                                 // positions per chunk
 constexpr uint32_t kHugeCap = 8192;                                   // entries of the list of such segments (disjoint runs of > kSegHuge positions: <= 2^24 / 4097 per launch)
-constexpr int kHugeBlock = 1024;
+constexpr uint32_t kHugeChunkCap = (1u << 24) / kHugeChunk + kHugeCap;   // ... and of their chunks: every segment ends with one partly filled chunk
 
 static inline int par_grid(uint64_t n, int per_block = kParBlock, int cap = 1 << 20) {
     uint64_t g = (n + per_block - 1) / per_block;
@@ -602,6 +604,14 @@ NF_DEV void store_record(void* base, uint64_t i, const Rec& r) {
     for (int k = 0; k < 9; k++) p[k] = make_uint4(r.d[4 * k], r.d[4 * k + 1], r.d[4 * k + 2], r.d[4 * k + 3]);
 }
 
+// the end of the segment that begins at sorted position p: the first position in (p, n] whose sort key reaches `limit` = (hash
+// bits, end of the epoch) — a binary search, the array is sorted
+NF_DEV uint64_t seg_end(const uint64_t* __restrict__ ks, uint64_t n, uint64_t p, uint64_t limit) {
+    uint64_t lo = p + 1, hi = n;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ks[mid] < limit) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
 // One lane per sorted position p whose record i starts a flow in a middle epoch (pos[i] != kParNone). Its segment: the positions
 // from p up to (not including) the first whose sort key reaches (hash bits, first record of the next epoch) — the array is sorted
 // by (hash bits, index), so that is where the flow's records of this epoch end — less the records of other flows with the same
@@ -630,12 +640,26 @@ __global__ __launch_bounds__(kParBlock) void k_par_segfold(const void* __restric
         // in one run, and every head with kSegShort positions of the run behind it lands here — G such flows list ~G segments
         // from G records. Beyond the list's room this lane folds its segment itself, however long the run is: slower, never out
         // of bounds (tests/test_account_par_gpu.py::test_many_runs_of_flows_that_share_their_key_hash).
-        // ... and a whole workgroup a segment of more than kSegHuge positions: the hot flows of a LONG epoch (CACHE_MAX_FLOWS =
-        // 100 000: ~600 k records per epoch, 42 k of them the hottest flow's — 656 dependent gathers for one wave, 1.3 ms on the
-        // critical path of every launch: profiles/r06_account_regimes.txt)
+        // ... and a segment of more than kSegHuge positions goes in chunks of kHugeChunk, a wave per chunk, the chunks' partials
+        // combined afterwards (k_par_huge_chunks / k_par_huge_combine): the hot flows of a LONG epoch (CACHE_MAX_FLOWS = 100 000:
+        // ~600 k records per epoch, 42 k of them the hottest flow's — 656 dependent gathers for one wave, 1.3 ms on the critical
+        // path of every launch; a workgroup of 1024 lanes per segment still took 0.73 ms: profiles/r06_account_regimes.txt).
+        // This lane finds the segment's end (a binary search: these segments are few) and lists the chunks.
         if (p + kSegHuge < n && ks[p + kSegHuge] < limit) {
-            const uint32_t ah = atomicAdd(n_huge, 1u);
-            if (ah < kHugeCap) { huge_list[ah] = (uint32_t)p; return; }
+            const uint64_t end = seg_end(ks, n, p, limit);
+            const uint32_t chunks = (uint32_t)((end - p + kHugeChunk - 1) / kHugeChunk);
+            const uint32_t ah = atomicAdd(&n_huge[0], 1u);
+            if (ah < kHugeCap) {
+                const uint32_t c0 = atomicAdd(&n_huge[1], chunks);
+                if (c0 + chunks <= kHugeChunkCap) {
+                    huge_list[3 * ah] = (uint32_t)p; huge_list[3 * ah + 1] = c0; huge_list[3 * ah + 2] = chunks;
+                    uint32_t* cl = huge_list + 3 * kHugeCap;
+                    for (uint32_t c = 0; c < chunks; c++) cl[c0 + c] = ah;
+                    return;
+                }
+                huge_list[3 * ah] = (uint32_t)p; huge_list[3 * ah + 1] = 0; huge_list[3 * ah + 2] = 0;    // (no room for its chunks — cannot happen within the
+                                                                                                         // caps above — : listed empty, folded as a long segment)
+            }
         }
         const uint32_t at = atomicAdd(n_long, 1u);
         if (at < long_cap) { long_list[at] = (uint32_t)p; return; }
@@ -738,14 +762,6 @@ NF_DEV void seg_gather(const void* __restrict__ recs, const uint64_t* __restrict
     }
 }
 
-// the end of the segment that begins at sorted position p: the first position in (p, n] whose sort key reaches `limit` = (hash
-// bits, end of the epoch) — a binary search, the array is sorted
-NF_DEV uint64_t seg_end(const uint64_t* __restrict__ ks, uint64_t n, uint64_t p, uint64_t limit) {
-    uint64_t lo = p + 1, hi = n;
-    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ks[mid] < limit) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-
 // One wave per listed segment. The lanes take the positions 64 at a time; what they hold is combined with xor-shuffles; lane 0
 // applies it to the first record and stores.
 template <bool SKETCH>
@@ -778,39 +794,102 @@ __global__ __launch_bounds__(kParBlock) void k_par_segfold_long(const void* __re
     }
 }
 
-// One workgroup of kHugeBlock lanes per segment of more than kSegHuge positions: its sixteen waves take the positions 1024 at a
-// time, their partials meet in LDS, lane 0 combines them (SegAcc is order-free: the records' indices decide "first" and "last").
-template <bool SKETCH>
-__global__ __launch_bounds__(kHugeBlock) void k_par_segfold_huge(const void* __restrict__ recs, const uint64_t* __restrict__ ks, uint64_t n,
-                                                                 const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cuts,
-                                                                 uint32_t max_entries, SketchView sk, void* __restrict__ out,
-                                                                 const uint32_t* __restrict__ huge_list, const uint32_t* __restrict__ n_huge) {
-    __shared__ SegAcc part[kHugeBlock / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t count = *n_huge < kHugeCap ? *n_huge : kHugeCap;
-    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
-        const uint64_t p = huge_list[e];
+// The segments of more than kSegHuge positions, in two steps. huge_list: {p, first chunk, chunks} per segment, then (from
+// 3 * kHugeCap on) the segment of every chunk; n_huge[0] segments, n_huge[1] chunks.
+//   k_par_huge_chunks    one wave per chunk of kHugeChunk positions: its order-free partial (SegAcc) to `partials`
+//   k_par_huge_combine   one wave per segment: the chunks' partials combined (order-free), applied to the first record, stored
+struct alignas(16) SegPartial { uint64_t w[12]; };                    // a SegAcc, 96 bytes
+NF_DEV void seg_pack(const SegAcc& a, SegPartial& o) {
+    o.w[0] = a.bytes; o.w[1] = a.end; o.w[2] = a.start_inv; o.w[3] = a.eth_tag; o.w[4] = a.dscp_tag; o.w[5] = a.samp_tag; o.w[6] = a.smac; o.w[7] = a.dmac;
+    o.w[8] = (uint64_t)a.packets | ((uint64_t)a.flags << 32); o.w[9] = (uint64_t)a.smac_at | ((uint64_t)a.dmac_at << 32); o.w[10] = 0; o.w[11] = 0;
+}
+NF_DEV void seg_unpack(const SegPartial& o, SegAcc& a) {
+    a.bytes = o.w[0]; a.end = o.w[1]; a.start_inv = o.w[2]; a.eth_tag = o.w[3]; a.dscp_tag = o.w[4]; a.samp_tag = o.w[5]; a.smac = o.w[6]; a.dmac = o.w[7];
+    a.packets = (uint32_t)o.w[8]; a.flags = (uint32_t)(o.w[8] >> 32); a.smac_at = (uint32_t)o.w[9]; a.dmac_at = (uint32_t)(o.w[9] >> 32);
+}
+NF_DEV void seg_wave_combine(SegAcc& a) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        SegAcc o;
+        o.bytes = shfl_xor_u64(a.bytes, m); o.end = shfl_xor_u64(a.end, m); o.start_inv = shfl_xor_u64(a.start_inv, m);
+        o.eth_tag = shfl_xor_u64(a.eth_tag, m); o.dscp_tag = shfl_xor_u64(a.dscp_tag, m); o.samp_tag = shfl_xor_u64(a.samp_tag, m);
+        o.smac = shfl_xor_u64(a.smac, m); o.dmac = shfl_xor_u64(a.dmac, m);
+        o.packets = (uint32_t)__shfl_xor((int)a.packets, m); o.flags = (uint32_t)__shfl_xor((int)a.flags, m);
+        o.smac_at = (uint32_t)__shfl_xor((int)a.smac_at, m); o.dmac_at = (uint32_t)__shfl_xor((int)a.dmac_at, m);
+        a.combine(o);
+    }
+}
+
+__global__ __launch_bounds__(kParBlock) void k_par_huge_chunks(const void* __restrict__ recs, const uint64_t* __restrict__ ks, uint64_t n,
+                                                               const uint32_t* __restrict__ pos, const uint32_t* __restrict__ cuts, uint32_t max_entries,
+                                                               const uint32_t* __restrict__ huge_list, const uint32_t* __restrict__ n_huge,
+                                                               SegPartial* __restrict__ partials) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * (kParBlock / 64);
+    const uint32_t n_seg = n_huge[0] < kHugeCap ? n_huge[0] : kHugeCap;
+    const uint32_t count = n_huge[1] < kHugeChunkCap ? n_huge[1] : kHugeChunkCap;
+    const uint32_t* chunk_seg = huge_list + 3 * kHugeCap;
+    for (uint32_t c = blockIdx.x * (kParBlock / 64) + (threadIdx.x >> 6); c < count; c += waves) {
+        const uint32_t sg = chunk_seg[c];
+        if (sg >= n_seg) continue;                                    // (wave-uniform)
+        const uint64_t p = huge_list[3 * sg];
+        const uint32_t c0 = huge_list[3 * sg + 1], chunks = huge_list[3 * sg + 2];
+        if (c - c0 >= chunks) continue;                               // a chunk entry of a segment that was listed empty
         const uint64_t key = ks[p];
         const uint32_t i = key_index(key);
-        const uint32_t ps = pos[i];
-        const uint64_t limit = (key & kHashMask) | (uint64_t)cuts[ps / max_entries + 1];
-        const uint64_t end = seg_end(ks, n, p, limit);
-        Rec head;
-        load_record(recs, i, head);
-        head.canonicalize();
+        const uint64_t limit = (key & kHashMask) | (uint64_t)cuts[pos[i] / max_entries + 1];
         uint64_t w[5];
-        head.key_words(w);
+        par_key(recs, i, w);
+        const uint64_t lo = p + (uint64_t)(c - c0) * kHugeChunk;
+        uint64_t hi = lo + kHugeChunk;
+        if (hi > n) hi = n;
+        // the chunk ends where the segment does: the last chunk of a segment stops at the first key that reaches `limit`
+        // (positions are sorted: once a key reaches it, every later one does)
         SegAcc a;
-        seg_gather(recs, ks, p + (uint64_t)tid, end, kHugeBlock, w, a);
-        if (lane == 0) part[wv] = a;
-        __syncthreads();
-        if (tid == 0) {
-            for (int q = 1; q < kHugeBlock / 64; q++) a.combine(part[q]);
+        a.clear();
+        for (uint64_t q = lo + lane; q < hi; q += 64) {
+            const uint64_t k2 = ks[q];
+            if (k2 >= limit) break;
+            const uint32_t i2 = key_index(k2);
+            Rec r;
+            load_record_head(recs, i2, r);
+            r.d[9] &= 0x00ffffffu;
+            uint64_t w2[5];
+            r.key_words(w2);
+            if (par_same_key(w, w2)) a.add(r, i2);
+        }
+        seg_wave_combine(a);
+        if (lane == 0) seg_pack(a, partials[c]);
+    }
+}
+
+template <bool SKETCH>
+__global__ __launch_bounds__(kParBlock) void k_par_huge_combine(const void* __restrict__ recs, const uint64_t* __restrict__ ks,
+                                                                const uint32_t* __restrict__ pos, SketchView sk, void* __restrict__ out,
+                                                                const uint32_t* __restrict__ huge_list, const uint32_t* __restrict__ n_huge,
+                                                                const SegPartial* __restrict__ partials) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * (kParBlock / 64);
+    const uint32_t n_seg = n_huge[0] < kHugeCap ? n_huge[0] : kHugeCap;
+    for (uint32_t sg = blockIdx.x * (kParBlock / 64) + (threadIdx.x >> 6); sg < n_seg; sg += waves) {
+        const uint64_t p = huge_list[3 * sg];
+        const uint32_t c0 = huge_list[3 * sg + 1], chunks = huge_list[3 * sg + 2];
+        if (chunks == 0) continue;
+        const uint32_t i = key_index(ks[p]);
+        SegAcc a;
+        a.clear();
+        for (uint32_t c = lane; c < chunks; c += 64) { SegAcc o; seg_unpack(partials[c0 + c], o); a.combine(o); }
+        seg_wave_combine(a);
+        if (lane == 0) {
+            Rec head;
+            load_record(recs, i, head);
+            head.canonicalize();
+            uint64_t w[5];
+            head.key_words(w);
             a.apply(head);
             if (SKETCH) sketch_add(sk, w, a.bytes);
-            store_record(out, ps, head);
+            store_record(out, pos[i], head);
         }
-        __syncthreads();                                              // part[] is read before the next segment rewrites it
     }
 }
 
@@ -865,15 +944,16 @@ uint64_t par_rank_tiles(uint64_t records) { return (records + kRankTile - 1) / k
 
 // The complete epochs [t_lo, t_hi) of the middle (epoch t = records [cuts[t], cuts[t + 1]); i_lo = cuts[t_lo], i_hi = cuts[t_hi]):
 // positions, then both folds. d_out: where the FIRST middle epoch's eviction begins (epoch t goes to d_out + t * max_entries records).
-// d_long: room for long_cap positions, d_huge: for par_huge_cap(); d_n_long: two counters; d_tiles: par_rank_tiles(i_hi - i_lo) counters; *d_n_long is zeroed here (in stream order);
+// d_long: room for long_cap positions, d_huge: par_huge_cap() words; d_n_long: three counters; d_tiles: par_rank_tiles(i_hi - i_lo) counters; *d_n_long is zeroed here (in stream order);
 // *d_bad accumulates.
 hipError_t launch_par_middle(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, const int32_t* d_prev, const uint32_t* d_cuts,
                              uint32_t t_lo, uint32_t t_hi, uint32_t i_lo, uint32_t i_hi, uint32_t max_entries, const SketchView& sk, uint32_t* d_pos,
                              void* d_out, uint32_t* d_long, uint32_t long_cap, uint32_t* d_huge, uint32_t* d_tiles, uint32_t* d_n_long, uint32_t* d_bad, hipStream_t s) {
     if (t_hi <= t_lo || i_hi <= i_lo) return hipSuccess;
     const uint32_t n_mid = t_hi - t_lo;
-    hipError_t e = hipMemsetAsync(d_n_long, 0, 2 * sizeof(uint32_t), s);    // [0] long segments listed, [1] huge ones
+    hipError_t e = hipMemsetAsync(d_n_long, 0, 3 * sizeof(uint32_t), s);    // [0] long segments listed, [1] huge ones, [2] their chunks
     uint32_t* d_n_huge = d_n_long + 1;
+    SegPartial* d_partials = reinterpret_cast<SegPartial*>(((uintptr_t)(d_huge + 3 * kHugeCap + kHugeChunkCap) + 15u) & ~(uintptr_t)15u);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
     const uint32_t n_tiles = (uint32_t)par_rank_tiles(i_hi - i_lo);
@@ -882,16 +962,18 @@ hipError_t launch_par_middle(const void* d_records, const uint64_t* d_keys_sorte
     hipLaunchKernelGGL(k_par_rank_write, dim3(n_tiles), dim3(kParBlock), 0, s, d_prev, d_cuts, t_lo, t_hi, i_lo, i_hi, max_entries, (const uint32_t*)d_tiles, d_pos, d_bad);
     if (sk.flags) {
         hipLaunchKernelGGL(k_par_segfold<true>, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, d_long, d_n_long, long_cap, d_huge, d_n_huge, i_lo, i_hi);
-        hipLaunchKernelGGL(k_par_segfold_huge<true>, dim3(256), dim3(kHugeBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_huge, (const uint32_t*)d_n_huge);
+        hipLaunchKernelGGL(k_par_huge_chunks, dim3(1024), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, (const uint32_t*)d_huge, (const uint32_t*)d_n_huge, d_partials);
+        hipLaunchKernelGGL(k_par_huge_combine<true>, dim3(64), dim3(kParBlock), 0, s, d_records, d_keys_sorted, (const uint32_t*)d_pos, sk, d_out, (const uint32_t*)d_huge, (const uint32_t*)d_n_huge, (const SegPartial*)d_partials);
         hipLaunchKernelGGL(k_par_segfold_long<true>, dim3(2048), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_long, (const uint32_t*)d_n_long, long_cap);
     } else {
         hipLaunchKernelGGL(k_par_segfold<false>, dim3(par_grid(n)), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, d_long, d_n_long, long_cap, d_huge, d_n_huge, i_lo, i_hi);
-        hipLaunchKernelGGL(k_par_segfold_huge<false>, dim3(256), dim3(kHugeBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_huge, (const uint32_t*)d_n_huge);
+        hipLaunchKernelGGL(k_par_huge_chunks, dim3(1024), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, (const uint32_t*)d_huge, (const uint32_t*)d_n_huge, d_partials);
+        hipLaunchKernelGGL(k_par_huge_combine<false>, dim3(64), dim3(kParBlock), 0, s, d_records, d_keys_sorted, (const uint32_t*)d_pos, sk, d_out, (const uint32_t*)d_huge, (const uint32_t*)d_n_huge, (const SegPartial*)d_partials);
         hipLaunchKernelGGL(k_par_segfold_long<false>, dim3(2048), dim3(kParBlock), 0, s, d_records, d_keys_sorted, n, (const uint32_t*)d_pos, d_cuts, max_entries, sk, d_out, (const uint32_t*)d_long, (const uint32_t*)d_n_long, long_cap);
     }
     return hipGetLastError();
 }
 uint32_t par_seg_short() { return kSegShort; }
-uint32_t par_huge_cap() { return kHugeCap; }
+uint32_t par_huge_cap() { return 3 * kHugeCap + kHugeChunkCap + (uint32_t)(kHugeChunkCap * sizeof(SegPartial) / sizeof(uint32_t)) + 8; }   // words: segment list, chunk list, chunk partials
 
 }  // namespace nfagg

@@ -136,7 +136,54 @@ __global__ __launch_bounds__(256) void k_synth(uint4* __restrict__ out, uint64_t
 
 }  // namespace
 
+// ---- the chip's own yardsticks for bench.py ("confirm with a stream microbench in the same run"): what HBM delivers
+// to kernels shaped like the fold's, measured with HIP events in the run that reports them. Round 5 used torch.Tensor.copy_ (a
+// library blit: 4.8 TB/s) where MI355X_MICROARCH.md measures 6.3 TB/s for a float4 copy kernel.
+//   y_read_records   144-byte records, one per lane and trip, the first 112 bytes as seven 16-byte loads — what pass 1 of the fold
+//                    issues (tools/pmc_calib.hip calib_read_records); whole lines cross the fabric: n x 144 bytes
+//   y_read_stream    a plain 16-byte grid-stride read of the same bytes
+//   y_copy           16 bytes read and 16 written per lane and trip
+__global__ __launch_bounds__(1024) void y_read_records(const uint4* __restrict__ in, uint64_t n, uint64_t* sink) {
+    uint64_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4* p = in + i * 9;
+#pragma unroll
+        for (int k = 0; k < 7; k++) { const uint4 v = p[k]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    }
+    if (acc == 0x123456789abcdefull) *sink = acc;
+}
+__global__ __launch_bounds__(256) void y_read_stream(const uint4* __restrict__ in, uint64_t n16, uint64_t* sink) {
+    uint64_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) { const uint4 v = in[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x123456789abcdefull) *sink = acc;
+}
+__global__ __launch_bounds__(256) void y_copy(const uint4* __restrict__ in, uint4* __restrict__ out, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
 extern "C" {
+
+// which: 0 = y_read_records over `bytes` / 144 records at d_a, 1 = y_read_stream over bytes / 16 units at d_a, 2 = y_copy of bytes / 16 units
+// from d_a to d_b. One untimed pass, then `reps` timed ones between two HIP events on the null stream. Returns the mean milliseconds
+// per pass (< 0: a HIP error). d_sink: 8 bytes of device memory.
+double nfagg_synth_yardstick(int which, const void* d_a, void* d_b, uint64_t bytes, void* d_sink, int reps) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+    auto pass = [&]() {
+        if (which == 0) hipLaunchKernelGGL(y_read_records, dim3(256 * 2), dim3(1024), 0, 0, (const uint4*)d_a, bytes / 144, (uint64_t*)d_sink);
+        else if (which == 1) hipLaunchKernelGGL(y_read_stream, dim3(256 * 16), dim3(256), 0, 0, (const uint4*)d_a, bytes / 16, (uint64_t*)d_sink);
+        else hipLaunchKernelGGL(y_copy, dim3(256 * 16), dim3(256), 0, 0, (const uint4*)d_a, (uint4*)d_b, bytes / 16);
+    };
+    (void)hipGetLastError();
+    pass();
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; r++) pass();
+    hipEventRecord(e1, 0);
+    float ms = -1.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess) ms = -1.f;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return ms < 0.f ? -1.0 : (double)ms / (reps > 0 ? reps : 1);
+}
 
 // Fill d_out[0..n) (device, 16-byte aligned) with records j0..j0+n of the stream.
 // d_thresholds: device table from nfagg_synth_zipf_thresholds (NULL = uniform);

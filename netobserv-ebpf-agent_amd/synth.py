@@ -46,3 +46,12 @@ def stream_device(d_out: int, n, j0=0, seed=1, n_keys=1000, d_thresholds: int = 
                                    hot_permille, variant, C.c_void_p(d_pop_index or None), C.c_void_p(stream or None))
     if rc != 0:
         raise RuntimeError("nfagg_synth_stream launch failed")
+
+
+def yardstick(which: int, d_a: int, d_b: int, nbytes: int, d_sink: int, reps: int = 3) -> float:
+    """Milliseconds per pass of one of the HBM yardstick kernels (nfagg_synth.hip): 0 = records read as the fold reads them (seven
+    16-byte loads of every 144-byte record), 1 = plain 16-byte stream read, 2 = 16-byte copy d_a -> d_b. bench.py's roofline notes."""
+    ms = _lib().nfagg_synth_yardstick(which, C.c_void_p(d_a), C.c_void_p(d_b or None), nbytes, C.c_void_p(d_sink), reps)
+    if ms < 0:
+        raise RuntimeError("yardstick kernel failed")
+    return ms

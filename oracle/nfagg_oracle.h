@@ -120,6 +120,7 @@ size_t orc_acc_ingest_shard(orc_accounter*, const void* records, size_t n, uint3
 /* nfagg_oracle_mt.c: partition-then-fold on T threads (bench.py cpu_baseline.multicore); seconds[0] partition, [1] fold */
 size_t orc_partition_fold_mt(const void* records, size_t n, uint32_t T, uint64_t max_entries, int mode, size_t* flows, double seconds[3]);
 size_t orc_local_fold_mt(const void* records, size_t n, uint32_t T, uint64_t max_entries, size_t* flows, double seconds[3], void* out, size_t out_cap);
+void orc_mt_set_pinning(int on);   /* 1: thread t of orc_local_fold_mt binds to the t-th CPU in NUMA-node order (bench.py's cpu_baseline) */
 /* account.go:102-124 up to NewRecord: all entries as 144-byte records sorted by
  * the 40 key bytes (memcmp), table cleared. Returns the count (writes at most cap). */
 size_t orc_acc_evict(orc_accounter*, void* out, size_t cap);

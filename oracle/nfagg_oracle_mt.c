@@ -12,6 +12,7 @@
 #define _GNU_SOURCE
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -185,6 +186,46 @@ static int lf_upsert(lf_table* t, const orc_flow_id* key, const orc_flow_metrics
     return 1;
 }
 
+/* Thread placement (bench.py's cpu_baseline; round-5 review item 7: the unpinned baseline varied 3.6 x by box and got slower with more
+ * threads). orc_mt_set_pinning(1): thread t of the next runs binds itself to the t-th CPU of the list "node 0's CPUs, node 1's, ..."
+ * (/sys/devices/system/node/node<k>/cpulist, restricted to the process's affinity mask): T threads fill one NUMA node before the next
+ * is touched, and a thread stays where its table's pages were first touched. 0 (default): wherever the scheduler puts them. */
+#include <sched.h>
+static int g_pin = 0;
+static int g_cpu_order[4096];
+static int g_cpu_count = -1;
+void orc_mt_set_pinning(int on) { g_pin = on; }
+static void pin_build(void) {
+    cpu_set_t allowed;
+    g_cpu_count = 0;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    for (int node = 0; node < 64; node++) {
+        char path[96];
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+        FILE* f = fopen(path, "r");
+        if (!f) { if (node == 0) break; else continue; }
+        char buf[4096];
+        if (fgets(buf, sizeof buf, f)) {
+            for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(0, ",\n")) {
+                int a, b;
+                const int k = sscanf(tok, "%d-%d", &a, &b);
+                if (k == 1) b = a;
+                if (k >= 1) for (int c = a; c <= b && g_cpu_count < 4096; c++) if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) g_cpu_order[g_cpu_count++] = c;
+            }
+        }
+        fclose(f);
+    }
+    if (g_cpu_count == 0)                                       /* no NUMA information: the allowed CPUs in numerical order */
+        for (int c = 0; c < CPU_SETSIZE && g_cpu_count < 4096; c++) if (CPU_ISSET(c, &allowed)) g_cpu_order[g_cpu_count++] = c;
+}
+static void pin_self(uint32_t t) {
+    if (!g_pin || g_cpu_count <= 0) return;
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(g_cpu_order[t % (uint32_t)g_cpu_count], &one);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+}
+
 typedef struct lf_job_s {
     const orc_flow_record* recs;
     size_t n;
@@ -199,6 +240,7 @@ typedef struct lf_job_s {
 
 static void* lf_fold(void* p) {
     lf_job* j = (lf_job*)p;
+    pin_self(j->t);
     const size_t per = (j->n + j->T - 1) / j->T;
     size_t lo = (size_t)j->t * per, hi = lo + per;
     if (lo > j->n) lo = j->n;
@@ -224,6 +266,7 @@ static void* lf_fold(void* p) {
 
 static void* lf_merge(void* p) {
     lf_job* j = (lf_job*)p;
+    pin_self(j->t);
     size_t mine = 0;
     for (uint32_t t = 0; t < j->T; t++) mine += j->all[t].shard_start[j->t + 1] - j->all[t].shard_start[j->t];
     if (!lf_init(&j->merged, mine)) { j->failed = 1; return 0; }
@@ -245,6 +288,7 @@ static int lf_rec_cmp(const void* x, const void* y) { return memcmp(x, y, 40); }
  * sorted by key, when they fit. T <= 256; the local tables hold what their slices hold (memory: ~300 B per distinct flow and slice). */
 size_t orc_local_fold_mt(const void* records, size_t n, uint32_t T, uint64_t max_entries, size_t* flows, double seconds[3], void* out, size_t out_cap) {
     if (T == 0 || T > 256 || n >= 0xFFFFFFFFull) return 0;
+    if (g_pin && g_cpu_count < 0) pin_build();
     lf_job* jobs = (lf_job*)calloc(T, sizeof *jobs);
     for (uint32_t t = 0; t < T; t++) {
         jobs[t].recs = (const orc_flow_record*)records; jobs[t].n = n; jobs[t].T = T; jobs[t].t = t;

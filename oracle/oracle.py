@@ -44,6 +44,7 @@ def lib():
             "orc_acc_ingest_shard": (_sz, [_vp, _vp, _sz, C.c_uint32, C.c_uint32]),
             "orc_partition_fold_mt": (_sz, [_vp, _sz, C.c_uint32, _u64, C.c_int, C.POINTER(_sz), C.POINTER(C.c_double)]),
             "orc_local_fold_mt": (_sz, [_vp, _sz, C.c_uint32, _u64, C.POINTER(_sz), C.POINTER(C.c_double), _vp, _sz]),
+            "orc_mt_set_pinning": (None, [C.c_int]),
             "orc_record_times": (None, [C.c_int64, _u64, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
             "orc_key_hash": (_u64, [_vp]), "orc_ip_hash": (_u64, [_vp, C.c_uint32]),
             "orc_shard_of": (C.c_uint32, [_vp, C.c_uint32]),
@@ -171,6 +172,11 @@ def partition_fold_mt(records, threads, max_entries, mode=0):
     secs = (C.c_double * 3)()
     folded = lib().orc_partition_fold_mt(_p(r), r.nbytes // 144, threads, max_entries, mode, C.byref(flows), secs)
     return folded, flows.value, secs[0], secs[1], secs[2]
+
+
+def mt_set_pinning(on: bool):
+    """orc_local_fold_mt's threads bound to CPUs in NUMA-node order (True) or left to the scheduler (False, the default)."""
+    lib().orc_mt_set_pinning(1 if on else 0)
 
 
 def local_fold_mt(records, threads, max_entries, want_flows=False):

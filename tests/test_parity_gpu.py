@@ -113,6 +113,71 @@ def test_evict_period(nf):
     acc.close()
 
 
+def test_batching_policy_keeps_tick_and_closing_semantics(nf):
+    """The shim gathers records until BATCH_RECORDS wait or the oldest has waited BATCH_TIMEOUT (accounter.py; INTEGRATION.md §3:
+    the reference's channel delivers ONE record per operation, pkg/agent/agent.go:408, and a call costs ~80 us whatever it
+    holds). What must survive (account.go:61-96): records received before a tick are in the eviction the tick makes; closing
+    accounts what was received, then evicts; an eviction on full happens at the record that finds the map full, whatever the
+    batch boundaries; and the calls are few."""
+    now = 1661272402 * 10**9
+    R = nf.FLOW_RECORD
+    # (1) a long batch timeout: the records wait in the shim; the TICK flushes them first, and its eviction holds them
+    acc = nf.NewAccounter(100, 0.5, lambda: now, lambda: 1000, nf.NoOp(), batch_records=1000, batch_timeout=30.0)
+    len(acc.table)
+    inputs, evictor = queue.Queue(), queue.Queue()
+    th = threading.Thread(target=acc.Account, args=(inputs, evictor), daemon=True)
+    th.start()
+    for t in (123, 456, 789):
+        inputs.put(mk(R, K1, PN, bytes=10, packets=1, start=t, end=t, flags=1))
+    r = evictor.get(timeout=10)                               # the timeout eviction, although no batch was ever "ready"
+    assert len(r) == 1 and (int(r[0].Metrics["bytes"]), int(r[0].Metrics["packets"])) == (30, 3)
+    assert acc.calls == 1                                     # three channel operations, one call
+    # (2) closing: what was received is accounted, then evicted
+    inputs.put(mk(R, K2, PN, bytes=7, packets=1, start=5, end=5, flags=1))
+    inputs.put(mk(R, K2, PN, bytes=8, packets=1, start=6, end=6, flags=1))
+    inputs.put(nf.CLOSE)
+    r = evictor.get(timeout=10)
+    assert len(r) == 1 and (int(r[0].Metrics["bytes"]), int(r[0].Metrics["packets"])) == (15, 2)
+    th.join(timeout=10)
+    assert acc.calls == 2
+    acc.close()
+    # (3) a batch of a given size: flushed when it is full, not before the timeout; the eviction on full falls where the
+    # reference's does (TestEvict_MaxEntries' records, batch of 4: the fourth record finds the map of 2 full)
+    acc = nf.NewAccounter(2, 3600.0, lambda: now, lambda: 1000, nf.NoOp(), batch_records=4, batch_timeout=30.0)
+    inputs, evictor = queue.Queue(), queue.Queue()
+    th = threading.Thread(target=acc.Account, args=(inputs, evictor), daemon=True)
+    th.start()
+    inputs.put(mk(R, K1, PN, bytes=123, packets=1, start=123, end=123, flags=1))
+    inputs.put(mk(R, K2, PN, bytes=456, packets=1, start=456, end=456, flags=1))
+    inputs.put(mk(R, K1, PN, bytes=321, packets=1, start=789, end=789, flags=1))
+    time.sleep(0.3)
+    assert evictor.empty() and acc.calls == 0
+    inputs.put(mk(R, K3, PN, bytes=111, packets=1, start=888, end=888, flags=1))
+    r = evictor.get(timeout=10)
+    assert sorted(int(x.Metrics["bytes"]) for x in r) == [444, 456]
+    assert acc.calls == 1 and acc.metrics.evictions_total == {("accounter", "full"): 1}
+    inputs.put(nf.CLOSE)
+    r = evictor.get(timeout=10)
+    assert len(r) == 1 and int(r[0].Metrics["bytes"]) == 111
+    th.join(timeout=10)
+    acc.close()
+    # (4) the default policy under a stream of single records: ~1 ms batches, far fewer calls than records, nothing lost
+    acc = nf.NewAccounter(5000, 3600.0, lambda: now, lambda: 1000, nf.NoOp())
+    len(acc.table)
+    inputs, evictor = queue.Queue(), queue.Queue()
+    th = threading.Thread(target=acc.Account, args=(inputs, evictor), daemon=True)
+    th.start()
+    n = 20_000
+    for k in range(n):
+        inputs.put(mk(R, K1 if k % 2 else K2, PN, bytes=1, packets=1, start=1 + k, end=1 + k, flags=1))
+    inputs.put(nf.CLOSE)
+    r = evictor.get(timeout=30)
+    assert len(r) == 2 and sum(int(x.Metrics["packets"]) for x in r) == n
+    th.join(timeout=10)
+    assert acc.calls < n // 10, acc.calls
+    acc.close()
+
+
 def test_timeout_eviction_fires_under_sustained_load(nf):
     """account.go:61-71: the ticker arm of the select is served although `in` never runs dry (the host mirror
     used to starve it). Records keep arriving for ~5 evict periods; 'timeout' evictions must happen meanwhile."""

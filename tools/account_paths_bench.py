@@ -37,6 +37,10 @@ pin_in.records[:] = host
 h_ev = np.empty(n // 2 + 8192, dtype=nf.FLOW_RECORD)
 h_ev.view(np.uint8)[::4096] = 0
 ends_cap = n // M + 16
+pin_close = nf.PinnedRecords(max(8192, M))
+h_close = np.empty(max(8192, M), dtype=nf.FLOW_RECORD)
+h_close.view(np.uint8)[::4096] = 0
+close_buf = {"device": pin_close.records, "page_locked": pin_close.records, "pageable": h_close}
 res = {"variant": variant, "records": n, "max_entries": M, "staging_records": staging, "sketches": bool(sk)}
 with nf.FlowTable(max_entries=M, ingest_variant=variant, staging_records=staging, sketches=sk) as tab:
     def call(leg):
@@ -48,7 +52,8 @@ with nf.FlowTable(max_entries=M, ingest_variant=variant, staging_records=staging
                              tab.account(pin_in.records, out=pin_ev.records, max_epochs=ends_cap))
             n_ep, flows = len(epochs), sum(len(e) for e in epochs)
         assert rc == nf.OK and c == n, (rc, c)
-        flows += len(tab.evict(nf.REASON_CLOSING, cap=max(8192, M)))
+        # (the closing eviction into a buffer the caller keeps, as the evictions on full: a fresh 14 MB array per call is page faults, not the library)
+        flows += len(tab.evict(nf.REASON_CLOSING, out=close_buf[leg]))
         return n_ep + 1, flows
     for leg in ("device", "page_locked", "pageable"):
         call(leg)
