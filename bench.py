@@ -63,6 +63,11 @@ def parse_args(argv=None):
                     "100 M-record stream of configs[1] — ~10 s on one core, ~4 s more for the multi-core variants)")
     ap.add_argument("--max-entries", type=int, default=0)
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the bounded extra legs (e2e host path, configs[2], configs[4] shape, CACHE_MAX_FLOWS 5000)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1 (local fold): window k's tick (sketch all-reduce, partials export, all-to-all, "
+                    "merge, eviction) strictly after its fold and before the next window's — round 5's line. Default: the tick of window k runs "
+                    "beside the fold of window k + 1 (two tables per rank, a host thread for the tick)")
+    ap.add_argument("--dump-evictions", default="", help="tests: after the timed windows every rank writes the records of its LAST eviction to "
+                    "<path>.<rank> (raw 144-byte records): their union is compared with ONE oracle Accounter over the common stream")
     ap.add_argument("--presharded", action="store_true", help="N > 1: round 2's line — every rank folds a private stream over its own shard's "
                     "population through the shard filter; no data-path exchange (linear by construction; for comparison only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend at N>1: nccl (= RCCL, the product path) or gloo "
@@ -220,17 +225,27 @@ def rank_main(args):
     max_entries = args.max_entries or (DEFAULT_MAX_ENTRIES if not local_fold else
                                        max(DEFAULT_MAX_ENTRIES, min(next_pow2(keys_total * (2 if args.dedup else 1)), 1 << (24 if args.dedup else 23))))
     sk_flags = (nf.SKETCH_CM | nf.SKETCH_HLL) if sketches else 0
-    ext = None
-    cm_t = hll_t = None
-    if sketches:
-        cm_t = [torch.zeros(4 << 20, dtype=torch.int64, device="cuda") for _ in range(2)]
-        hll_t = [torch.zeros(1 << 14, dtype=torch.uint8, device="cuda") for _ in range(2)]     # one byte per register: a 16 KiB all-reduce
-        ext = [cm_t[0].data_ptr(), cm_t[1].data_ptr(), hll_t[0].data_ptr(), hll_t[1].data_ptr()]
-        torch.cuda.synchronize()
-    tab = nf.FlowTable(max_entries=max_entries, device=local_rank, sketches=sk_flags, profile=True,
-                       mode=nf.MODE_KERNEL_DEDUP if args.dedup else nf.MODE_ACCOUNTER,
-                       ingest_variant=args.variant, n_shards=1 if local_fold else world, shard_id=0 if local_fold else rank, ext_sketch=ext,
-                       local_fold=local_fold)
+    # Local fold at N > 1: TWO tables per rank, windows alternate between them — while window k + 1 is folded into one, window k's tick
+    # (sketch all-reduce, partials to their owners, merge, eviction) runs on the other, from a host thread of its own (SURVEY.md
+    # §8(e); --no-overlap: one table, everything in sequence). Each table has its own sketch arrays: the all-reduce
+    # of window k's must not see window k + 1's records.
+    overlap = local_fold and not args.no_overlap
+    n_tabs = 2 if overlap else 1
+    tabs, cm_ts, hll_ts = [], [], []
+    for _ in range(n_tabs):
+        ext = None
+        cm_t = hll_t = None
+        if sketches:
+            cm_t = [torch.zeros(4 << 20, dtype=torch.int64, device="cuda") for _ in range(2)]
+            hll_t = [torch.zeros(1 << 14, dtype=torch.uint8, device="cuda") for _ in range(2)]     # one byte per register: a 16 KiB all-reduce
+            ext = [cm_t[0].data_ptr(), cm_t[1].data_ptr(), hll_t[0].data_ptr(), hll_t[1].data_ptr()]
+            torch.cuda.synchronize()
+        tabs.append(nf.FlowTable(max_entries=max_entries, device=local_rank, sketches=sk_flags, profile=True,
+                                 mode=nf.MODE_KERNEL_DEDUP if args.dedup else nf.MODE_ACCOUNTER,
+                                 ingest_variant=args.variant, n_shards=1 if local_fold else world, shard_id=0 if local_fold else rank, ext_sketch=ext,
+                                 local_fold=local_fold))
+        cm_ts.append(cm_t); hll_ts.append(hll_t)
+    tab = tabs[0]
     PARTIAL_BYTES = tab.partial_bytes           # 192; 256 for the sub-flow partials of the kernel-dedup mode
     out_cap = (keys_total if local_fold else keys) + 4096
     d_out = torch.empty(min(out_cap, max_entries + 4096) * 144 + 16, dtype=torch.uint8, device="cuda")
@@ -268,65 +283,126 @@ def rank_main(args):
         torch.cuda.synchronize()
         return total_in // W8, sum(counts)
 
-    def step(timed=None):
+    def fold(w):
+        tb = tabs[w % n_tabs]
+        if local_fold:
+            tb.set_sequence(rank * n)
+        off = 0
+        while off < n:
+            m = min(chunk, n - off)
+            rc, c = tb.ingest_device(d_recs.data_ptr() + off * 144, m)
+            assert rc == nf.OK and c == m, (rc, c)
+            off += m
+
+    def tick(w, timed=None):
+        tb, cm_t, hll_t = tabs[w % n_tabs], cm_ts[w % n_tabs], hll_ts[w % n_tabs]
+
         def mark(name, t_prev):
             if timed is None:
                 return t_prev
-            torch.cuda.synchronize(); tab.sync()
+            torch.cuda.synchronize(); tb.sync()
             t = time.perf_counter()
             timed[name] = timed.get(name, 0.0) + (t - t_prev) * 1e3
             return t
         t = time.perf_counter()
-        if local_fold:
-            tab.set_sequence(rank * n)
-        off = 0
-        while off < n:
-            m = min(chunk, n - off)
-            rc, c = tab.ingest_device(d_recs.data_ptr() + off * 144, m)
-            assert rc == nf.OK and c == m, (rc, c)
-            off += m
-        t = mark("fold_ms", t)
         if sketches and dist_on:
-            tab.sync()          # the sketch kernels run on the table's stream
+            tb.sync()          # the sketch kernels run on the table's stream
             nf.distributed.merge_sketches(cm_t, hll_t)
             torch.cuda.synchronize()
         t = mark("sketch_allreduce_ms", t)
         if local_fold:
-            rc, counts, n_exp = tab.partials_export_device(world, rank, d_exp.data_ptr(), d_exp.numel() * 8 // PARTIAL_BYTES)
+            rc, counts, n_exp = tb.partials_export_device(world, rank, d_exp.data_ptr(), d_exp.numel() * 8 // PARTIAL_BYTES)
             assert rc == nf.OK, "partials buffer too small: %d needed" % n_exp
             t = mark("export_ms", t)
             n_in, n_sent = exchange(counts)
             t = mark("all_to_all_ms", t)
-            tab.partials_merge_device(world, rank, d_imp.data_ptr(), n_in)
-            rc, flows = tab.evict_owned_device(world, rank, d_out.data_ptr(), out_cap, nf.REASON_TIMEOUT)
+            tb.partials_merge_device(world, rank, d_imp.data_ptr(), n_in)
+            rc, flows = tb.evict_owned_device(world, rank, d_out.data_ptr(), out_cap, nf.REASON_TIMEOUT)
             assert rc == nf.OK, "eviction buffer too small: %d needed" % flows
             t = mark("merge_evict_ms", t)
             if timed is not None:
                 timed["partials_sent"], timed["partials_received"] = n_sent, n_in
         else:
-            flows = tab.evict_device(d_out.data_ptr(), out_cap, nf.REASON_TIMEOUT)
+            flows = tb.evict_device(d_out.data_ptr(), out_cap, nf.REASON_TIMEOUT)
             t = mark("evict_ms", t)
         if sketches:
-            tab.sketch_reset()
+            tb.sketch_reset()
         return flows
+
+    def step(timed=None):
+        """One window, everything in sequence (N = 1; --no-overlap; the instrumented step)."""
+        t = time.perf_counter()
+        fold(0)
+        if timed is not None:
+            torch.cuda.synchronize(); tabs[0].sync()
+            timed["fold_ms"] = timed.get("fold_ms", 0.0) + (time.perf_counter() - t) * 1e3
+        return tick(0, timed)
+
+    def run_windows(k_windows, timed=None):
+        """k_windows windows. Overlapped: the tick of window w runs on a host thread beside the fold of window w + 1 (other table,
+        other sketch arrays; the library's streams are non-blocking and the collectives run on torch's: nothing serialises them);
+        the last tick has no fold beside it. One tick at a time: the next starts when the previous has ended."""
+        if not overlap:
+            f = 0
+            for _ in range(k_windows):
+                f = step()
+            return f
+        import threading
+        res = {"flows": 0, "err": None}
+
+        def tick_thread(w):
+            try:
+                torch.cuda.set_device(local_rank)
+                t0_ = time.perf_counter()
+                res["flows"] = tick(w)
+                if timed is not None:
+                    timed["tick_ms_beside_a_fold"] = timed.get("tick_ms_beside_a_fold", 0.0) + (time.perf_counter() - t0_) * 1e3
+            except BaseException as exc:
+                res["err"] = exc
+        th = None
+        for w in range(k_windows):
+            t0_ = time.perf_counter()
+            fold(w)
+            tabs[w % n_tabs].sync()
+            if timed is not None:
+                timed["fold_ms_beside_a_tick"] = timed.get("fold_ms_beside_a_tick", 0.0) + (time.perf_counter() - t0_) * 1e3
+            if th is not None:
+                th.join()
+                if res["err"] is not None:
+                    raise res["err"]
+            th = threading.Thread(target=tick_thread, args=(w,))
+            th.start()
+        th.join()
+        if res["err"] is not None:
+            raise res["err"]
+        return res["flows"]
 
     def barrier():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
-        tab.sync()
+        for tb in tabs:
+            tb.sync()
 
     flows = 0
-    for _ in range(args.warmup):
-        flows = step()
+    if args.warmup:
+        flows = run_windows(args.warmup)
     barrier()
-    tab.reset_profile()
+    for tb in tabs:
+        tb.reset_profile()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        flows = step()
+    flows = run_windows(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    st = tab.stats()
+    if args.dump_evictions:
+        d_out[: flows * 144].cpu().numpy().tofile("%s.%d" % (args.dump_evictions, rank))
+    class _Sum:                                     # the tables' stats, added up (two tables when the windows alternate)
+        pass
+    st = _Sum()
+    sts = [tb.stats() for tb in tabs]
+    for name in ("records_ingested", "ingest_kernel_ms", "ingest_launches", "sketch_kernel_ms", "sketch_launches", "evict_kernel_ms",
+                 "evict_launches", "records_bypassed", "table_bytes"):
+        setattr(st, name, sum(getattr(x, name) for x in sts))
     records_folded = [int(st.records_ingested)]
     if dist_on:
         mdev = "cuda" if args.backend == "nccl" else "cpu"          # bookkeeping collectives (gloo rehearsal: host tensors)
@@ -339,9 +415,20 @@ def rank_main(args):
         rf = [torch.zeros(1, dtype=torch.int64, device=mdev) for _ in range(world)]
         dist.all_gather(rf, torch.tensor([int(st.records_ingested)], dtype=torch.int64, device=mdev))
         records_folded = [int(x.item()) for x in rf]
-        # one more, instrumented step (outside the timed region): where the time of a step goes
+        # one more, instrumented window (outside the timed region), everything in sequence: what each phase costs on its own ...
         step(timed=phase)
         barrier()
+        if overlap:
+            # ... and three more, overlapped as the timed ones: how long a fold and a tick take when they run beside each other
+            ov = {}
+            t_ov = time.perf_counter()
+            run_windows(3, timed=ov)
+            barrier()
+            phase["overlapped"] = {"windows": 3, "wall_ms_per_window": round((time.perf_counter() - t_ov) * 1e3 / 3, 3),
+                                   "fold_ms_beside_a_tick": round(ov.get("fold_ms_beside_a_tick", 0.0) / 3, 3),
+                                   "tick_ms_beside_a_fold": round(ov.get("tick_ms_beside_a_fold", 0.0) / 3, 3),
+                                   "what": "window w's tick (all-reduce, export, all-to-all, merge, evict) on a host thread beside window w + 1's fold; "
+                                           "the exchange is hidden when wall_ms_per_window is about max(fold, tick), not their sum"}
     else:
         flows_total = flows
 
@@ -387,8 +474,10 @@ def rank_main(args):
                 "records_per_gpu_per_step": n, "unique_flows_per_gpu": keys, "hot_permille": args.hot_permille,
                 "stream_variant": 2 if args.dedup else 0, "mode": "kernel_dedup" if args.dedup else "accounter",
                 "max_entries": max_entries, "table_bytes": int(st.table_bytes), "chunk": chunk,
-                "parallelism": ("one process per GPU x%d, local fold + partials to key-hash owners" % world if local_fold
+                "parallelism": ("one process per GPU x%d, local fold + partials to key-hash owners%s" % (world, ", window w's tick beside window "
+                                 "w + 1's fold (two tables per rank)" if overlap else ", fold and tick in sequence") if local_fold
                                 else "key-hash shards x%d" % world) + rehearsal,
+                "windows_overlapped": bool(overlap),
                 "ingest_variant": args.variant,
                 "evictions_per_step": 1, "evicted_flows_per_step": flows_total,
                 "evictions_per_s": round(steps / dt, 3), "evicted_flows_per_s": round(flows_total * steps / dt, 1),
@@ -483,7 +572,9 @@ def rank_main(args):
                             and not args.chunk and not args.max_entries)
         if default_workload and not args.no_extras:
             # the extra legs regenerate streams into d_recs: before the copy test overwrites half of it
-            tab.close()
+            for tb in tabs:
+                tb.close()
+            tabs = []
             tab = None
             try:
                 out["extra"] = extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys)
@@ -518,8 +609,8 @@ def rank_main(args):
             out["roofline"]["hbm_copy_measured_GBs"] = None
             out["roofline"]["hbm_copy_error"] = str(exc)[:100]
         quiet.emit(json.dumps(out))
-    if tab is not None:
-        tab.close()
+    for tb in tabs:
+        tb.close()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -204,6 +204,30 @@ def test_bench_gpus_2_as_a_plain_process_rehearsed_on_one_gpu(nf):
     assert j["roofline"]["alg_bytes_per_record"] == 522 and j["roofline"]["launch_ms"] > 0
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+def test_bench_gpus_2_evictions_equal_one_accounter(nf, O, overlap, tmp_path):
+    """What `bench.py --gpus 2` EVICTS — with window w's tick (sketch all-reduce, export, all-to-all, merge, evict) running on a host
+    thread beside window w + 1's fold on the rank's second table (the default since round 6), and with everything in sequence
+    (--no-overlap) — against ONE oracle Accounter (pkg/flow/account.go:58-124) over the common stream: the union of the two ranks'
+    last evictions, bit for bit. Two gloo ranks on one device."""
+    n, keys = 500_000, 40_000
+    dump = str(tmp_path / "ev")
+    argv = ["--gpus", "2", "--same-device", "--backend", "gloo", "--records", str(n), "--flows", str(keys), "--steps", "3", "--warmup", "1",
+            "--dump-evictions", dump] + ([] if overlap else ["--no-overlap"])
+    j = _bench(*argv)
+    assert j["config"]["windows_overlapped"] is overlap
+    from netobserv_ebpf_agent_amd import synth
+    th = synth.zipf_thresholds(2 * keys, 1.1)
+    whole = synth.stream_host(2 * n, seed=2, n_keys=2 * keys, thresholds=th)
+    want = O.run_accounter(whole, 1 << 22)[0][1]
+    got = np.concatenate([np.fromfile("%s.%d" % (dump, r), dtype=nf.FLOW_RECORD) for r in range(2)])
+    assert len(got) == len(want) == j["config"]["evicted_flows_per_step"]
+    assert_records_equal(nf.sort_by_key(got), want, "bench.py --gpus 2 (%s): union of the ranks' evictions vs ONE Accounter" % ("overlapped" if overlap else "in sequence"))
+    if overlap:
+        ov = j["config"]["exchange"]["overlapped"]
+        assert ov["wall_ms_per_window"] > 0 and ov["tick_ms_beside_a_fold"] > 0
+
+
 def test_bench_presharded_line_still_runs(nf):
     j = _bench("--gpus", "2", "--same-device", "--backend", "gloo", "--presharded", "--no-sketches", "--records", "400000", "--flows", "20000",
                "--steps", "1", "--warmup", "1")
@@ -216,8 +240,13 @@ def test_bench_n1_line_carries_the_extra_legs(nf):
     assert j["n_gpus"] == 1 and j["roofline"]["frac"] > 0 and j["cpu_baseline"]["kind"] == "port"
     ex = j["extra"]
     assert "error" not in ex, ex
-    for k in ("configs2", "configs4_shape", "e2e", "cache_max_flows_5000"):
-        assert k in ex, ex.keys()
+    for k in ("configs2", "configs4_shape", "e2e", "cache_max_flows_5000", "cache_max_flows_10000", "cache_max_flows_100000", "shim_small_calls"):
+        assert k in ex and "error" not in ex[k], (k, ex.get(k))
+    assert j["roofline"]["frac"] <= 1.0 and j["roofline"]["hbm_read_stream_measured_GBs"] > 1000
+    for M in ("10000", "100000"):
+        leg = ex["cache_max_flows_" + M]
+        assert leg["account_host_path"]["evicted_flows"] == leg["account_device_resident"]["evicted_flows"] == leg["account_host_path_page_locked"]["evicted_flows"]
+    assert set(ex["shim_small_calls"]["by_call_size"]) >= {"1", "1024", "65536"}
     assert ex["configs2"]["alg_bytes_per_record"] == 522 and ex["configs2"]["Mrecords_per_s"] > 0
     assert ex["e2e"]["Mrecords_per_s"] > 0 and ex["cache_max_flows_5000"]["account_host_path"]["evictions"] > 10
     assert ex["cache_max_flows_5000"]["account_host_path"]["evicted_flows"] == ex["cache_max_flows_5000"]["account_device_resident"]["evicted_flows"]
