@@ -1010,6 +1010,12 @@ def extras(args, torch, nf, synth, d_recs, d_out, gen_stream, n, keys):
             r_ = {}
             try:
                 account_leg(0, r_, M)
+                tbm, tsrcm = leg_traffic("cache_max_flows_%d" % M, m2)          # the PMC passes of tools/account_5000_prof.py --max-entries M
+                if tbm and "account_device_resident" in r_:
+                    rm = r_["account_device_resident"]
+                    rm["traffic_bytes_per_launch"], rm["traffic_source"] = tbm, tsrcm
+                    rm["frac_traffic"] = round(tbm / (rm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    rm["frac_stream_floor"] = round(144 * m2 / (rm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 r_["cpu_oracle_1_core"] = cpu_baseline_small_table(host[:m2], M)
             except Exception as exc:
                 r_["error"] = repr(exc)[:300]

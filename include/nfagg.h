@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define NFAGG_ABI_VERSION 1u
+#define NFAGG_ABI_VERSION 2u   /* 2 (round 6): nfagg_stats grew by account_epochs_first / account_chain / account_declined in round 5 without a bump — a
+                                   caller built against version 1's header must not be handed the longer struct; cfg.copy_threads = 0 means "the
+                                   calibrated number of parts" (was: 4) */
 
 /* ------------------------------------------------------------------ */
 /* Record ABI — byte-for-byte the structs of bpf/types.h               */

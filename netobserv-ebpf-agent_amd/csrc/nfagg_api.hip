@@ -695,7 +695,7 @@ static int device_numa_node(int device) {
 // First handle of the process: the copy workers, bound next to its GPU. Later handles (other GPUs of a group) share them.
 static void host_pool_for_device(int device) {
     static std::once_flag once;
-    std::call_once(once, [device] { (void)HostPool::get().configure(0, device_numa_node(device)); });
+    std::call_once(once, [device] { (void)HostPool::get().configure(0, device_numa_node(device), /*explicit_call=*/false); });
 }
 
 extern "C" {
@@ -2308,6 +2308,19 @@ int nfagg_debug_last_analysis(nfagg_handle* h, uint64_t* keys_sorted, int32_t* p
     if (keys_sorted) HIP_TRY(h, hipMemcpy(keys_sorted, h->d_par[1], n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (prev) HIP_TRY(h, hipMemcpy(prev, h->d_par[2], n * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (pos) HIP_TRY(h, hipMemcpy(pos, h->d_par[3], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return NFAGG_OK;
+}
+// libnfagg_diag.so only: the dense-identity timing experiment of k_finalize + k_evict (nfagg_kernels.hip g_diag_dense). on = 1: a
+// buffer of one 64-byte unit per slot is allocated and every table of the PROCESS uses it (one table at a time); 0: back to the
+// cold half lines. Evicted MACs are wrong while it is on.
+int nfagg_debug_dense_identity(nfagg_handle* h, int on) {
+    static void* buf = nullptr;
+    if (!h) return NFAGG_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (buf) { (void)hipFree(buf); buf = nullptr; }
+    if (on) HIP_TRY(h, hipMalloc(&buf, (size_t)h->slots * 64));
+    HIP_TRY(h, diag_set_dense(buf));
     return NFAGG_OK;
 }
 // libnfagg_diag.so only (not part of the drop-in ABI): per-phase wave-cycle sums of the phase-timing builds (variants 6/8/9).

@@ -57,8 +57,12 @@ public:
 
     // (Re)shape the pool: `threads` workers (0 = keep / default 16; the submitting thread always works too), bound to NUMA node
     // `node` (-1 = leave them where they are). Returns the workers running.
-    unsigned configure(unsigned threads, int node) {
+    // explicit = the caller asked for this shape (nfagg_host_threads): the implicit default of the first nfagg_create leaves it alone
+    // afterwards — an agent that keeps the pool off its own cores (threads = 2, node = -1) must not find it re-bound behind its back.
+    unsigned configure(unsigned threads, int node, bool explicit_call = true) {
         std::lock_guard<std::mutex> cfg(cfg_mu_);
+        if (!explicit_call && explicit_) return (unsigned)workers_.size();
+        if (explicit_call) explicit_ = true;
         if (threads == 0) threads = workers_.empty() ? 16u : (unsigned)workers_.size();
         if (threads > 64) threads = 64;
         if (threads == workers_.size() && node == node_) return threads;
@@ -66,13 +70,16 @@ public:
         node_ = node;
         cpu_set_t set;
         const bool bind = node >= 0 && node_cpus(node, &set);
+        bool all_bound = bind;
         for (unsigned t = 0; t < threads; t++) {
             try {
                 workers_.emplace_back([this] { work(); });
             } catch (...) { break; }                                  // thread limit reached: a smaller pool
-            if (bind) (void)pthread_setaffinity_np(workers_.back().native_handle(), sizeof set, &set);
+            // (fails, or is intersected with the allowed set, under a cgroup cpuset: then the pool is NOT bound, and says so)
+            if (bind && pthread_setaffinity_np(workers_.back().native_handle(), sizeof set, &set) != 0) all_bound = false;
         }
-        bound_ = bind;
+        bound_ = all_bound && !workers_.empty();
+        n_workers_.store((unsigned)workers_.size(), std::memory_order_release);
         calibrate();
         return (unsigned)workers_.size();
     }
@@ -86,7 +93,8 @@ public:
     // (nfagg_account copies up and down at the same time): workers serve whichever has parts left. A job lives on its submitter's
     // stack: a worker's last touch of it is the `done` count, under the mutex the submitter waits under.
     void parallel(unsigned parts, const std::function<void(unsigned)>& fn) {
-        if (parts <= 1 || workers_.empty()) { for (unsigned p = 0; p < parts; p++) fn(p); return; }
+        // (the count, not the vector: configure() may be re-shaping it on another thread)
+        if (parts <= 1 || n_workers_.load(std::memory_order_acquire) == 0) { for (unsigned p = 0; p < parts; p++) fn(p); return; }
         Job job; job.parts = parts; job.fn = &fn;
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -134,7 +142,8 @@ private:
     std::condition_variable cv_, done_cv_;
     std::vector<Job*> jobs_;
     std::vector<std::thread> workers_;
-    bool stop_ = false, bound_ = false;
+    bool stop_ = false, bound_ = false, explicit_ = false;
+    std::atomic<unsigned> n_workers_{0};
     int node_ = -1;
     std::atomic<unsigned> best_parts_{4};
     double calib_gbs_ = 0.0;
@@ -160,6 +169,7 @@ private:
         }
     }
     void stop_workers() {
+        n_workers_.store(0, std::memory_order_release);              // parallel() copies inline while the pool is re-shaped
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
         cv_.notify_all();
         for (auto& t : workers_) if (t.joinable()) t.join();

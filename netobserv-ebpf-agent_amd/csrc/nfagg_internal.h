@@ -174,6 +174,9 @@ int32_t par_prev_pad_value();
 hipError_t launch_par_middle(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, const int32_t* d_prev, const uint32_t* d_cuts,
                              uint32_t t_lo, uint32_t t_hi, uint32_t i_lo, uint32_t i_hi, uint32_t max_entries, const SketchView& sk, uint32_t* d_pos,
                              void* d_out, uint32_t* d_long, uint32_t long_cap, uint32_t* d_huge, uint32_t* d_tiles, uint32_t* d_n_long, uint32_t* d_bad, hipStream_t s);
+#ifdef NFAGG_DIAG
+hipError_t diag_set_dense(void* p);       // nfagg_kernels.hip: the dense-identity timing experiment (libnfagg_diag.so only)
+#endif
 uint32_t par_seg_short();
 uint32_t par_huge_cap();
 uint64_t par_rank_tiles(uint64_t records);

@@ -86,6 +86,18 @@ __global__ __launch_bounds__(kFlagBlock) void k_first_flags(TableView t, const u
 // rank a ballot gave it (one n_out atomic per wave, not per lane), and the window — the wave's records back to back —
 // goes out with 16-byte stores, consecutive lanes on consecutive addresses.
 // ------------------------------------------------------------------
+#ifdef NFAGG_DIAG
+// Experiment (libnfagg_diag.so only; round-2..5 reviews: "a dense 64-byte identity record per live-list position"): when set,
+// k_finalize writes the first record's identity words to g_diag_dense[live-list position] and k_evict reads them from there —
+// sequential 64-byte units instead of one random cold half line per flow (whose other half is a neighbour's: 128 bytes fetched
+// for 64). The first-MAC high words stay in the cold line, which k_evict does NOT read in this mode: evicted MACs are WRONG (their
+// high 16 bits zero) — a timing experiment for k_finalize + k_evict, not a layout. profiles/r06x_dense_identity.txt.
+__device__ SlotCold* g_diag_dense = nullptr;
+hipError_t diag_set_dense(void* p) { SlotCold* v = static_cast<SlotCold*>(p); return hipMemcpyToSymbol(HIP_SYMBOL(g_diag_dense), &v, sizeof v); }
+#define NF_DENSE_AT(pos, idx) (g_diag_dense ? &g_diag_dense[pos] : &t.cold[idx])
+#else
+#define NF_DENSE_AT(pos, idx) (&t.cold[idx])
+#endif
 constexpr int kEvictWaves = 2;                        // waves per workgroup
 // Rows are padded to an odd number of 16-byte chunks (9 and 5): lane l reading chunk c of ITS row touches banks
 // (36 l + 4 c) mod 32 resp. (20 l + 4 c) mod 32 — eight consecutive lanes cover all 32 banks, a 16-byte read per lane runs
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(64 * kEvictWaves) void k_evict(TableView t, uint64_
         for (int p = 0; p < 4; p++) {
             const int s = 16 * p + (lane >> 2);
             const uint32_t idx = __shfl(my_idx, s);
-            if ((uint64_t)s < cnt) W.cold[s][lane & 3] = reinterpret_cast<const uint4*>(&t.cold[idx])[lane & 3];
+            if ((uint64_t)s < cnt) W.cold[s][lane & 3] = reinterpret_cast<const uint4*>(NF_DENSE_AT(base + s, idx))[lane & 3];
         }
         __builtin_amdgcn_wave_barrier();
         // ---- one lane per slot: rebuild the record in registers
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(256) void k_finalize(TableView t, const void* __res
         if ((uint32_t)(id0 >> 32) == 0 || ri >= n) continue;   // claimed, but no record of this batch's folded range is its first
         const uint4* rp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + ri * kRecordBytes);
         const uint4 c5 = rp[5], c6 = rp[6], c7 = rp[7], c8 = rp[8];     // record dwords 20..35
-        uint4* cw = reinterpret_cast<uint4*>(&t.cold[idx]);
+        uint4* cw = reinterpret_cast<uint4*>(NF_DENSE_AT(i, idx));
         cw[1] = make_uint4(c5.z, c6.x, c6.y, c6.z & 0x0000ffffu);       // dwords 22, 24, 25, 26 (pad2 cleared)
         cw[2] = make_uint4(c6.w, c7.x, c7.y, c7.z);                     // 27..30
         cw[3] = make_uint4(c7.w, c8.x, c8.y, c8.z);                     // 31..34

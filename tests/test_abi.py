@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(nf):
 
 
 def test_abi_version(nf):
-    assert nf._lib.lib.nfagg_abi_version() == 1
+    assert nf._lib.lib.nfagg_abi_version() == 2
 
 
 PROBE = r"""

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Test infrastructure: nfagg_account on its default path (calls of more than a few epochs: epochs found first, csrc/nfagg_epoch_par.hip;
 the others: the kernel chain) with fresh seeds for a time budget — table sizes from 1 to 20 000 entries, ragged calls, hot flows, the
-sketches fed along, every eviction against the oracle. Usage: python tests/tools/soak_account_par.py [seconds] [first seed]"""
+sketches fed along, every eviction against the oracle. Usage: python tests/tools/soak_account_par.py [seconds] [first seed] [--large]
+--large (round 6): the table sizes beyond the kernel chain's 32 768 — 10 000 ... 250 000 entries (scripts/agent.yml:35-36,
+pkg/flow/tracer_map_bench_test.go:64-111), streams of 2-6 M records, hot flows (segments of tens of thousands of records: folded in chunks)."""
 import os, sys, time, traceback
 import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -11,8 +13,10 @@ import netobserv_ebpf_agent_amd as nf
 from oracle import oracle as O
 from test_account_gpu import _check, _stream
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+large = "--large" in sys.argv
+argv = [a for a in sys.argv[1:] if a != "--large"]
+budget = float(argv[0]) if len(argv) > 0 else 60.0
+seed = int(argv[1]) if len(argv) > 1 else 100
 t_end = time.time() + budget
 runs = recs_total = 0
 while time.time() < t_end:
@@ -23,8 +27,14 @@ while time.time() < t_end:
     n = int(rng.choice([120_000, 400_000, 1_200_000]))
     if max_entries <= 7:
         n = min(n, 200_000)                          # tens of thousands of evictions: bound the oracle's time
+    if large:
+        max_entries = int(rng.choice([10_000, 40_000, 100_000, 100_000, 250_000]))
+        keys = int(rng.choice([max_entries + 1, 3 * max_entries + 10, 1_000_000, 3_000_000]))
+        n = int(rng.choice([2_000_000, 4_000_000, 6_000_000]))
     recs = _stream(O, n, keys, seed=seed, hot=int(rng.choice([0, 0, 500, 950])), variant=int(rng.choice([0, 1])))
     batches = [int(rng.choice([1, 777, 70_000, 150_000, 400_000, 1 << 30])) for _ in range(600)]
+    if large:
+        batches = [int(rng.choice([131_071, 131_072, 500_000, 1_048_576, 3_000_000, 1 << 30])) for _ in range(600)]
     desc = dict(seed=seed, max_entries=max_entries, keys=keys, n=n)
     try:
         sk = bool(rng.integers(0, 2))

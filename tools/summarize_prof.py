@@ -76,7 +76,7 @@ if f_read and f_write:
         bench = None
     ingest = [k for k in per_kernel if any(s in k for s in ("k_fold", "k_pass1", "k_pass2", "k_merge_overflow", "k_ingest", "k_dedup_claim", "k_dedup_fold", "k_dedup_stream", "k_dedup_parts", "k_dedup_overflow", "k_finalize",
                                                                 "k_sketch_update", "k_ep_", "k_par_", "radix_sort"))]
-    if leg == "cache_max_flows_5000":                          # nfagg_account: the evictions are part of the call
+    if leg and leg.startswith("cache_max_flows_"):             # nfagg_account: the evictions are part of the call
         ingest += [k for k in per_kernel if "k_evict" in k and k not in ingest]
     evict = [k for k in per_kernel if "k_evict" in k]
     ev_calls = max((per_kernel[k].get("FETCH_SIZE", (1, 0))[0] for k in evict), default=1)
