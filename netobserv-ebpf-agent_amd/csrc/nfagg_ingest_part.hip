@@ -557,6 +557,174 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
     if (spilled) aadd(&t.ctr->n_bypassed, spilled);
 }
 
+// ---- pass 1 WITHOUT its barriers (round 6; ingest_variant 17) -------------------------------------------------------------------
+// k_pass1 above takes its 16 waves through two workgroup barriers per tile: one so that the creator of a cache entry may write the
+// entry's key with plain stores before anybody compares it, one for the spill staging (a group is drained a tile after it was
+// filled). Its phase timing says what that costs: 29 % of the wave-cycles at the barriers, waves that hold their loads already
+// waiting for the slowest one (profiles/r03_pass1_ablation.txt; two tiles of prefetch did not help: r05x_pass1_two_tiles_ahead.txt).
+// Neither barrier is needed for EXACTNESS if the two protocols say when their data is complete:
+//   * cache entries are PUBLISHED. The creator claims the entry with a marker no key hash can equal (hashes are stored | 1: odd;
+//     the marker is 2), writes the key, then stores the hash with release semantics. Whoever reads the hash (acquire) reads a
+//     complete key; whoever meets the marker treats the record as a miss (it is spilled: pass 2 folds it). Entries are never
+//     evicted and keys never change, so a fold only ever adds a record to an entry whose full key it has compared. A flow may end
+//     up with two entries (two lanes racing past each other's markers): two partials, merged by the flush like any others.
+//   * staging groups are drained by their LAST WRITER. An append reserves a position (low half of the group's counter), writes its
+//     item, then counts itself done (high half); the lane whose "done" is the fourth reads the group — every writer's store precedes
+//     its "done" — and resets the counter. Appends that meet a full group (position >= 4) are carried to the lane's next tile,
+//     as before; nobody waits.
+// The waves then run free: a wave that has its records folds them while another still waits for its loads.
+constexpr uint64_t kEntryBusy = 2ull;              // never a stored hash (those are odd), never 0 (free)
+
+template <bool DOOR>
+NF_DEV int cache_claim_published(Cache& L, uint32_t* door, uint64_t h, const uint64_t w[5]) {
+    const uint64_t hk = h | 1ull;
+    uint32_t e = (uint32_t)(h >> 40) & (kEntries - 1);
+#pragma unroll 1
+    for (int p = 0; p < kProbe; p++) {
+        uint64_t cur = __hip_atomic_load(lo64(&L.k0[e]), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cur == 0) {
+            if (DOOR) {
+                const uint32_t b = (uint32_t)(h >> 14) & (kDoorBits - 1), m = 1u << (b & 31);
+                if (!(door[b >> 5] & m) && !(atomicOr(&door[b >> 5], m) & m)) return -1;
+            }
+            cur = atomicCAS(lo64(&L.k0[e]), 0ull, (unsigned long long)kEntryBusy);
+            if (cur == 0) {
+                *hi64(&L.k0[e]) = w[0];
+                L.k1[e] = mk4(w[1], w[2]);
+                L.k2[e] = mk4(w[3], w[4]);
+                __hip_atomic_store(lo64(&L.k0[e]), (unsigned long long)hk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return (int)e;
+            }
+        }
+        if (cur == hk) return (int)e;
+        if (cur == kEntryBusy) return -1;          // somebody is writing a key here (maybe this flow's): a miss, not a wait
+        e = (e + 1) & (kEntries - 1);
+    }
+    return -1;
+}
+
+template <bool SKETCH, bool DOOR>
+__global__ __launch_bounds__(kBlock) void k_pass1_free(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
+                                                       uint64_t n, uint64_t seq_base) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    Cache& L = *reinterpret_cast<Cache*>(lds_raw);
+    Stage& S = *reinterpret_cast<Stage*>(lds_raw + sizeof(Cache));
+    uint32_t* door = reinterpret_cast<Door*>(lds_raw + sizeof(Cache) + sizeof(Stage))->bits;   // with DOOR only
+    const int tid = threadIdx.x;
+    const uint32_t seq_base32 = (uint32_t)seq_base;
+    cache_init(L, tid);
+    for (int p = tid; p < kSpillParts; p += kBlock) S.cnt[p] = 0;
+    if (DOOR) for (int p = tid; p < kDoorBits / 32; p += kBlock) door[p] = 0;
+    __syncthreads();
+    const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
+    const uint64_t tile_first = (uint64_t)blockIdx.x, tile_step = (uint64_t)gridDim.x;
+    unsigned long long skipped = 0, spilled = 0;
+    const bool tag_on = n <= (uint64_t)kIdxMask;
+    const uint32_t sub_shift = sub_shift_of(q);
+    constexpr int kMine = kSpillParts / kBlock;
+    // a group this lane drained: its queue position is reserved when it is drained, the store follows a tile later (the
+    // reservation is a returning atomic: no HBM round trip inside a tile). A lane appends at most twice per tile.
+    uint4 pend_v[2];
+    uint32_t pend_at[2], pend_p[2];
+    bool pend[2] = {false, false};
+#pragma unroll
+    for (int k = 0; k < 2; k++) { pend_at[k] = 0; pend_p[k] = 0; pend_v[k] = make_uint4(0, 0, 0, 0); }
+    uint32_t carry = 0xffffffffu, carry_p = 0;
+    int carried_for = 0;                                           // tiles the carried item has met a full group
+    auto append = [&](uint32_t p, uint32_t qi, int slot) __attribute__((always_inline)) -> bool {
+        const uint32_t at = atomicAdd(&S.cnt[p], 1u) & 0xffffu;
+        if (at >= (uint32_t)kStage) return false;                  // full (its last writer has not reset it yet)
+        S.buf[p][at] = qi;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the item before the "done"
+        const uint32_t old = atomicAdd(&S.cnt[p], 0x10000u);
+        if ((old >> 16) == (uint32_t)kStage - 1) {                 // the last of the four writers: the group is complete, and this lane's
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            pend_v[slot] = *reinterpret_cast<const uint4*>(S.buf[p]);
+            __hip_atomic_store(&S.cnt[p], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // appends resume
+            pend_at[slot] = aadd(&q.qtail[p], (uint32_t)kStage);
+            pend_p[slot] = p; pend[slot] = true;
+        }
+        return true;
+    };
+    auto flush_pends = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (pend[k]) {
+                if (pend_at[k] + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)pend_p[k] * q.qcap + pend_at[k]) = pend_v[k];
+                else overflow_push(q, pend_v[k]);
+                pend[k] = false;
+            }
+        }
+    };
+    bool valid; uint64_t i; Rec r;
+    {
+        const uint64_t pos = tile_first * kBlock + tid;
+        valid = pos < n; i = valid ? pos : 0;
+        load_record_head(recs, i, r);
+    }
+    for (uint64_t tile = tile_first; tile < n_tiles; tile += tile_step) {
+        bool valid_n; uint64_t i_n; Rec r_n;
+        {
+            const uint64_t pos = (tile + tile_step) * kBlock + tid;
+            valid_n = pos < n; i_n = valid_n ? pos : 0;
+            load_record_head(recs, i_n, r_n);
+        }
+        // what this lane drained in its previous tile goes out now (its reservation has long arrived)
+        flush_pends();
+        uint64_t w[5];
+        uint64_t h = 0;
+        bool v = valid;
+        if (v) {
+            r.canonicalize();
+            r.key_words(w);
+            h = key_hash(w);
+            if (t.n_shards > 1 && shard_of_hash(h, t.n_shards) != t.shard_id) { v = false; skipped++; }
+        }
+        const uint32_t seq32 = seq_base32 + (uint32_t)i;
+        int ent = v ? cache_claim_published<DOOR>(L, door, h, w) : -1;
+        if (v && ent >= 0) ent = cache_fold(L, ent, r, w, seq32);
+        if (carry != 0xffffffffu) {
+            if (append(carry_p, carry, 0)) { carry = 0xffffffffu; carried_for = 0; }
+            else if (++carried_for >= 2) { overflow_push_one(q, carry); carry = 0xffffffffu; carried_for = 0; }   // full twice in a row: very rare
+        }
+        if (v && ent < 0) {
+            spilled++;
+            const uint32_t p = part_of(h, q);
+            const uint32_t qi = (uint32_t)i | (tag_on ? ((uint32_t)(h >> sub_shift) & (uint32_t)(kSubs - 1)) << kIdxBits : 0u);
+            if (!append(p, qi, 1)) {
+                if (carry == 0xffffffffu) { carry = qi; carry_p = p; carried_for = 0; }
+                else overflow_push_one(q, qi);                     // (a carried item is still waiting: at most one per lane)
+            }
+        }
+        valid = valid_n; i = i_n;
+#pragma unroll
+        for (int k = 0; k < 28; k++) r.d[k] = r_n.d[k];
+    }
+    flush_pends();                                                 // (the carried item below may drain another group into slot 0)
+    if (carry != 0xffffffffu) { if (!append(carry_p, carry, 0)) overflow_push_one(q, carry); }
+    __syncthreads();                                               // every append of the workgroup is done: every complete group was drained by its last writer
+    flush_pends();
+    // whatever is staged in groups that never filled (padded with invalid indices): every lane looks after its two partitions
+#pragma unroll
+    for (int k = 0; k < kMine; k++) {
+        const int p = tid + k * kBlock;
+        uint32_t c = S.cnt[p] & 0xffffu;
+        if (c > (uint32_t)kStage) c = kStage;
+        if (c) {
+            const uint32_t at = aadd(&q.qtail[p], (uint32_t)kStage);
+            uint4 vq = *reinterpret_cast<const uint4*>(S.buf[p]);
+            if (c < 2) vq.y = 0xffffffffu;
+            if (c < 3) vq.z = 0xffffffffu;
+            if (c < 4) vq.w = 0xffffffffu;
+            if (at + kStage <= q.qcap) *reinterpret_cast<uint4*>(q.queue + (uint64_t)p * q.qcap + at) = vq;
+            else overflow_push(q, vq);
+        }
+    }
+    for (int e = tid; e < kEntries; e += kBlock) cache_flush_entry<SKETCH, false>(t, sk, L, e, recs, seq_base32, nullptr, nullptr, false);
+    if (skipped) aadd(&t.ctr->n_skipped, skipped);
+    if (spilled) aadd(&t.ctr->n_bypassed, spilled);
+}
+
 // ---- pass 2 ------------------------------------------------------------------------------------------------------
 // Workgroup b folds the records whose indices pass 1 queued for partition b, in its LDS cache, and owns the partition's
 // flows while it runs (plain read-modify-write flush, nfagg_device.h merge_partial_exclusive).
@@ -820,7 +988,7 @@ __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView 
     if (direct) aadd(&t.ctr->n_direct, direct);
 }
 
-template <bool SKETCH, bool T1 = false, bool T2 = false, bool DOOR = true, int ABL = 0, bool DEEP = false>
+template <bool SKETCH, bool T1 = false, bool T2 = false, bool DOOR = true, int ABL = 0, bool DEEP = false, bool FREE = false>
 static hipError_t run(const TableView& t, const SketchView& sk, const SpillView& q, const void* d_records, uint64_t n,
                       uint64_t seq_base, hipStream_t s) {
     const size_t lds1 = sizeof(Cache) + sizeof(Stage) + (DOOR ? sizeof(Door) : 0), lds2 = sizeof(Cache) + sizeof(Pass2Lds);
@@ -830,8 +998,9 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     (void)hipGetDevice(&dev_);
     std::atomic<bool>& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<SKETCH, T1, DOOR, ABL, DEEP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        hipError_t e = FREE ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1_free<SKETCH, DOOR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)
+                            : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<SKETCH, T1, DOOR, ABL, DEEP>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<SKETCH, T2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -846,7 +1015,8 @@ static hipError_t run(const TableView& t, const SketchView& sk, const SpillView&
     if (grid > 256) grid = 256;
     if (grid > tiles) grid = tiles;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_pass1<SKETCH, T1, DOOR, ABL, DEEP>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
+    if (FREE) hipLaunchKernelGGL((k_pass1_free<SKETCH, DOOR>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
+    else hipLaunchKernelGGL((k_pass1<SKETCH, T1, DOOR, ABL, DEEP>), dim3((unsigned)grid), dim3(kBlock), lds1, s, t, sk, q, d_records, n, seq_base);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_pass2<SKETCH, T2>), dim3(q.n_parts), dim3(kBlock), lds2, s, t, sk, q, d_records, n, seq_base);
@@ -892,6 +1062,9 @@ hipError_t launch_ingest_part(const TableView& t, const SketchView& sk, const Sp
         default: break;
     }
 #endif
+    if (variant == 17)   // round 6: pass 1 without its barriers (published cache entries, staging groups drained by their last writer)
+        return sk.flags ? part::run<true, false, false, true, 0, false, true>(tq, sk, q, d_records, n, seq_base, s)
+                        : part::run<false, false, false, true, 0, false, true>(tq, sk, q, d_records, n, seq_base, s);
     if (variant == 11)   // A/B: pass 1 without the admission filter (first come, first served)
         return sk.flags ? part::run<true, false, false, false>(tq, sk, q, d_records, n, seq_base, s)
                         : part::run<false, false, false, false>(tq, sk, q, d_records, n, seq_base, s);

@@ -312,7 +312,7 @@ hipError_t launch_ingest_cached(const TableView& t, const SketchView& sk, const 
 constexpr uint64_t kDirectMaxBatch = 6144;
 constexpr uint64_t kPartMinBatch = 3u << 17;   // 384 Ki (round 3: 0.114 against 0.128 ms at 256 Ki, 0.18 against 0.23 at 512 Ki)
 constexpr uint64_t kDedupCachedMinBatch = 1u << 16;
-static bool takes_two_pass(int variant, uint64_t n) { return (variant >= 8 && variant <= 11) || (variant >= 20 && variant <= 28) || ((variant == 0 || variant == 30) && n >= kPartMinBatch); }
+static bool takes_two_pass(int variant, uint64_t n) { return (variant >= 8 && variant <= 11) || variant == 17 || (variant >= 20 && variant <= 28) || ((variant == 0 || variant == 30) && n >= kPartMinBatch); }
 // Shipping variants: 0 (by batch size), 1 direct, 3/4/5/7 geometries of the single-pass cached kernel, 10/11 two-pass
 // (with / without the admission filter). 6/8/9 are the phase-timing builds and exist only in libnfagg_diag.so (-DNFAGG_DIAG).
 bool ingest_variant_supported(int variant) {
@@ -320,6 +320,7 @@ bool ingest_variant_supported(int variant) {
     if (variant == 6 || variant == 8 || variant == 9 || (variant >= 13 && variant <= 15) || (variant >= 20 && variant <= 28)) return true;
 #endif
     return variant == 0 || variant == 1 || variant == 3 || variant == 4 || variant == 5 || variant == 7 || variant == 10 || variant == 11 || variant == 12 ||
+           variant == 17 ||   // 17: the two-pass fold always, pass 1 without its barriers (nfagg_ingest_part.hip k_pass1_free)
            variant == 16 ||   // 16 (kernel-dedup mode, tests): the cached passes always, the partition pass always sorts its items first
            variant == 30;     // 30 (tests): everything as 0, but nfagg_account always takes its kernel chain — the fallback of the epochs-found-first path
 }

@@ -38,7 +38,7 @@ def test_device_generator_matches_host_generator(nf, O, torch):
         assert d.cpu().numpy().tobytes() == h.tobytes(), kw
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 1, 3, 4, 5, 7, 10])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 3, 4, 5, 7, 10, 17])
 def test_device_ingest_parity_2m_records(nf, O, torch, ingest_variant):
     n, keys = 2_000_000, 100_000
     th = nf.synth.zipf_thresholds(keys, 1.1)

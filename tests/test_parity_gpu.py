@@ -207,7 +207,7 @@ def test_timeout_eviction_fires_under_sustained_load(nf):
 
 # ---------------------------------------------------------------- seeded streams vs the oracle
 @pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("ingest_variant", [0, 1, 3, 4, 5, 7, 10, 11])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 3, 4, 5, 7, 10, 11, 17])
 @pytest.mark.parametrize("batch", [1 << 30, 1000, 257])
 def test_stream_parity(nf, O, variant, ingest_variant, batch):
     th = O.zipf_thresholds(3000, 1.1)
@@ -228,7 +228,7 @@ def test_config1_10k_records_1k_keys(nf, O):
     assert len(want[0][1]) == len(np.unique(recs["id"]["src_port"]))
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 1, 3, 4, 5, 7, 10, 11])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 3, 4, 5, 7, 10, 11, 17])
 def test_hot_key_stream(nf, O, ingest_variant):
     """BASELINE configs[4] shape: 90 % of the records are one flow (LDS / atomic contention)."""
     th = O.zipf_thresholds(5000, 1.1)
@@ -236,7 +236,7 @@ def test_hot_key_stream(nf, O, ingest_variant):
     check_against_oracle(nf, O, recs, 1 << 16, 1 << 30, ingest_variant=ingest_variant)
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 1, 7, 10])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 7, 10, 17])
 def test_wraparound_and_zero_fields(nf, O, ingest_variant):
     """u64 bytes / u32 packets wrap (flow_content.go:42-43) and all-zero optional fields."""
     recs = O.gen_stream(3000, seed=9, n_keys=3, variant=1)   # ~1000 records per key, wrap values injected
@@ -245,7 +245,7 @@ def test_wraparound_and_zero_fields(nf, O, ingest_variant):
     check_against_oracle(nf, O, z, 100, 1 << 30, ingest_variant=ingest_variant)
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 1, 7, 10])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 7, 10, 17])
 @pytest.mark.parametrize("max_entries,batch", [(2, 1 << 30), (100, 1 << 30), (100, 333), (1, 50), (999, 4096), (3000, 1 << 30)])
 def test_evict_on_full_inside_batches(nf, O, max_entries, batch, ingest_variant):
     """account.go:85-94: the arrival of the (maxEntries+1)-th distinct key flushes what was
@@ -318,7 +318,7 @@ def test_small_staging_ring_many_chunks(nf, O):
     check_against_oracle(nf, O, recs, 4096, 1 << 30, staging_records=1000)
 
 
-@pytest.mark.parametrize("ingest_variant", [0, 1, 7, 10])
+@pytest.mark.parametrize("ingest_variant", [0, 1, 7, 10, 17])
 @pytest.mark.parametrize("n_shards", [2, 8])
 def test_sharded_tables_cover_the_stream(nf, O, n_shards, ingest_variant):
     """Records shard by flow-key hash; every shard folds only its own keys; the
