@@ -10,6 +10,7 @@ import netobserv_ebpf_agent_amd as nf
 from netobserv_ebpf_agent_amd import synth
 def arg(name, d): return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else d
 n, keys, hot, reps = 100_000_000, arg("--flows", 1_000_000), arg("--hot", 0), arg("--reps", 5)
+variants = [int(x) for x in (sys.argv[sys.argv.index("--variants") + 1] if "--variants" in sys.argv else "0,17").split(",")]
 th = synth.zipf_thresholds(keys, 1.1)
 d_th = torch.from_numpy(th.view(np.int64)).cuda()
 d = torch.empty(n * 144, dtype=torch.uint8, device="cuda")
@@ -18,7 +19,7 @@ synth.stream_device(d.data_ptr(), n, seed=2, n_keys=keys, d_thresholds=d_th.data
 res, ev = {"flows": keys, "hot_permille": hot}, {}
 M = 1 << 21 if keys <= 1_000_000 else 1 << 24
 for rnd in range(2):
-    for v in (0, 17):
+    for v in variants:
         with nf.FlowTable(max_entries=M, ingest_variant=v, profile=True) as tab:
             for rep in range(reps + 1):
                 if rep == 1:
@@ -30,5 +31,5 @@ for rnd in range(2):
             res.setdefault("variant_%d" % v, []).append({"fold_call_ms": round(st.ingest_kernel_ms / st.ingest_launches, 4), "bypassed_share": round(st.records_bypassed / (n * (reps + 1)), 4), "flows": int(flows)})
             if rnd == 0:
                 ev[v] = nf.sort_by_key(out[: flows * 144].cpu().numpy().view(nf.FLOW_RECORD))
-res["bit_identical"] = bool(ev[0].tobytes() == ev[17].tobytes())
+res["bit_identical"] = all(ev[v].tobytes() == ev[variants[0]].tobytes() for v in variants)
 print(json.dumps(res))
