@@ -204,28 +204,32 @@ def test_bench_gpus_2_as_a_plain_process_rehearsed_on_one_gpu(nf):
     assert j["roofline"]["alg_bytes_per_record"] == 522 and j["roofline"]["launch_ms"] > 0
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_bench_gpus_2_evictions_equal_one_accounter(nf, O, overlap, tmp_path):
+@pytest.mark.parametrize("overlap,dedup", [(True, False), (False, False), (True, True)])
+def test_bench_gpus_2_evictions_equal_one_accounter(nf, O, overlap, dedup, tmp_path):
     """What `bench.py --gpus 2` EVICTS — with window w's tick (sketch all-reduce, export, all-to-all, merge, evict) running on a host
     thread beside window w + 1's fold on the rank's second table (the default since round 6), and with everything in sequence
     (--no-overlap) — against ONE oracle Accounter (pkg/flow/account.go:58-124) over the common stream: the union of the two ranks'
-    last evictions, bit for bit. Two gloo ranks on one device."""
+    last evictions, bit for bit. Two gloo ranks on one device. dedup: configs[4]'s line (--dedup --hot-permille 900: sub-flow
+    tables, the sketches fed by the kernel-dedup fold's flushes) against ONE kernel-dedup table (bpf/flows.c:76-143)."""
     n, keys = 500_000, 40_000
     dump = str(tmp_path / "ev")
     argv = ["--gpus", "2", "--same-device", "--backend", "gloo", "--records", str(n), "--flows", str(keys), "--steps", "3", "--warmup", "1",
-            "--dump-evictions", dump] + ([] if overlap else ["--no-overlap"])
+            "--dump-evictions", dump] + ([] if overlap else ["--no-overlap"]) + (["--dedup", "--hot-permille", "900"] if dedup else [])
     j = _bench(*argv)
     assert j["config"]["windows_overlapped"] is overlap
     from netobserv_ebpf_agent_amd import synth
     th = synth.zipf_thresholds(2 * keys, 1.1)
-    whole = synth.stream_host(2 * n, seed=2, n_keys=2 * keys, thresholds=th)
-    want = O.run_accounter(whole, 1 << 22)[0][1]
+    whole = synth.stream_host(2 * n, seed=2, n_keys=2 * keys, thresholds=th, hot_permille=900 if dedup else 0, variant=2 if dedup else 0)
+    want = O.run_accounter(whole, 1 << 22, mode=1 if dedup else 0)[0][1]
     got = np.concatenate([np.fromfile("%s.%d" % (dump, r), dtype=nf.FLOW_RECORD) for r in range(2)])
     assert len(got) == len(want) == j["config"]["evicted_flows_per_step"]
-    assert_records_equal(nf.sort_by_key(got), want, "bench.py --gpus 2 (%s): union of the ranks' evictions vs ONE Accounter" % ("overlapped" if overlap else "in sequence"))
+    assert_records_equal(nf.sort_by_key(got), want, "bench.py --gpus 2 (%s%s): union of the ranks' evictions vs ONE %s"
+                         % ("overlapped" if overlap else "in sequence", ", kernel-dedup" if dedup else "", "kernel-dedup table" if dedup else "Accounter"))
     if overlap:
         ov = j["config"]["exchange"]["overlapped"]
         assert ov["wall_ms_per_window"] > 0 and ov["tick_ms_beside_a_fold"] > 0
+    if dedup:
+        assert j["roofline"]["sketch_launch_ms"] is None           # the sketches are fed by the fold itself: no second pass
 
 
 def test_bench_presharded_line_still_runs(nf):

@@ -104,3 +104,19 @@ def test_truncated_ring_tail_stops_the_drain_but_not_the_path(nf, O):
         assert tab.staging_commit(n) == (nf.OK, 49)
         got = nf.sort_by_key(tab.evict(nf.REASON_CLOSING))
     assert_records_equal(got, O.run_accounter(recs[:49], 1 << 12)[0][1])
+
+
+def test_an_explicitly_shaped_host_pool_survives_nfagg_create(nf):
+    """nfagg_host_threads(2, -1) is how an agent keeps the library's copy workers off its own cores (include/nfagg.h); the implicit
+    default of the first nfagg_create — 16 workers bound to the GPU's NUMA node — must not undo it (round-5 advisor finding).
+    Run in a process of its own: the pool is per process and other tests have created handles already."""
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import netobserv_ebpf_agent_amd as nf\n"
+            "assert nf.host_threads(2, -1) == 2\n"
+            "with nf.FlowTable(max_entries=1024) as tab:\n"
+            "    info = nf.host_info()\n"
+            "assert info['workers'] == 2 and not info['bound'] and info['numa_node'] == -1, info\n"
+            "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stdout[-500:] + p.stderr[-2000:]
