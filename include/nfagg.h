@@ -419,16 +419,18 @@ int nfagg_evict_device(nfagg_handle* h, int reason, void* d_out, size_t cap, siz
  * nfagg_ingest. *consumed = leading records folded. Returns NFAGG_OK when all n are, NFAGG_TRUNCATED when `out` has no room
  * for another eviction (out_cap - records written < live flows; keep out_cap >= max_entries) or max_epochs are used up:
  * drain `out`, then call again with the rest (a pending eviction is delivered first).
- * With a small CACHE_MAX_FLOWS (the reference ships 5000, pkg/config/config.go:146) the stream stops on "full" every few
- * thousand records; here that whole loop runs on the device (max_entries <= 32768, NFAGG_MODE_ACCOUNTER). A call of more than a few
- * epochs (n >= 4 * max_entries + 65536) has its epochs FOUND FIRST (csrc/nfagg_epoch_par.hip): previous-occurrence
- * links from one sort of (key hash, index) keys, one prefix count per epoch — WHERE the loop of account.go:81-96 evicts does not
- * need the map — and every complete epoch is then folded on its own, all of them at once, each flow's records gathered in arrival
- * order and folded as flow_content.go:28-61 folds them, straight into `out`; only the call's first epoch (it continues what the
- * table holds) and its last (it stays live) touch the table. Sketches are fed along. Shorter calls take a chain of small kernels
- * driven by a control block in device memory, replayed from a hipGraph (csrc/nfagg_epoch_chain.hip; the host reads the control
- * block back once per 24 windows); ingest_variant 30 forces that chain for every call (tests). Same evictions, in the same order,
- * either way.
+ * With a small CACHE_MAX_FLOWS (the reference ships 5000, pkg/config/config.go:146, deploys 10 000, scripts/agent.yml:35-36, and
+ * benchmarks 1 k / 10 k / 100 k, pkg/flow/tracer_map_bench_test.go:64-111) the stream stops on "full" every few thousand records;
+ * here that whole loop runs on the device (NFAGG_MODE_ACCOUNTER, max_entries <= 2^22). A call of more than five chain windows'
+ * worth of records (n >= 5 / (1 / 16384 + 1 / (2 max_entries)): 31 k at 5000 entries, never more than 80 k) has its epochs FOUND
+ * FIRST (csrc/nfagg_epoch_par.hip): previous-occurrence links from one sort of (key hash, index) keys, one prefix
+ * count per epoch — WHERE the loop of account.go:81-96 evicts does not need the map — and every complete epoch is then folded on
+ * its own, all of them at once, each flow's records gathered in arrival order and folded as flow_content.go:28-61 folds them,
+ * straight into `out`; only the call's first epoch (it continues what the table holds) and its last (it stays live) touch the
+ * table. Sketches are fed along. Shorter calls take a chain of small kernels driven by a control block in device memory, replayed
+ * from hipGraphs of 2 / 6 / 24 windows (csrc/nfagg_epoch_chain.hip; max_entries <= 32768; beyond: the optimistic fold of
+ * nfagg_ingest); ingest_variant 30 forces that chain for every call (tests). Same evictions, in the same order, either way.
+ * A call costs ~80 us whatever it holds: gather records (64 Ki, or what 1 ms brings) before calling — INTEGRATION.md section 3.
  * All pointers HOST memory: */
 int nfagg_account(nfagg_handle* h, const void* records, size_t n, void* out, size_t out_cap, uint64_t* epoch_end,
                   size_t max_epochs, size_t* n_epochs, size_t* consumed);

@@ -252,6 +252,19 @@ NF_DEV void load_record_head(const void* base, uint64_t i, Rec& r) {
     }
 }
 
+// ... six, when the seventh is known not to matter (pass 2: the queue entry says whether the record's dscp is non-zero)
+NF_DEV void load_record_head_6or7(const void* base, uint64_t i, Rec& r, bool need7) {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + i * kRecordBytes);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint4 v = p[k];
+        r.d[4 * k] = v.x; r.d[4 * k + 1] = v.y; r.d[4 * k + 2] = v.z; r.d[4 * k + 3] = v.w;
+    }
+    uint4 v = make_uint4(0, 0, 0, 0);                                 // dscp = 0: what the flag said
+    if (need7) v = p[6];
+    r.d[24] = v.x; r.d[25] = v.y; r.d[26] = v.z; r.d[27] = v.w;
+}
+
 NF_DEV uint4 rec_chunk(const void* recs, uint64_t i, int k) {
     return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + i * kRecordBytes)[k];
 }
@@ -319,6 +332,18 @@ NF_DEV uint32_t cache_flush_entry(const TableView& t, const SketchView& sk, Cach
 // queue by these bits without gathering a record — no gain even on a uniform 10 M-flow stream, 30.4 against 30.6 ms.)
 constexpr int kSubBits = 3, kSubs = 1 << kSubBits;
 constexpr uint32_t kIdxBits = 32 - kSubBits, kIdxMask = (1u << kIdxBits) - 1u;
+// ... and, in batches of up to 2^28 - 1 records, one bit below them says whether pass 2 needs the record's SEVENTH 16-byte unit
+// (bytes 96..111): of everything the fold reads only dscp lives there (metrics byte 58), and a record whose dscp is zero — most
+// traffic is best effort — contributes nothing to the flow's "last non-zero dscp". Without the unit a gathered record is bytes
+// 0..95: it stays inside ONE 128-byte line in 3 of the 8 alignments a 144-byte record can have instead of 2 (1.625 lines per
+// record instead of 1.75), and the gather is what bounds pass 2 (profiles/r05x_gather_flavours.txt: six units instead of seven
+// -14 % time). Pass 1 has the record in registers when it queues it: it knows.
+constexpr uint32_t kNeed7Bit = 1u << (kIdxBits - 1);                  // bit 28
+constexpr uint32_t kIdxMaskFlagged = kNeed7Bit - 1u;                  // 28-bit indices
+NF_DEV bool flag_on_for(uint64_t n) { return n <= (uint64_t)kIdxMaskFlagged; }
+NF_DEV uint32_t queue_entry(uint64_t i, uint64_t h, uint32_t sub_shift, bool tag_on, bool flag_on, const Rec& r) {
+    return (uint32_t)i | (tag_on ? ((uint32_t)(h >> sub_shift) & (uint32_t)(kSubs - 1)) << kIdxBits : 0u) | ((flag_on && r.dscp()) ? kNeed7Bit : 0u);
+}
 NF_DEV uint32_t sub_shift_of(const SpillView& q) { return q.part_shift >= (uint32_t)kSubBits ? q.part_shift - kSubBits : 0; }
 
 // ---- pass 1 ------------------------------------------------------------------------------------------------------
@@ -350,6 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
     const uint64_t tile_first = (uint64_t)blockIdx.x, tile_end = n_tiles, tile_step = (uint64_t)gridDim.x;
     unsigned long long skipped = 0, spilled = 0;
     const bool tag_on = n <= (uint64_t)kIdxMask;                       // the index leaves room for the sub-partition bits
+    const bool flag_on = flag_on_for(n);                               // ... and for the "seventh unit needed" bit
     const uint32_t sub_shift = sub_shift_of(q);
     // Drain state. The lane whose append FILLS a staging group (position kStage - 1) drains it one tile later — no lane polls the
     // 2048 group counters (round 2: two LDS reads per lane and tile) — and stores the drained group another tile later, when the
@@ -465,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
             if (!(ABL & 1)) {
                 const uint32_t p = part_of(h, q);
                 const uint32_t at = atomicAdd(&S.cnt[p], 1u);
-                const uint32_t qi = (uint32_t)i | (tag_on ? ((uint32_t)(h >> sub_shift) & (uint32_t)(kSubs - 1)) << kIdxBits : 0u);
+                const uint32_t qi = queue_entry(i, h, sub_shift, tag_on, flag_on, r);
                 if (at < (uint32_t)kStage) { S.buf[p][at] = qi; if (at == (uint32_t)kStage - 1) fill_p[1] = p; }
                 else { carry = qi; carry_p = p; }
             }
@@ -620,6 +646,7 @@ __global__ __launch_bounds__(kBlock) void k_pass1_free(TableView t, SketchView s
     const uint64_t tile_first = (uint64_t)blockIdx.x, tile_step = (uint64_t)gridDim.x;
     unsigned long long skipped = 0, spilled = 0;
     const bool tag_on = n <= (uint64_t)kIdxMask;
+    const bool flag_on = flag_on_for(n);
     const uint32_t sub_shift = sub_shift_of(q);
     constexpr int kMine = kSpillParts / kBlock;
     // a group this lane drained: its queue position is reserved when it is drained, the store follows a tile later (the
@@ -690,7 +717,7 @@ __global__ __launch_bounds__(kBlock) void k_pass1_free(TableView t, SketchView s
         if (v && ent < 0) {
             spilled++;
             const uint32_t p = part_of(h, q);
-            const uint32_t qi = (uint32_t)i | (tag_on ? ((uint32_t)(h >> sub_shift) & (uint32_t)(kSubs - 1)) << kIdxBits : 0u);
+            const uint32_t qi = queue_entry(i, h, sub_shift, tag_on, flag_on, r);
             if (!append(p, qi, 1)) {
                 if (carry == 0xffffffffu) { carry = qi; carry_p = p; carried_for = 0; }
                 else overflow_push_one(q, qi);                     // (a carried item is still waiting: at most one per lane)
@@ -750,8 +777,10 @@ struct Pass2Lds {                 // after the Cache
 // sub-partition) instead of being merged on their own; COHERENT: the entries were written by this workgroup (read past L1).
 template <bool SKETCH, bool TIMING, bool RETRY, bool COHERENT>
 NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass2Lds& P, const uint32_t* queue, uint32_t count,
-                        uint32_t* retry_to, const void* recs, uint64_t seq_base, uint32_t idx_mask, unsigned long long& direct,
+                        uint32_t* retry_to, const void* recs, uint64_t seq_base, uint32_t idx_mask, uint32_t need7_bit, unsigned long long& direct,
                         unsigned long long* ph, unsigned long long& tp) {
+    // need7_bit: kNeed7Bit when pass 1 flagged its queue entries (batches of < 2^28 records), 0 when every record's seventh unit is read
+    auto need7 = [&](uint32_t qi) -> bool { return need7_bit == 0u || (qi & need7_bit) != 0u; };
 #define NF_TICK2(k) do { if (TIMING) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
     const int tid = threadIdx.x;
     const uint32_t seq_base32 = (uint32_t)seq_base;
@@ -766,7 +795,7 @@ NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass
         valid = qi != 0xffffffffu; i = valid ? (qi & idx_mask) : 0;
         qi_cur = qi;
         if (pos + kBlock < count) qi_next = qload(pos + kBlock);
-        load_record_head(recs, i, r);
+        load_record_head_6or7(recs, i, r, need7(qi));
     }
     for (uint32_t tile = 0; tile < n_tiles; tile++) {
         bool valid_n; uint32_t i_n; Rec r_n; uint32_t qi_nn = 0xffffffffu;
@@ -774,7 +803,7 @@ NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass
             valid_n = qi_next != 0xffffffffu; i_n = valid_n ? (qi_next & idx_mask) : 0;
             const uint64_t p2 = (uint64_t)(tile + 2) * kBlock + tid;
             if (p2 < count) qi_nn = qload((uint32_t)p2);
-            load_record_head(recs, i_n, r_n);
+            load_record_head_6or7(recs, i_n, r_n, need7(qi_next));
         }
         uint64_t w[5];
         uint64_t h = 0;
@@ -883,11 +912,13 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
     // sub-partition = the three hash bits below the partition's (slot-index bits, nfagg_create); retries need 29-bit indices
     // and room for the sorted list behind the queue
     const bool tagged = n <= (uint64_t)kIdxMask;                      // pass 1 put the sub-partition bits above the index
-    const uint32_t idx_mask = tagged ? kIdxMask : 0xffffffffu;
+    const bool flagged = flag_on_for(n);                              // ... and the "seventh unit needed" bit below them
+    const uint32_t idx_mask = flagged ? kIdxMaskFlagged : (tagged ? kIdxMask : 0xffffffffu);
+    const uint32_t need7_bit = flagged ? kNeed7Bit : 0u;
     const uint32_t sorted_at = (count + 3u) & ~3u;
     const bool retry_ok = tagged && (uint64_t)sorted_at + count <= q.qcap;
-    if (retry_ok) pass2_round<SKETCH, TIMING, true, false>(t, sk, L, P, my_queue, count, my_queue, recs, seq_base, idx_mask, direct, ph, tp);
-    else pass2_round<SKETCH, TIMING, false, false>(t, sk, L, P, my_queue, count, nullptr, recs, seq_base, idx_mask, direct, ph, tp);
+    if (retry_ok) pass2_round<SKETCH, TIMING, true, false>(t, sk, L, P, my_queue, count, my_queue, recs, seq_base, idx_mask, need7_bit, direct, ph, tp);
+    else pass2_round<SKETCH, TIMING, false, false>(t, sk, L, P, my_queue, count, nullptr, recs, seq_base, idx_mask, need7_bit, direct, ph, tp);
 #define NF_TICK3(k) do { if (TIMING) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
     pass2_flush<SKETCH>(t, sk, L, P, recs, seq_base32);
     NF_TICK3(4);                                                      // phase 4 = the flushes, phase 6 = sort + cache set-up
@@ -945,7 +976,7 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
             }
             const uint32_t c = P.sub_off[e] - P.sub_off[s];
             if (c) {
-                pass2_round<SKETCH, TIMING, false, true>(t, sk, L, P, sorted + P.sub_off[s], c, nullptr, recs, seq_base, idx_mask, direct, ph, tp);
+                pass2_round<SKETCH, TIMING, false, true>(t, sk, L, P, sorted + P.sub_off[s], c, nullptr, recs, seq_base, idx_mask, need7_bit, direct, ph, tp);
                 open = true;
             }
             runs += e - s;
@@ -969,7 +1000,7 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
 template <bool SKETCH>
 __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
                                                         uint64_t n, uint64_t seq_base) {
-    const uint32_t idx_mask = n <= (uint64_t)kIdxMask ? kIdxMask : 0xffffffffu;
+    const uint32_t idx_mask = flag_on_for(n) ? kIdxMaskFlagged : (n <= (uint64_t)kIdxMask ? kIdxMask : 0xffffffffu);
     uint32_t count = *q.ovf_tail;
     if (count > q.ovf_cap) count = q.ovf_cap;
     unsigned long long direct = 0;

@@ -1,4 +1,4 @@
-"""CPU only. The claim behind DESIGN.md §10.4 / §13.1 item 1: WHERE the evict-on-full loop of Accounter.Account
+"""CPU only. The claim behind DESIGN.md §4.11b (first stated in §10.4 and HISTORY.md §13.1 item 1): WHERE the evict-on-full loop of Accounter.Account
 (pkg/flow/account.go:81-96) cuts a record stream into epochs can be computed without the flow table, from previous-occurrence
 links — prev(i) = the index of the previous record of record i's flow in the call, -1 when there is none:
 

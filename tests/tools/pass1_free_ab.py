@@ -10,17 +10,18 @@ import netobserv_ebpf_agent_amd as nf
 from netobserv_ebpf_agent_amd import synth
 def arg(name, d): return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else d
 n, keys, hot, reps = 100_000_000, arg("--flows", 1_000_000), arg("--hot", 0), arg("--reps", 5)
+dedup = "--dedup" in sys.argv
 variants = [int(x) for x in (sys.argv[sys.argv.index("--variants") + 1] if "--variants" in sys.argv else "0,17").split(",")]
 th = synth.zipf_thresholds(keys, 1.1)
 d_th = torch.from_numpy(th.view(np.int64)).cuda()
 d = torch.empty(n * 144, dtype=torch.uint8, device="cuda")
 out = torch.empty((keys + 4096) * 144, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
-synth.stream_device(d.data_ptr(), n, seed=2, n_keys=keys, d_thresholds=d_th.data_ptr(), hot_permille=hot); torch.cuda.synchronize()
-res, ev = {"flows": keys, "hot_permille": hot}, {}
+synth.stream_device(d.data_ptr(), n, seed=2, n_keys=keys, d_thresholds=d_th.data_ptr(), hot_permille=hot, variant=2 if dedup else 0); torch.cuda.synchronize()
+res, ev = {"flows": keys, "hot_permille": hot, "dedup": dedup}, {}
 M = 1 << 21 if keys <= 1_000_000 else 1 << 24
 for rnd in range(2):
     for v in variants:
-        with nf.FlowTable(max_entries=M, ingest_variant=v, profile=True) as tab:
+        with nf.FlowTable(max_entries=M, ingest_variant=v, profile=True, mode=nf.MODE_KERNEL_DEDUP if dedup else nf.MODE_ACCOUNTER) as tab:
             for rep in range(reps + 1):
                 if rep == 1:
                     tab.sync(); tab.reset_profile()
