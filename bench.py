@@ -124,6 +124,20 @@ def main(argv=None):
     return rank_main(args)
 
 
+def frac_of_a_real_bound(rf):
+    """SURVEY 8(d)'s algorithmic bytes over the launch time are a MODEL rate (a slot read + write per record that a fold in LDS never
+    moves). Where it exceeds the peak it describes no bound: achieved / frac become those of a real one — the counter traffic when a
+    PMC file of this workload taken on the loaded library exists, else the records read once — and frac_basis says which; the model
+    stays under alg_model_GBs (round-5 review, item 3: no frac above 1 anywhere in a bench line)."""
+    if rf.get("frac") is None or rf["frac"] <= 1.0:
+        return rf
+    if rf.get("traffic") and not rf.get("traffic_stale"):
+        rf["achieved"], rf["frac"], rf["frac_basis"] = rf["traffic"], rf["frac_traffic"], "counter_traffic"
+    elif rf.get("frac_stream_floor") is not None:
+        rf["achieved"], rf["frac"], rf["frac_basis"] = round(rf["frac_stream_floor"] * HBM_PEAK_GBS, 1), rf["frac_stream_floor"], "stream_floor"
+    return rf
+
+
 class _QuietStdout:
     """stdout carries ONE JSON line (the driver's contract). Whatever libraries print there while the bench runs — RCCL's
     version banner at communicator creation, a compiler invoked by ensure_built() — is sent to stderr instead: file
@@ -555,11 +569,7 @@ def rank_main(args):
                 break
         # ---- a model rate above the peak describes no bound: the line's fraction is that of a real one (round-5 review, item 3)
         rf = out["roofline"]
-        if rf["frac"] is not None and rf["frac"] > 1.0:
-            if rf.get("traffic") and not rf.get("traffic_stale"):
-                rf["achieved"], rf["frac"], rf["frac_basis"] = rf["traffic"], rf["frac_traffic"], "counter_traffic"
-            elif rf.get("frac_stream_floor") is not None:
-                rf["achieved"], rf["frac"], rf["frac_basis"] = round(rf["frac_stream_floor"] * HBM_PEAK_GBS, 1), rf["frac_stream_floor"], "stream_floor"
+        frac_of_a_real_bound(rf)
         if sketch_sep_ms:
             rf["sketch_launch_in_launch_ms"] = True
         # ---- CPU baseline: the oracle (C restatement of pkg/flow.Accounter), 1 core, bounded sample

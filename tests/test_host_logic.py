@@ -178,3 +178,19 @@ def test_bench_stdout_carries_the_json_line_only():
     assert p.stdout == '{"value": 1}\n'
     for s in ("python-level chatter", "library-level chatter on fd 1", "a child process", "after the line"):
         assert s in p.stderr
+
+
+def test_bench_line_never_reports_a_fraction_above_one():
+    """bench.py frac_of_a_real_bound: SURVEY 8(d)'s algorithmic bytes over the launch time are a model; where the model exceeds the
+    peak the line's achieved / frac are those of a real bound (counter traffic if a fresh PMC file exists, else the stream floor)."""
+    import bench
+    ok = {"achieved": 7800.0, "frac": 0.975, "frac_basis": "alg_model", "alg_model_GBs": 7800.0, "traffic": 4900.0, "frac_traffic": 0.6125,
+          "traffic_stale": False, "frac_stream_floor": 0.36}
+    assert bench.frac_of_a_real_bound(dict(ok)) == ok                                   # at or below the peak: the contract's definition stands
+    over = dict(ok, achieved=8264.7, frac=1.0331, alg_model_GBs=8264.7)
+    got = bench.frac_of_a_real_bound(dict(over))
+    assert (got["frac"], got["achieved"], got["frac_basis"], got["alg_model_GBs"]) == (0.6125, 4900.0, "counter_traffic", 8264.7)
+    stale = bench.frac_of_a_real_bound(dict(over, traffic_stale=True))                 # a traffic file of another build does not count
+    assert stale["frac_basis"] == "stream_floor" and stale["frac"] == 0.36 and stale["achieved"] == round(0.36 * bench.HBM_PEAK_GBS, 1)
+    none = bench.frac_of_a_real_bound(dict(over, traffic=None, frac_traffic=None))
+    assert none["frac_basis"] == "stream_floor" and none["frac"] <= 1.0
