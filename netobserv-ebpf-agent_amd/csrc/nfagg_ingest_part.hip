@@ -252,16 +252,18 @@ NF_DEV void load_record_head(const void* base, uint64_t i, Rec& r) {
     }
 }
 
-// ... six, when the seventh is known not to matter (pass 2: the queue entry says whether the record's dscp is non-zero)
-NF_DEV void load_record_head_6or7(const void* base, uint64_t i, Rec& r, bool need7) {
+// ... five or six, when the queue entry says that the others do not matter (pass 2: need6 / need7, see queue_entry)
+NF_DEV void load_record_head_5to7(const void* base, uint64_t i, Rec& r, bool need6, bool need7) {
     const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + i * kRecordBytes);
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
+    for (int k = 0; k < 5; k++) {
         const uint4 v = p[k];
         r.d[4 * k] = v.x; r.d[4 * k + 1] = v.y; r.d[4 * k + 2] = v.z; r.d[4 * k + 3] = v.w;
     }
-    uint4 v = make_uint4(0, 0, 0, 0);                                 // dscp = 0: what the flag said
+    uint4 u = make_uint4(0, 0, 0, 0), v = make_uint4(0, 0, 0, 0);     // sampling = 0, dst_mac's last four bytes = 0, dscp = 0: what the flags said
+    if (need6) u = p[5];
     if (need7) v = p[6];
+    r.d[20] = u.x; r.d[21] = u.y; r.d[22] = u.z; r.d[23] = u.w;
     r.d[24] = v.x; r.d[25] = v.y; r.d[26] = v.z; r.d[27] = v.w;
 }
 
@@ -332,19 +334,34 @@ NF_DEV uint32_t cache_flush_entry(const TableView& t, const SketchView& sk, Cach
 // queue by these bits without gathering a record — no gain even on a uniform 10 M-flow stream, 30.4 against 30.6 ms.)
 constexpr int kSubBits = 3, kSubs = 1 << kSubBits;
 constexpr uint32_t kIdxBits = 32 - kSubBits, kIdxMask = (1u << kIdxBits) - 1u;
-// ... and, in batches of up to 2^28 - 1 records, one bit below them says whether pass 2 needs the record's SEVENTH 16-byte unit
-// (bytes 96..111): of everything the fold reads only dscp lives there (metrics byte 58), and a record whose dscp is zero — most
-// traffic is best effort — contributes nothing to the flow's "last non-zero dscp". Without the unit a gathered record is bytes
-// 0..95: it stays inside ONE 128-byte line in 3 of the 8 alignments a 144-byte record can have instead of 2 (1.625 lines per
-// record instead of 1.75), and the gather is what bounds pass 2 (profiles/r05x_gather_flavours.txt: six units instead of seven
-// -14 % time). Pass 1 has the record in registers when it queues it: it knows.
+// ... and below them, while the batch leaves room, bits that say which of the record's last 16-byte units pass 2 NEEDS. Pass 1 has the
+// record in registers when it queues it: it knows. Of everything the fold reads
+//   * only dscp lives in the SEVENTH unit (bytes 96..111: metrics byte 58), and a record whose dscp is zero — most traffic is best
+//     effort — contributes nothing to the flow's "last non-zero dscp": bit 28, batches of up to 2^28 - 1 records;
+//   * only sampling (metrics byte 52) and the last four bytes of dst_mac live in the SIXTH (bytes 80..95); the fold wants sampling when
+//     it is non-zero and of dst_mac only WHETHER it is non-zero, which its first two bytes (unit five) answer unless they are zero
+//     and the last four are not: bit 27, batches of up to 2^27 - 1 records.
+// Without them a gathered record is bytes 0..79 / 0..95: a 144-byte record at offset 16 k of its 128-byte line (k = i mod 8) keeps
+// 80 bytes inside ONE line for k <= 3, 96 for k <= 2, 112 only for k <= 1 — 1.5 / 1.625 / 1.75 lines per gathered record — and the
+// gather is what bounds pass 2 (profiles/r05x_gather_flavours.txt: six units instead of seven -14 % time;
+// profiles/r06x_pass2_fewer_units.txt: the 100 M-record call 5.22 -> 5.04 ms with the first bit alone).
 constexpr uint32_t kNeed7Bit = 1u << (kIdxBits - 1);                  // bit 28
-constexpr uint32_t kIdxMaskFlagged = kNeed7Bit - 1u;                  // 28-bit indices
-NF_DEV bool flag_on_for(uint64_t n) { return n <= (uint64_t)kIdxMaskFlagged; }
-NF_DEV uint32_t queue_entry(uint64_t i, uint64_t h, uint32_t sub_shift, bool tag_on, bool flag_on, const Rec& r) {
-    return (uint32_t)i | (tag_on ? ((uint32_t)(h >> sub_shift) & (uint32_t)(kSubs - 1)) << kIdxBits : 0u) | ((flag_on && r.dscp()) ? kNeed7Bit : 0u);
+constexpr uint32_t kNeed6Bit = 1u << (kIdxBits - 2);                  // bit 27
+constexpr uint32_t kIdxMaskFlagged = kNeed7Bit - 1u;                  // 28-bit indices: one flag
+constexpr uint32_t kIdxMaskFlagged2 = kNeed6Bit - 1u;                 // 27-bit indices: both flags
+// the index's share of a queue entry in a batch of n records (and with it: which flags the entries carry)
+NF_DEV uint32_t entry_idx_mask(uint64_t n) {
+    return n <= (uint64_t)kIdxMaskFlagged2 ? kIdxMaskFlagged2 : (n <= (uint64_t)kIdxMaskFlagged ? kIdxMaskFlagged : (n <= (uint64_t)kIdxMask ? kIdxMask : 0xffffffffu));
 }
 NF_DEV uint32_t sub_shift_of(const SpillView& q) { return q.part_shift >= (uint32_t)kSubBits ? q.part_shift - kSubBits : 0; }
+NF_DEV uint32_t queue_entry(uint64_t i, uint64_t h, uint32_t sub_shift, uint32_t idx_mask, const Rec& r) {
+    uint32_t e = (uint32_t)i;
+    if (idx_mask <= kIdxMask) e |= ((uint32_t)(h >> sub_shift) & (uint32_t)(kSubs - 1)) << kIdxBits;
+    if (idx_mask <= kIdxMaskFlagged && r.dscp()) e |= kNeed7Bit;
+    // r.d[19] >> 16 = dst_mac's first two bytes, r.d[20] = its last four, r.d[23] = sampling
+    if (idx_mask <= kIdxMaskFlagged2 && (r.d[23] != 0u || ((r.d[19] >> 16) == 0u && r.d[20] != 0u))) e |= kNeed6Bit;
+    return e;
+}
 
 // ---- pass 1 ------------------------------------------------------------------------------------------------------
 // 256 workgroups stream records[0..n), tiles of 1024 consecutive records, one per lane. Hot flows fold in the workgroup's
@@ -375,7 +392,8 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
     const uint64_t tile_first = (uint64_t)blockIdx.x, tile_end = n_tiles, tile_step = (uint64_t)gridDim.x;
     unsigned long long skipped = 0, spilled = 0;
     const bool tag_on = n <= (uint64_t)kIdxMask;                       // the index leaves room for the sub-partition bits
-    const bool flag_on = flag_on_for(n);                               // ... and for the "seventh unit needed" bit
+    const uint32_t e_mask = entry_idx_mask(n);                         // ... and for the "units needed" bits
+    (void)tag_on;                                                      // (the diag build's queue-store experiment reads it)
     const uint32_t sub_shift = sub_shift_of(q);
     // Drain state. The lane whose append FILLS a staging group (position kStage - 1) drains it one tile later — no lane polls the
     // 2048 group counters (round 2: two LDS reads per lane and tile) — and stores the drained group another tile later, when the
@@ -491,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void k_pass1(TableView t, SketchView sk, Sp
             if (!(ABL & 1)) {
                 const uint32_t p = part_of(h, q);
                 const uint32_t at = atomicAdd(&S.cnt[p], 1u);
-                const uint32_t qi = queue_entry(i, h, sub_shift, tag_on, flag_on, r);
+                const uint32_t qi = queue_entry(i, h, sub_shift, e_mask, r);
                 if (at < (uint32_t)kStage) { S.buf[p][at] = qi; if (at == (uint32_t)kStage - 1) fill_p[1] = p; }
                 else { carry = qi; carry_p = p; }
             }
@@ -645,8 +663,7 @@ __global__ __launch_bounds__(kBlock) void k_pass1_free(TableView t, SketchView s
     const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
     const uint64_t tile_first = (uint64_t)blockIdx.x, tile_step = (uint64_t)gridDim.x;
     unsigned long long skipped = 0, spilled = 0;
-    const bool tag_on = n <= (uint64_t)kIdxMask;
-    const bool flag_on = flag_on_for(n);
+    const uint32_t e_mask = entry_idx_mask(n);
     const uint32_t sub_shift = sub_shift_of(q);
     constexpr int kMine = kSpillParts / kBlock;
     // a group this lane drained: its queue position is reserved when it is drained, the store follows a tile later (the
@@ -717,7 +734,7 @@ __global__ __launch_bounds__(kBlock) void k_pass1_free(TableView t, SketchView s
         if (v && ent < 0) {
             spilled++;
             const uint32_t p = part_of(h, q);
-            const uint32_t qi = queue_entry(i, h, sub_shift, tag_on, flag_on, r);
+            const uint32_t qi = queue_entry(i, h, sub_shift, e_mask, r);
             if (!append(p, qi, 1)) {
                 if (carry == 0xffffffffu) { carry = qi; carry_p = p; carried_for = 0; }
                 else overflow_push_one(q, qi);                     // (a carried item is still waiting: at most one per lane)
@@ -779,8 +796,11 @@ template <bool SKETCH, bool TIMING, bool RETRY, bool COHERENT>
 NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass2Lds& P, const uint32_t* queue, uint32_t count,
                         uint32_t* retry_to, const void* recs, uint64_t seq_base, uint32_t idx_mask, uint32_t need7_bit, unsigned long long& direct,
                         unsigned long long* ph, unsigned long long& tp) {
-    // need7_bit: kNeed7Bit when pass 1 flagged its queue entries (batches of < 2^28 records), 0 when every record's seventh unit is read
+    // need7_bit: kNeed7Bit when pass 1 flagged its queue entries (batches of < 2^28 records), 0 when every record's seventh unit is read;
+    // the sixth unit's flag rides along in batches of < 2^27 records (idx_mask says so)
+    const uint32_t need6_bit = idx_mask == kIdxMaskFlagged2 ? kNeed6Bit : 0u;
     auto need7 = [&](uint32_t qi) -> bool { return need7_bit == 0u || (qi & need7_bit) != 0u; };
+    auto need6 = [&](uint32_t qi) -> bool { return need6_bit == 0u || (qi & need6_bit) != 0u; };
 #define NF_TICK2(k) do { if (TIMING) { const unsigned long long tn_ = __builtin_readcyclecounter(); ph[k] += tn_ - tp; tp = tn_; } } while (0)
     const int tid = threadIdx.x;
     const uint32_t seq_base32 = (uint32_t)seq_base;
@@ -795,7 +815,7 @@ NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass
         valid = qi != 0xffffffffu; i = valid ? (qi & idx_mask) : 0;
         qi_cur = qi;
         if (pos + kBlock < count) qi_next = qload(pos + kBlock);
-        load_record_head_6or7(recs, i, r, need7(qi));
+        load_record_head_5to7(recs, i, r, need6(qi), need7(qi));
     }
     for (uint32_t tile = 0; tile < n_tiles; tile++) {
         bool valid_n; uint32_t i_n; Rec r_n; uint32_t qi_nn = 0xffffffffu;
@@ -803,7 +823,7 @@ NF_DEV void pass2_round(const TableView& t, const SketchView& sk, Cache& L, Pass
             valid_n = qi_next != 0xffffffffu; i_n = valid_n ? (qi_next & idx_mask) : 0;
             const uint64_t p2 = (uint64_t)(tile + 2) * kBlock + tid;
             if (p2 < count) qi_nn = qload((uint32_t)p2);
-            load_record_head_6or7(recs, i_n, r_n, need7(qi_next));
+            load_record_head_5to7(recs, i_n, r_n, need6(qi_next), need7(qi_next));
         }
         uint64_t w[5];
         uint64_t h = 0;
@@ -912,9 +932,8 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
     // sub-partition = the three hash bits below the partition's (slot-index bits, nfagg_create); retries need 29-bit indices
     // and room for the sorted list behind the queue
     const bool tagged = n <= (uint64_t)kIdxMask;                      // pass 1 put the sub-partition bits above the index
-    const bool flagged = flag_on_for(n);                              // ... and the "seventh unit needed" bit below them
-    const uint32_t idx_mask = flagged ? kIdxMaskFlagged : (tagged ? kIdxMask : 0xffffffffu);
-    const uint32_t need7_bit = flagged ? kNeed7Bit : 0u;
+    const uint32_t idx_mask = entry_idx_mask(n);                      // ... and the "units needed" bits below them
+    const uint32_t need7_bit = idx_mask <= kIdxMaskFlagged ? kNeed7Bit : 0u;
     const uint32_t sorted_at = (count + 3u) & ~3u;
     const bool retry_ok = tagged && (uint64_t)sorted_at + count <= q.qcap;
     if (retry_ok) pass2_round<SKETCH, TIMING, true, false>(t, sk, L, P, my_queue, count, my_queue, recs, seq_base, idx_mask, need7_bit, direct, ph, tp);
@@ -1000,7 +1019,7 @@ __global__ __launch_bounds__(kBlock) void k_pass2(TableView t, SketchView sk, Sp
 template <bool SKETCH>
 __global__ __launch_bounds__(256) void k_merge_overflow(TableView t, SketchView sk, SpillView q, const void* __restrict__ recs,
                                                         uint64_t n, uint64_t seq_base) {
-    const uint32_t idx_mask = flag_on_for(n) ? kIdxMaskFlagged : (n <= (uint64_t)kIdxMask ? kIdxMask : 0xffffffffu);
+    const uint32_t idx_mask = entry_idx_mask(n);
     uint32_t count = *q.ovf_tail;
     if (count > q.ovf_cap) count = q.ovf_cap;
     unsigned long long direct = 0;

@@ -228,8 +228,8 @@ def test_configs3_at_its_full_size_one_billion_records(nf, O, torch):
     into ONE incremental oracle Accounter (pkg/flow/account.go:58-124 restated; every chunk pre-folded on the host's cores by
     orc_local_fold_mt, then merged in arrival order), and the union of the eight ranks' evictions must be that Accounter's closing
     eviction. Beside it, what does not depend on size:
-      * two independent routes through the library deliver the SAME evictions, bit for bit: (A) one handle, three calls of
-        600 M / 300 M / 100 M records (one per form of the partition queues' entries); (B) eight unsharded handles standing for the ranks of `bench.py --gpus 8`, each folding its 125 M-record
+      * two independent routes through the library deliver the SAME evictions, bit for bit: (A) one handle, four calls of
+        540 M / 270 M / 140 M / 50 M records (one per form of the partition queues' entries); (B) eight unsharded handles standing for the ranks of `bench.py --gpus 8`, each folding its 125 M-record
         slice with job-global sequence numbers, then partials by owner, merge, evict owned (the route of the test above);
       * linearity against the stream itself: the evicted flows' bytes add up to the stream's (mod 2^64), their packets to the
         stream's (mod 2^32, the width of the field), their flags OR to the stream's, the latest end and the earliest non-zero
@@ -345,11 +345,12 @@ def test_configs3_at_its_full_size_one_billion_records(nf, O, torch):
     assert ev_b.shape[0] == n_distinct
     # ---- route A: one handle, the stream in eight calls
     with nf.FlowTable(max_entries=1 << 24) as tab:
-        # three calls, one per form of the partition queues' entries (csrc/nfagg_ingest_part.hip): 600 M records (>= 2^29: plain
-        # 32-bit indices, no retry rounds), 300 M (>= 2^28: index + sub-partition bits), 100 M (index + sub-partition bits + the
-        # "seventh unit needed" flag: pass 2 gathers six 16-byte units of a record whose dscp is zero)
+        # four calls, one per form of the partition queues' entries (csrc/nfagg_ingest_part.hip entry_idx_mask): 540 M records
+        # (>= 2^29: plain 32-bit indices, no retry rounds), 270 M (>= 2^28: index + sub-partition bits), 140 M (>= 2^27: + the
+        # "seventh unit needed" flag: pass 2 gathers six 16-byte units of a record whose dscp is zero), 50 M (+ the "sixth unit
+        # needed" flag: five units when sampling is zero too and dst_mac's first two bytes say that it is set)
         off = 0
-        for m in (600_000_000, 300_000_000, 100_000_000):
+        for m in (540_000_000, 270_000_000, 140_000_000, 50_000_000):
             assert tab.ingest_device(d.data_ptr() + off * 144, m) == (nf.OK, m)
             off += m
         assert off == n and len(tab) == n_distinct

@@ -423,3 +423,24 @@ def test_epoch_tags_wrap_after_65535_evictions(nf, O):
         for part in (b, a, b):                                             # epoch numbers 1 (again), 2, 3
             assert tab.ingest(part.view(nf.FLOW_RECORD)) == (nf.OK, len(part))
             assert_records_equal(nf.sort_by_key(tab.evict(nf.REASON_CLOSING)), O.run_accounter(part, 1000)[0][1])
+
+
+@pytest.mark.parametrize("ingest_variant", [10, 17])
+def test_spilled_records_gathered_in_five_six_or_seven_units(nf, O, ingest_variant):
+    """Pass 2 of the two-pass fold gathers only the 16-byte units of a spilled record that the fold needs (csrc/nfagg_ingest_part.hip
+    queue_entry): the seventh (bytes 96..111) only when dscp is non-zero, the sixth (80..95) only when sampling is non-zero or
+    dst_mac's first two bytes are zero while its last four are not — every combination here, with the MAC shapes the seeded streams
+    never produce (00:00:5e:.. — VRRP: zero first bytes, set last ones; all zero; only the first byte set), so that "first non-zero
+    dst_mac", "last non-zero sampling / dscp" (pkg/model/flow_content.go:48-59) are decided by records read in every one of the forms."""
+    n, keys = 300_000, 60_000
+    recs = O.gen_stream(n, seed=77, n_keys=keys, thresholds=O.zipf_thresholds(keys, 1.1), variant=0)
+    rng = np.random.default_rng(ingest_variant)
+    m = recs["metrics"]
+    shapes = np.array([[0, 0, 0, 0, 0, 0], [0, 0, 0x5e, 0, 1, 7], [2, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 9], [0x0a, 0x0b, 0x0c, 0x0d, 0x0e, 0x0f]], dtype=np.uint8)
+    m["dst_mac"] = shapes[rng.integers(0, len(shapes), n)]
+    m["src_mac"] = shapes[rng.integers(0, len(shapes), n)]
+    m["sampling"] = rng.choice(np.array([0, 0, 0, 50, 7], dtype=np.uint32), n)
+    m["dscp"] = rng.choice(np.array([0, 0, 0, 46, 10], dtype=np.uint8), n)
+    want = check_against_oracle(nf, O, recs, 1 << 17, 1 << 30, ingest_variant=ingest_variant)
+    ev = want[0][1]["metrics"]
+    assert (ev["sampling"] != 0).any() and (ev["dscp"] != 0).any() and (ev["dst_mac"][:, :2] == 0).all(axis=1).any()
