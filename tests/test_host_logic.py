@@ -194,3 +194,85 @@ def test_bench_line_never_reports_a_fraction_above_one():
     assert stale["frac_basis"] == "stream_floor" and stale["frac"] == 0.36 and stale["achieved"] == round(0.36 * bench.HBM_PEAK_GBS, 1)
     none = bench.frac_of_a_real_bound(dict(over, traffic=None, frac_traffic=None))
     assert none["frac_basis"] == "stream_floor" and none["frac"] <= 1.0
+
+
+def test_account_loop_batching_policy_on_cpu(O):
+    """The host loop of the Accounter mirror (netobserv-ebpf-agent_amd/accounter.py Account: the batching policy of INTEGRATION.md
+    section 3) with the flow table replaced by the oracle's — TEST scaffolding: the object is put together by hand here, the product's
+    constructor knows no table but libnfagg's. What the loop itself must guarantee whatever folds the records (account.go:58-100):
+    records received before a tick are accounted before the tick's eviction, closing accounts what was received and then evicts,
+    batches are flushed by size and by age, an eviction on full resets the ticker."""
+    import queue
+    import threading
+    import time
+    import netobserv_ebpf_agent_amd as nf
+    from netobserv_ebpf_agent_amd import accounter as A
+
+    class OracleTable:                                      # the three calls the loop makes, answered by oracle/nfagg_oracle.c
+        def __init__(self, max_entries):
+            self.acc, self.max_entries = O.Accounter(max_entries, 0), max_entries
+
+        def __len__(self):
+            return len(self.acc)
+
+        def account(self, records):
+            raw = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
+            n, off, epochs = len(raw) // 144, 0, []
+            while off < n:
+                off += self.acc.ingest(raw[off * 144:])
+                if off < n:
+                    epochs.append(self.acc.evict().view(nf.FLOW_RECORD))
+            return nf.OK, n, epochs
+
+        def evict(self, code):
+            return self.acc.evict().view(nf.FLOW_RECORD)
+
+        def close(self):
+            self.acc.close()
+
+    def make(max_entries, evict_timeout, batch_records, batch_timeout):
+        a = A.Accounter.__new__(A.Accounter)
+        a.maxEntries, a.evictTimeout, a.clock, a.monoClock, a.metrics = max_entries, evict_timeout, (lambda: 10**18), (lambda: 1000), A.NoOp()
+        a.batchRecords, a.batchTimeout, a.calls, a.table = batch_records, batch_timeout, 0, OracleTable(max_entries)
+        return a
+
+    recs = O.gen_stream(9, seed=3, n_keys=3)                  # three flows, three records each
+    one = lambda k: recs[k:k + 1].view(nf.FLOW_RECORD)
+    # by size: nothing is handed over before the third record; by age: the rest follows after batch_timeout
+    a = make(100, 3600.0, 3, 0.2)
+    inp, out = queue.Queue(), queue.Queue()
+    th = threading.Thread(target=a.Account, args=(inp, out), daemon=True)
+    th.start()
+    inp.put(one(0)); inp.put(one(1))
+    time.sleep(0.05)
+    assert a.calls == 0
+    inp.put(one(2))
+    time.sleep(0.1)
+    assert a.calls == 1 and len(a.table) == 3
+    inp.put(one(3))
+    time.sleep(0.5)
+    assert a.calls == 2                                       # the lone record went after 0.2 s
+    inp.put(one(4)); inp.put(A.CLOSE)                         # closing: the record is accounted, then everything is evicted
+    batch = out.get(timeout=5)
+    th.join(timeout=5)
+    assert a.calls == 3 and sum(int(r.Metrics["packets"]) for r in batch) == int(recs["metrics"]["packets"][:5].sum())
+    assert a.metrics.evictions_total == {("accounter", "closing"): 1}
+    # a tick accounts what waits first; an eviction on full happens at the record that finds the map full
+    a = make(2, 0.3, 1000, 30.0)
+    inp, out = queue.Queue(), queue.Queue()
+    th = threading.Thread(target=a.Account, args=(inp, out), daemon=True)
+    th.start()
+    for k in range(9):
+        inp.put(one(k))
+    first = out.get(timeout=5)                                # the tick flushed the nine records: the third flow found the map of 2 full
+    assert a.calls == 1 and len(first) == 2
+    assert a.metrics.evictions_total.get(("accounter", "full"), 0) >= 1
+    inp.put(A.CLOSE)
+    rest = []
+    while th.is_alive() or not out.empty():
+        try:
+            rest.append(out.get(timeout=1))
+        except queue.Empty:
+            pass
+    th.join(timeout=5)
+    assert sum(int(r.Metrics["packets"]) for b in [first] + rest for r in b) == int(recs["metrics"]["packets"].sum())
