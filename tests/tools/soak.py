@@ -19,7 +19,7 @@ while time.time() < t_end:
     hot = int(rng.choice([0, 0, 500, 900, 999]))
     dedup = bool(rng.integers(0, 4) == 0)
     variant = int(rng.choice([1, 2] if dedup else [1, 1, 1, 0]))       # stream variant: scrambled fields (2: interfaces for dedup)
-    ingest_variant = int(rng.choice([0, 0, 0, 7, 10, 11, 1])) if not dedup else int(rng.choice([0, 0, 1, 10, 16]))    # 16: partition pass sorted first
+    ingest_variant = int(rng.choice([0, 0, 0, 7, 10, 11, 1, 17])) if not dedup else int(rng.choice([0, 0, 1, 10, 16]))    # 16: partition pass sorted first
     max_entries = int(rng.choice([1 << 20, 1 << 23, max(2, keys // 3), keys + 5]))
     if max_entries < keys:          # evict-on-full: bound the number of eviction round trips of a round
         n = min(n, 50_000 if max_entries < 1000 else 2_000_000)
