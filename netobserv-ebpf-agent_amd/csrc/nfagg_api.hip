@@ -144,6 +144,7 @@ struct nfagg_handle {
     size_t d_par_cap[8] = {};
     hipStream_t par_stream = nullptr;
     hipEvent_t par_done = nullptr;
+    hipEvent_t par_part[16] = {};   // one behind every part of the cut walk (kParWalkPartsMax)
     nfagg_stats stats{};
     std::vector<EventPair> ev_pending;
     std::vector<EventPair> ev_free;
@@ -873,6 +874,7 @@ void nfagg_destroy(nfagg_handle* h) {
     if (h->h_par) hipHostFree(h->h_par);
     for (int k = 0; k < 8; k++) if (h->d_par[k]) hipFree(h->d_par[k]);
     if (h->par_done) hipEventDestroy(h->par_done);
+    for (int k = 0; k < 16; k++) if (h->par_part[k]) hipEventDestroy(h->par_part[k]);
     if (h->par_stream) hipStreamDestroy(h->par_stream);
     if (h->jv.hot) hipFree(h->jv.hot);
     if (h->jv.cold) hipFree(h->jv.cold);

@@ -386,7 +386,7 @@ NF_DEV void cut_block(int32_t cur[kCutPer], uint32_t wave_base_v, CutState& st, 
 // ordinary place for an epoch to go on across (the records of a block before the epoch's start were dead anyway).
 __global__ __launch_bounds__(kCutBlock) void k_par_cuts(const int32_t* __restrict__ prev, uint64_t n, uint32_t max_entries, uint32_t live0,
                                                         uint32_t* __restrict__ cuts, uint32_t max_cuts, uint32_t* __restrict__ ctl,
-                                                        uint64_t b_begin, uint64_t b_end) {
+                                                        uint64_t b_begin, uint64_t b_end, uint32_t* __restrict__ host_cuts, uint32_t* __restrict__ host_state) {
     __shared__ uint32_t wtot[2][kCutBlock / 64];                      // double-buffered by step parity: one barrier per step
     __shared__ uint32_t fnd[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -404,6 +404,7 @@ __global__ __launch_bounds__(kCutBlock) void k_par_cuts(const int32_t* __restric
         st.budget = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl[12]);
     }
     st.max_entries = max_entries; st.max_cuts = max_cuts;
+    const uint32_t k_begin = st.k;                                    // the cuts this part finds: [k_begin, st.k)
 #ifdef NFAGG_DIAG
     for (int k = 0; k < 8; k++) st.ph[k] = 0;
     st.tp = __builtin_readcyclecounter();
@@ -447,6 +448,18 @@ __global__ __launch_bounds__(kCutBlock) void k_par_cuts(const int32_t* __restric
     if (tid == 0) {
         ctl[0] = st.k; ctl[3] = st.before;
         ctl[8] = st.s; ctl[9] = st.k; ctl[10] = st.before; ctl[11] = st.first ? 1u : 0u; ctl[12] = st.budget;
+    }
+    // What the HOST needs of this part — the cuts it found, how far the walk is — goes straight into the host's pinned list: the
+    // parts of a walk are enqueued back to back with an event behind each, the host waits for the events and hands every part's
+    // epochs to the folds while the walk goes on; nothing of the walk waits for the host (it was a copy and a round trip per part:
+    // ~60 us of an idle walk each, profiles/r06x_walk_ungated.txt). host_state: a block of its own per part — the host reads part
+    // p's while part p + 1 runs.
+    if (host_cuts) {
+        __threadfence();                                              // lane 0's cuts[] stores, for the other lanes (read back past the vector cache)
+        __syncthreads();
+        for (uint32_t k = k_begin + (uint32_t)tid; k < st.k; k += kCutBlock)
+            host_cuts[k] = __atomic_load_n(&cuts[k], __ATOMIC_RELAXED);
+        if (tid == 0) { host_state[0] = st.k; host_state[1] = st.before; host_state[2] = __atomic_load_n(&ctl[1], __ATOMIC_RELAXED); host_state[3] = k_begin; }
     }
 }
 
@@ -927,10 +940,12 @@ hipError_t launch_par_live(const TableView& t, const void* d_records, int32_t* d
 
 // The walk over the blocks [b_begin, b_end) of par_cut_span() records each (k_par_cuts: b_begin > 0 resumes from the state in d_ctl);
 // b_end - b_begin: a multiple of four, b_end <= par_walk_blocks(n).
+// host_cuts / host_state: the host's pinned cut list and this part's four state words there ([0] cuts so far [1] new flows of the
+// epoch in progress [2] the links' overflow flag [3] cuts before this part), or null.
 hipError_t launch_par_cuts(const int32_t* d_prev, uint64_t n, uint32_t max_entries, uint32_t live0, uint32_t* d_cuts, uint32_t max_cuts,
-                           uint32_t* d_ctl, uint64_t b_begin, uint64_t b_end, hipStream_t s) {
+                           uint32_t* d_ctl, uint64_t b_begin, uint64_t b_end, uint32_t* host_cuts, uint32_t* host_state, hipStream_t s) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_par_cuts, dim3(1), dim3(kCutBlock), 0, s, d_prev, n, max_entries, live0, d_cuts, max_cuts, d_ctl, b_begin, b_end);
+    hipLaunchKernelGGL(k_par_cuts, dim3(1), dim3(kCutBlock), 0, s, d_prev, n, max_entries, live0, d_cuts, max_cuts, d_ctl, b_begin, b_end, host_cuts, host_state);
     return hipGetLastError();
 }
 uint64_t par_cut_span() { return kCutSpan; }

@@ -166,7 +166,7 @@ hipError_t launch_par_sort(void* temp, size_t* temp_bytes, const uint64_t* k_in,
 hipError_t launch_par_links(const void* d_records, const uint64_t* d_keys_sorted, uint64_t n, int32_t* d_prev, uint32_t* d_overflow, hipStream_t s);
 hipError_t launch_par_live(const TableView& t, const void* d_records, int32_t* d_prev, uint64_t n, hipStream_t s);
 hipError_t launch_par_cuts(const int32_t* d_prev, uint64_t n, uint32_t max_entries, uint32_t live0, uint32_t* d_cuts, uint32_t max_cuts,
-                           uint32_t* d_ctl, uint64_t b_begin, uint64_t b_end, hipStream_t s);
+                           uint32_t* d_ctl, uint64_t b_begin, uint64_t b_end, uint32_t* host_cuts, uint32_t* host_state, hipStream_t s);
 uint64_t par_cut_span();
 uint64_t par_walk_blocks(uint64_t n);
 uint64_t par_prev_entries(uint64_t n);
