@@ -41,6 +41,7 @@ constexpr uint32_t kParNone = 0xffffffffu;
 constexpr int kLinkSearch = 4096;                                     // records of OTHER flows with the same hash bits that k_par_links walks over before it gives up
 constexpr int kIdxBits = 24;                                          // a launch takes at most 2^24 records: the index's share of a sort key
 constexpr uint64_t kIdxMask = (1ull << kIdxBits) - 1ull, kHashMask = ~kIdxMask;   // ... and the key hash's: its top 40 bits
+constexpr int kSegUnroll = 4;                                         // record gathers a lane of the wave folds keeps in flight
 constexpr uint32_t kSegShort = 16;                                    // records per segment the one-lane fold takes
 constexpr uint32_t kSegHuge = 4096;                                   // positions per segment beyond which it is folded in CHUNKS, a wave per chunk (one wave for the whole segment up to here)
 constexpr uint32_t kHugeChunk = 2048;                                 // positions per chunk
@@ -754,14 +755,27 @@ NF_DEV uint64_t shfl_xor_u64(uint64_t v, int m) {
 NF_DEV void seg_gather(const void* __restrict__ recs, const uint64_t* __restrict__ ks, uint64_t first, uint64_t end, uint64_t step,
                        const uint64_t w[5], SegAcc& a) {
     a.clear();
-    for (uint64_t q = first; q < end; q += step) {
-        const uint32_t i2 = key_index(ks[q]);
-        Rec r;
-        load_record_head(recs, i2, r);
-        r.d[9] &= 0x00ffffffu;
-        uint64_t w2[5];
-        r.key_words(w2);
-        if (par_same_key(w, w2)) a.add(r, i2);
+    // kSegUnroll positions per lane and round, their loads issued together: with one gather in flight per lane a segment of the
+    // hottest flows was a chain of memory round trips (k_par_segfold_long 0.35 ms per part at 100 000 entries:
+    // profiles/r06x_walk_ungated.txt)
+    for (uint64_t q0 = first; q0 < end; q0 += kSegUnroll * step) {
+        uint32_t i2[kSegUnroll];
+        Rec r[kSegUnroll];
+#pragma unroll
+        for (int u = 0; u < kSegUnroll; u++) {
+            const uint64_t q = q0 + (uint64_t)u * step;
+            i2[u] = q < end ? key_index(ks[q]) : kParNone;
+        }
+#pragma unroll
+        for (int u = 0; u < kSegUnroll; u++) if (i2[u] != kParNone) load_record_head(recs, i2[u], r[u]);
+#pragma unroll
+        for (int u = 0; u < kSegUnroll; u++) {
+            if (i2[u] == kParNone) continue;
+            r[u].d[9] &= 0x00ffffffu;
+            uint64_t w2[5];
+            r[u].key_words(w2);
+            if (par_same_key(w, w2)) a.add(r[u], i2[u]);
+        }
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -860,16 +874,26 @@ __global__ __launch_bounds__(kParBlock) void k_par_huge_chunks(const void* __res
         // (positions are sorted: once a key reaches it, every later one does)
         SegAcc a;
         a.clear();
-        for (uint64_t q = lo + lane; q < hi; q += 64) {
-            const uint64_t k2 = ks[q];
-            if (k2 >= limit) break;
-            const uint32_t i2 = key_index(k2);
-            Rec r;
-            load_record_head(recs, i2, r);
-            r.d[9] &= 0x00ffffffu;
-            uint64_t w2[5];
-            r.key_words(w2);
-            if (par_same_key(w, w2)) a.add(r, i2);
+        for (uint64_t q0 = lo + lane; q0 < hi; q0 += 64u * kSegUnroll) {      // (kSegUnroll gathers in flight per lane: seg_gather)
+            uint32_t i2[kSegUnroll];
+            Rec r[kSegUnroll];
+#pragma unroll
+            for (int u = 0; u < kSegUnroll; u++) {
+                const uint64_t q = q0 + 64u * (uint64_t)u;
+                const uint64_t k2 = q < hi ? ks[q] : ~0ull;
+                i2[u] = k2 < limit ? key_index(k2) : kParNone;               // (sorted: once a key reaches the limit, every later one does)
+            }
+#pragma unroll
+            for (int u = 0; u < kSegUnroll; u++) if (i2[u] != kParNone) load_record_head(recs, i2[u], r[u]);
+#pragma unroll
+            for (int u = 0; u < kSegUnroll; u++) {
+                if (i2[u] == kParNone) continue;
+                r[u].d[9] &= 0x00ffffffu;
+                uint64_t w2[5];
+                r[u].key_words(w2);
+                if (par_same_key(w, w2)) a.add(r[u], i2[u]);
+            }
+            if (i2[kSegUnroll - 1] == kParNone) break;
         }
         seg_wave_combine(a);
         if (lane == 0) seg_pack(a, partials[c]);

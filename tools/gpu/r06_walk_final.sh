@@ -1,16 +1,16 @@
 # the un-gated cut walk at its final policy (4 parts below 7500 entries, 2 from there): parity, A/B against the tree before, soaks, timeline
-cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06walk; mkdir -p $O; rm -f $O/final_*.txt
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06walk5; mkdir -p $O; rm -f $O/final_*.txt
 timeout 1200 python -m pytest tests/test_account_par_gpu.py tests/test_isa_pins.py tests/test_parity_gpu.py -x -q -m gpu 2>&1 | tail -5 > $O/final_pytest.txt; cat $O/final_pytest.txt
 one() { python -c "import sys,json; j=json.loads(sys.stdin.read()); print('best %.3f median %.3f ms' % (j['ms_best'], j['ms_median']), j['evictions_per_call'], j['config']['evicted_flows_per_step'])"; }
 for rnd in 1 2; do
 for lib in libnfagg_prev.so libnfagg.so; do
-  for M in 1000 5000 10000 20000 100000; do
+  for M in 5000 10000 20000 50000 100000; do
     echo -n "$lib M=$M: " | tee -a $O/final_ab.txt
     NFAGG_LIB=$PWD/netobserv-ebpf-agent_amd/lib/$lib timeout 300 python tools/account_5000_prof.py --steps 12 --max-entries $M 2>/dev/null | one | tee -a $O/final_ab.txt
   done
 done
 done
-timeout 400 python tests/tools/soak_account_par.py 150 60000 2>&1 | tail -1 | tee $O/final_soak_a.txt
-timeout 400 python tests/tools/soak_account_par.py 150 70000 --large 2>&1 | tail -1 | tee $O/final_soak_b.txt
+timeout 400 python tests/tools/soak_account_par.py 120 100000 2>&1 | tail -1 | tee $O/final_soak_a.txt
+timeout 400 python tests/tools/soak_account_par.py 120 110000 --large 2>&1 | tail -1 | tee $O/final_soak_b.txt
 bash tools/gpu/r06_acc_timeline.sh 5000 > /dev/null 2>&1; cp gpurun_out/r06_acc_timeline_5000.txt $O/final_timeline_5000.txt
 bash tools/gpu/r06_acc_timeline.sh 100000 > /dev/null 2>&1; cp gpurun_out/r06_acc_timeline_100000.txt $O/final_timeline_100000.txt
