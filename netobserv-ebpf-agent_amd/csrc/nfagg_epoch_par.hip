@@ -42,10 +42,19 @@ constexpr int kLinkSearch = 4096;                                     // records
 constexpr int kIdxBits = 24;                                          // a launch takes at most 2^24 records: the index's share of a sort key
 constexpr uint64_t kIdxMask = (1ull << kIdxBits) - 1ull, kHashMask = ~kIdxMask;   // ... and the key hash's: its top 40 bits
 constexpr int kSegUnroll = 4;                                         // record gathers a lane of the wave folds keeps in flight
-constexpr uint32_t kSegShort = 16;                                    // records per segment the one-lane fold takes
-constexpr uint32_t kSegHuge = 4096;                                   // positions per segment beyond which it is folded in CHUNKS, a wave per chunk (one wave for the whole segment up to here)
-constexpr uint32_t kHugeChunk = 2048;                                 // positions per chunk
-constexpr uint32_t kHugeCap = 8192;                                   // entries of the list of such segments (disjoint runs of > kSegHuge positions: <= 2^24 / 4097 per launch)
+#ifndef NF_SEG_SHORT                                                  // (the three thresholds can be set on the compiler's command line: tools/gpu/r06_seg_sweep.sh)
+#define NF_SEG_SHORT 16
+#endif
+#ifndef NF_SEG_HUGE
+#define NF_SEG_HUGE 4096
+#endif
+#ifndef NF_HUGE_CHUNK
+#define NF_HUGE_CHUNK 2048
+#endif
+constexpr uint32_t kSegShort = NF_SEG_SHORT;                                    // records per segment the one-lane fold takes
+constexpr uint32_t kSegHuge = NF_SEG_HUGE;                                   // positions per segment beyond which it is folded in CHUNKS, a wave per chunk (one wave for the whole segment up to here)
+constexpr uint32_t kHugeChunk = NF_HUGE_CHUNK;                                 // positions per chunk
+constexpr uint32_t kHugeCap = (1u << 24) / (kSegHuge + 1u) + 4097u;                                   // entries of the list of such segments (disjoint runs of > kSegHuge positions: <= 2^24 / 4097 per launch)
 constexpr uint32_t kHugeChunkCap = (1u << 24) / kHugeChunk + kHugeCap;   // ... and of their chunks: every segment ends with one partly filled chunk
 
 static inline int par_grid(uint64_t n, int per_block = kParBlock, int cap = 1 << 20) {
