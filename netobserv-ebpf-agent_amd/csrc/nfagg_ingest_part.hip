@@ -31,7 +31,10 @@ namespace part {
 
 constexpr int kBlock = 1024;
 constexpr int kEntries = 1024;
-constexpr int kProbe = 8;         // cache probe window
+#ifndef NF_PART_PROBE                // (settable on the compiler's command line: tools/gpu/r06_probe_sweep.sh)
+#define NF_PART_PROBE 8
+#endif
+constexpr int kProbe = NF_PART_PROBE;   // cache probe window
 constexpr int kStage = 4;         // staged spills per partition = one 16-byte store
 
 // 116 bytes per entry, laid out as arrays of 16-BYTE UNITS so that phase B reads an entry's key with three ds_read_b128 and its
